@@ -1,0 +1,352 @@
+"""TEST INFRASTRUCTURE — ctypes bindings for the oracle (oracle/liboracle.so, the CPU restatement of
+the reference's hot path) and for oracle/_ref/libref.so (the reference's own ggml-free code).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (tortoise.cpp_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """Compile liboracle.so (and _ref/libref.so when /root/reference exists)."""
+    so = os.path.join(HERE, "liboracle.so")
+    if force or not os.path.exists(so) or any(
+        os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(so)
+        for f in os.listdir(HERE) if f.endswith((".cpp", ".h"))
+    ):
+        subprocess.check_call(["make", "-C", HERE, "-j8", "liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.exists("/root/reference/main.cpp"):
+        ref = os.path.join(HERE, "_ref", "libref.so")
+        if force or not os.path.exists(ref) or os.path.getmtime(os.path.join(HERE, "ref_shim.cpp")) > os.path.getmtime(ref):
+            subprocess.check_call(["bash", os.path.join(HERE, "build_ref.sh")], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(os.path.join(HERE, "liboracle.so"))
+        vp = C.c_void_p
+        sig = {
+            "orc_rng_new": (vp, [C.c_uint32]), "orc_rng_free": (None, [vp]),
+            "orc_rng_seed": (None, [vp, C.c_uint32]), "orc_rng_load_state": (C.c_int, [vp, C.c_char_p]),
+            "orc_rng_u32": (C.c_uint32, [vp]), "orc_rng_uniform": (C.c_float, [vp]),
+            "orc_rng_normal_fill": (None, [vp, _f32p, C.c_int64]),
+            "orc_sample": (None, [_f32p, _i32p, C.c_int, C.c_int, vp, _i32p, vp]),
+            "orc_buckets": (None, [C.c_int, _i32p]),
+            "orc_timestep_embedding": (None, [C.c_int, _f32p]),
+            "orc_schedule": (None, [_i32p, C.c_int] + [_f64p] * 7),
+            "orc_default_timestep_map": (None, [C.c_int, _i32p]),
+            "orc_diffusion_update": (None, [_i32p, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int]),
+            "orc_apply_padding": (None, [_i32p, C.c_int, _i32p]),
+            "orc_trimmed_rows": (C.c_int, [_i32p]),
+            "orc_tokenizer_new": (vp, [C.c_char_p]), "orc_tokenizer_free": (None, [vp]),
+            "orc_tokenizer_vocab_size": (C.c_int, [vp]),
+            "orc_tokenize": (C.c_int, [vp, C.c_char_p, _i32p, C.c_int]),
+            "orc_set_flags": (None, [C.c_float, C.c_int]), "orc_f16_round": (C.c_float, [C.c_float]),
+            "orc_model_load": (vp, [C.c_char_p]), "orc_model_free": (None, [vp]),
+            "orc_model_get": (C.c_int, [vp, C.c_char_p, vp, C.c_int64]),
+            "orc_ar_new": (vp, [vp]), "orc_ar_free": (None, [vp]), "orc_ar_layers": (C.c_int, [vp]),
+            "orc_ar_start": (None, [vp, _i32p, C.c_int, _f32p, C.c_int, C.c_int]),
+            "orc_ar_prefill": (None, [vp, _f32p]), "orc_ar_step": (None, [vp, _i32p, C.c_int, _f32p]),
+            "orc_ar_latents": (None, [vp, _i32p, C.c_int, C.c_int, _f32p]),
+            "orc_autoregressive": (C.c_int, [vp, _i32p, C.c_int, _f32p, C.c_int, vp, C.c_int, C.c_int, _i32p, _i32p, vp]),
+            "orc_diff_new": (vp, [vp]), "orc_diff_free": (None, [vp]), "orc_diff_T": (C.c_int, [C.c_int]),
+            "orc_diff_code_embedding": (None, [vp, _f32p, C.c_int, C.c_int, _f32p]),
+            "orc_diff_forward": (None, [vp, vp, _f32p, C.c_int, C.c_int, _f32p]),
+            "orc_diffusion": (None, [vp, _f32p, C.c_int, C.c_int, vp, vp, _f32p]),
+            "orc_voc_new": (vp, [vp]), "orc_voc_free": (None, [vp]), "orc_voc_audio_len": (C.c_int, [C.c_int]),
+            "orc_denormalize_mel": (None, [_f32p, C.c_int64]),
+            "orc_voc_forward": (None, [vp, _f32p, C.c_int, _f32p, _f32p]),
+            "orc_vocoder": (None, [vp, _f32p, C.c_int, vp, vp, _f32p]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Rng:
+    def __init__(self, seed=0):
+        self.h = lib().orc_rng_new(seed)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_rng_free(self.h)
+            self.h = None
+
+    def seed(self, s):
+        lib().orc_rng_seed(self.h, s)
+
+    def load_state(self, path):
+        assert lib().orc_rng_load_state(self.h, path.encode()) == 0
+
+    def u32(self):
+        return lib().orc_rng_u32(self.h)
+
+    def uniform(self):
+        return lib().orc_rng_uniform(self.h)
+
+    def normal(self, n):
+        out = np.empty(n, np.float32)
+        lib().orc_rng_normal_fill(self.h, out, n)
+        return out
+
+
+def sample(logits, ids, rng, want_probs=False):
+    """logits [B,8194] f32; ids [B,k] int32 (penalised ids). Returns samples[B] (and probs)."""
+    logits = np.ascontiguousarray(logits, np.float32)
+    ids = np.ascontiguousarray(ids, np.int32)
+    B = logits.shape[0]
+    out = np.empty(B, np.int32)
+    probs = np.empty((B, 8194), np.float32) if want_probs else None
+    lib().orc_sample(logits, ids.reshape(-1), ids.size, B, rng.h, out, _ptr(probs))
+    return (out, probs) if want_probs else out
+
+
+def buckets(n):
+    out = np.empty((n, n), np.int32)
+    lib().orc_buckets(n, out.reshape(-1))
+    return out
+
+
+def timestep_embedding(t):
+    out = np.empty(1024, np.float32)
+    lib().orc_timestep_embedding(t, out)
+    return out
+
+
+def default_timestep_map(steps=80):
+    out = np.empty(steps, np.int32)
+    lib().orc_default_timestep_map(steps, out)
+    return out
+
+
+SCHED_KEYS = ["betas", "acp", "post_logvar", "coef1", "coef2", "sqrt_recip", "sqrt_recipm1"]
+
+
+def schedule(tm):
+    tm = np.ascontiguousarray(tm, np.int32)
+    arrs = [np.empty(len(tm), np.float64) for _ in range(7)]
+    lib().orc_schedule(tm, len(tm), *arrs)
+    return dict(zip(SCHED_KEYS, arrs))
+
+
+def diffusion_update(tm, t, out_cond, out_uncond, x, noise, T):
+    tm = np.ascontiguousarray(tm, np.int32)
+    x = np.array(x, np.float32).reshape(-1).copy()
+    lib().orc_diffusion_update(tm, len(tm), t, np.ascontiguousarray(out_cond, np.float32).reshape(-1),
+                               np.ascontiguousarray(out_uncond, np.float32).reshape(-1), x,
+                               np.ascontiguousarray(noise, np.float32).reshape(-1), T)
+    return x
+
+
+def apply_padding(codes):
+    codes = np.ascontiguousarray(codes, np.int32)
+    out = np.empty(502, np.int32)
+    lib().orc_apply_padding(codes, len(codes), out)
+    return out
+
+
+def trimmed_rows(codes502):
+    return lib().orc_trimmed_rows(np.ascontiguousarray(codes502, np.int32))
+
+
+class Tokenizer:
+    def __init__(self, json_path):
+        self.h = lib().orc_tokenizer_new(json_path.encode())
+        assert self.h, json_path
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_tokenizer_free(self.h)
+            self.h = None
+
+    def encode(self, msg):
+        out = np.empty(4096, np.int32)
+        n = lib().orc_tokenize(self.h, msg.encode("utf-8"), out, 4096)
+        return out[:n].copy()
+
+
+def set_flags(gn_eps=1e-6, lut=0):
+    lib().orc_set_flags(gn_eps, lut)
+
+
+class Model:
+    def __init__(self, path):
+        self.h = lib().orc_model_load(path.encode())
+        if not self.h:
+            raise IOError("oracle: cannot load " + path)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_model_free(self.h)
+            self.h = None
+
+    def tensor(self, name):
+        n = lib().orc_model_get(self.h, name.encode(), None, 0)
+        if n < 0:
+            raise KeyError(name)
+        out = np.empty(n, np.float32)
+        lib().orc_model_get(self.h, name.encode(), _ptr(out), n)
+        return out
+
+
+class AR:
+    """Oracle autoregressive stage (orc_ar.cpp)."""
+    V = 8194
+
+    def __init__(self, model):
+        self.model = model
+        self.h = lib().orc_ar_new(model.h)
+        self.B = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_ar_free(self.h)
+            self.h = None
+
+    @property
+    def n_layers(self):
+        return lib().orc_ar_layers(self.h)
+
+    def start(self, tokens, voice, B, max_pos):
+        self.B = B
+        lib().orc_ar_start(self.h, np.ascontiguousarray(tokens, np.int32), len(tokens),
+                           np.ascontiguousarray(voice, np.float32), B, max_pos)
+
+    def prefill(self):
+        out = np.empty((self.B, self.V), np.float32)
+        lib().orc_ar_prefill(self.h, out.reshape(-1))
+        return out
+
+    def step(self, toks, i):
+        out = np.empty((self.B, self.V), np.float32)
+        lib().orc_ar_step(self.h, np.ascontiguousarray(toks, np.int32), i, out.reshape(-1))
+        return out
+
+    def latents(self, codes502, n_mel=502):
+        codes502 = np.ascontiguousarray(codes502, np.int32).reshape(-1, 502)
+        nb = codes502.shape[0]
+        n_out = min(500, n_mel)
+        out = np.empty((nb, n_out, 1024), np.float32)
+        lib().orc_ar_latents(self.h, codes502.reshape(-1), nb, n_mel, out.reshape(-1))
+        return out
+
+    def generate(self, tokens, voice, B, rng, max_steps, mask_stop=False):
+        codes = np.empty((B, 502), np.int32)
+        steps = np.zeros(1, np.int32)
+        raw = np.full((B, max_steps), -1, np.int32)
+        self.B = B
+        rc = lib().orc_autoregressive(self.h, np.ascontiguousarray(tokens, np.int32), len(tokens),
+                                      np.ascontiguousarray(voice, np.float32), B, rng.h, max_steps,
+                                      1 if mask_stop else 0, codes.reshape(-1), steps, _ptr(raw))
+        return rc, codes, int(steps[0]), raw
+
+
+class Diffusion:
+    def __init__(self, model):
+        self.model = model
+        self.h = lib().orc_diff_new(model.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_diff_free(self.h)
+            self.h = None
+
+    @staticmethod
+    def T_of(L):
+        return lib().orc_diff_T(L)
+
+    def code_embedding(self, latents, T):
+        latents = np.ascontiguousarray(latents, np.float32).reshape(-1, 1024)
+        out = np.empty((T, 1024), np.float32)
+        lib().orc_diff_code_embedding(self.h, latents.reshape(-1), latents.shape[0], T, out.reshape(-1))
+        return out
+
+    def forward(self, code_emb, x_t, timestep):
+        """x_t [100,T]; returns [200,T]."""
+        x_t = np.ascontiguousarray(x_t, np.float32)
+        T = x_t.shape[1]
+        out = np.empty((200, T), np.float32)
+        ce = None if code_emb is None else np.ascontiguousarray(code_emb, np.float32)
+        lib().orc_diff_forward(self.h, _ptr(ce), x_t.reshape(-1), T, timestep, out.reshape(-1))
+        return out
+
+    def sample(self, latents, n_steps=80, rng=None, noise=None):
+        latents = np.ascontiguousarray(latents, np.float32).reshape(-1, 1024)
+        L = latents.shape[0]
+        T = self.T_of(L)
+        mel = np.empty((100, T), np.float32)
+        nz = None if noise is None else np.ascontiguousarray(noise, np.float32)
+        lib().orc_diffusion(self.h, latents.reshape(-1), L, n_steps, rng.h if rng else None, _ptr(nz), mel.reshape(-1))
+        return mel
+
+
+class Vocoder:
+    def __init__(self, model):
+        self.model = model
+        self.h = lib().orc_voc_new(model.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_voc_free(self.h)
+            self.h = None
+
+    def run(self, mel, rng=None, noise=None):
+        """mel [100,T] normalised; noise [64,T+10] or drawn from rng. Returns audio."""
+        mel = np.ascontiguousarray(mel, np.float32)
+        T = mel.shape[1]
+        audio = np.empty(lib().orc_voc_audio_len(T), np.float32)
+        nz = None if noise is None else np.ascontiguousarray(noise, np.float32)
+        lib().orc_vocoder(self.h, mel.reshape(-1), T, rng.h if rng else None, _ptr(nz), audio)
+        return audio
+
+
+# ---------------------------------------------------------------------------------------------
+# The real reference code (only where /root/reference existed at build time).
+# ---------------------------------------------------------------------------------------------
+_ref = None
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        build()
+        p = os.path.join(HERE, "_ref", "libref.so")
+        if not os.path.exists(p):
+            return None
+        R = C.CDLL(p)
+        R.ref_uniform.restype = C.c_float
+        R.ref_raw_u32.restype = C.c_uint32
+        R.ref_normal_fill.argtypes = [_f32p, C.c_int]
+        R.ref_process_logits_and_sample.argtypes = [_f32p, _i32p, C.c_int, C.c_int, _i32p, C.c_void_p]
+        R.ref_buckets.argtypes = [C.c_int, _i32p]
+        R.ref_timestep_embedding.argtypes = [C.c_int, _f32p]
+        R.ref_schedule.argtypes = [_i32p, C.c_int] + [_f64p] * 7
+        R.ref_diffusion_update.argtypes = [_f32p, _f32p, _f32p, _f32p, C.c_int] + [C.c_float] * 7 + [C.c_int]
+        R.ref_denormalize_mel.argtypes = [_f32p, C.c_int]
+        R.ref_apply_padding.argtypes = [_i32p, C.c_int, _i32p]
+        R.ref_trim_latents.argtypes = [_f32p, _i32p, C.c_int, _f32p, _i32p]
+        R.ref_tokenizer_init.argtypes = [C.c_char_p]
+        R.ref_tokenize.argtypes = [C.c_char_p, _i32p, C.c_int]
+        R.ref_load_rng_state.argtypes = [C.c_char_p]
+        _ref = R
+    return _ref

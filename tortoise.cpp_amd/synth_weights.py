@@ -1,0 +1,183 @@
+"""Writer for the reference's weight container + a seeded synthetic-weight generator.
+
+File format (what the reference loaders read, /root/reference/main.cpp:811-888, 1545-1625,
+1932-2012): little-endian; u32 magic 0x67676d6c; then records until EOF:
+    i32 n_dims, i32 name_len, i32 ttype (0 = F32), i32 ne[n_dims] (ne[0] = innermost = last
+    PyTorch dim), name bytes, raw data. No padding, no hparams block.
+
+Tensor names/shapes are the reference's (main.cpp:682-792, 1244-1536, 1808-1923; SURVEY.md
+Appendix A). The trained weights are not available offline, so tests and bench use these synthetic
+ones (fixed seed). Layer counts may be reduced for fast tests: both this engine and the oracle
+discover them from the file (the reference hard-codes 30 / 4+3+10+3 / 3x4).
+"""
+import struct
+import numpy as np
+
+MAGIC = 0x67676D6C
+
+
+class GgmlWriter:
+    def __init__(self, path):
+        self.f = open(path, "wb")
+        self.f.write(struct.pack("<I", MAGIC))
+
+    def add(self, name, arr):
+        """arr: numpy float32 in PyTorch dim order (outermost first)."""
+        arr = np.ascontiguousarray(arr, np.float32)
+        ne = list(arr.shape[::-1])
+        nb = name.encode()
+        self.f.write(struct.pack("<iii", len(ne), len(nb), 0))
+        self.f.write(struct.pack("<%di" % len(ne), *ne))
+        self.f.write(nb)
+        self.f.write(arr.tobytes())
+
+    def close(self):
+        self.f.close()
+
+
+def read_ggml(path):
+    """Returns {name: ndarray (PyTorch dim order)}. Used by tests."""
+    out = {}
+    with open(path, "rb") as f:
+        (magic,) = struct.unpack("<I", f.read(4))
+        assert magic == MAGIC
+        while True:
+            hdr = f.read(12)
+            if len(hdr) < 12:
+                break
+            n_dims, ln, tt = struct.unpack("<iii", hdr)
+            ne = struct.unpack("<%di" % n_dims, f.read(4 * n_dims))
+            name = f.read(ln).decode()
+            n = int(np.prod(ne))
+            out[name] = np.frombuffer(f.read(4 * n), np.float32).reshape(ne[::-1]).copy()
+    return out
+
+
+class _Gen:
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+
+    def normal(self, shape, std):
+        return self.rng.standard_normal(shape, dtype=np.float32) * np.float32(std)
+
+    def lecun(self, shape, fan_in, gain=1.0):
+        return self.normal(shape, gain / np.sqrt(fan_in))
+
+    def gamma(self, n):
+        return (1.0 + self.normal((n,), 0.05)).astype(np.float32)
+
+    def beta(self, n):
+        return self.normal((n,), 0.05)
+
+
+def write_ar(path, n_layers=30, seed=1234):
+    """ggml-model.bin: GPT-2 30x1024 (main.cpp:682-792)."""
+    g = _Gen(seed)
+    w = GgmlWriter(path)
+    D = 1024
+    w.add("text_embedding.weight", g.normal((256, D), 0.02))
+    w.add("text_pos_embedding.emb.weight", g.normal((404, D), 0.02))
+    w.add("mel_embedding.weight", g.normal((8194, D), 0.02))
+    w.add("mel_pos_embedding.emb.weight", g.normal((608, D), 0.02))
+    rs = 1.0 / np.sqrt(2.0 * n_layers)
+    for i in range(n_layers):
+        p = "inference_model.transformer.h.%d." % i
+        w.add(p + "ln_1.weight", g.gamma(D)); w.add(p + "ln_1.bias", g.beta(D))
+        # HF Conv1D: PyTorch [in][out]  (ggml ne = [out, in])
+        w.add(p + "attn.c_attn.weight", g.normal((D, 3 * D), 0.02)); w.add(p + "attn.c_attn.bias", g.normal((3 * D,), 0.02))
+        w.add(p + "attn.c_proj.weight", g.normal((D, D), 0.02 * rs)); w.add(p + "attn.c_proj.bias", g.normal((D,), 0.02))
+        w.add(p + "ln_2.weight", g.gamma(D)); w.add(p + "ln_2.bias", g.beta(D))
+        w.add(p + "mlp.c_fc.weight", g.normal((D, 4 * D), 0.02)); w.add(p + "mlp.c_fc.bias", g.normal((4 * D,), 0.02))
+        w.add(p + "mlp.c_proj.weight", g.normal((4 * D, D), 0.02 * rs)); w.add(p + "mlp.c_proj.bias", g.normal((D,), 0.02))
+    w.add("inference_model.transformer.ln_f.weight", g.gamma(D)); w.add("inference_model.transformer.ln_f.bias", g.beta(D))
+    w.add("inference_model.lm_head.0.weight", g.gamma(D)); w.add("inference_model.lm_head.0.bias", g.beta(D))
+    # nn.Linear: PyTorch [out][in]; a larger std gives a peaked (non-uniform) token distribution
+    w.add("inference_model.lm_head.1.weight", g.normal((8194, D), 0.08)); w.add("inference_model.lm_head.1.bias", g.normal((8194,), 0.02))
+    w.close()
+
+
+def _add_attn(w, g, p, D=1024):
+    w.add(p + ".norm.weight", g.gamma(D)); w.add(p + ".norm.bias", g.beta(D))
+    w.add(p + ".qkv.weight", g.lecun((3 * D, D), D, 1.0)); w.add(p + ".qkv.bias", g.normal((3 * D,), 0.02))
+    w.add(p + ".proj_out.weight", g.lecun((D, D), D, 0.5)); w.add(p + ".proj_out.bias", g.normal((D,), 0.02))
+    w.add(p + ".relative_pos_embeddings.relative_attention_bias.weight", g.normal((32, 16), 0.1))
+
+
+def _add_res(w, g, p, D=1024):
+    w.add(p + ".in_layers.0.weight", g.gamma(D)); w.add(p + ".in_layers.0.bias", g.beta(D))
+    w.add(p + ".in_layers.2.weight", g.lecun((D, D), D, 1.0)); w.add(p + ".in_layers.2.bias", g.normal((D,), 0.02))
+    w.add(p + ".emb_layers.1.weight", g.lecun((2 * D, D), D, 0.5)); w.add(p + ".emb_layers.1.bias", g.normal((2 * D,), 0.02))
+    w.add(p + ".out_layers.0.weight", g.gamma(D)); w.add(p + ".out_layers.0.bias", g.beta(D))
+    w.add(p + ".out_layers.3.weight", g.lecun((D, D, 3), 3 * D, 0.5)); w.add(p + ".out_layers.3.bias", g.normal((D,), 0.02))
+
+
+def write_diffusion(path, n_main=10, n_tail=3, n_integ=3, n_lc=4, seed=1235):
+    """ggml-diffusion-model.bin (main.cpp:1244-1536)."""
+    g = _Gen(seed)
+    w = GgmlWriter(path)
+    D = 1024
+    w.add("diffusion_conditioning_latent", g.normal((1, 2 * D), 0.1))
+    w.add("latent_conditioner.0.weight", g.lecun((D, D, 3), 3 * D, 1.0)); w.add("latent_conditioner.0.bias", g.normal((D,), 0.02))
+    for i in range(1, 1 + n_lc):
+        _add_attn(w, g, "latent_conditioner.%d" % i)
+    w.add("code_norm.weight", g.gamma(D)); w.add("code_norm.bias", g.beta(D))
+    w.add("time_embed.0.weight", g.lecun((D, D), D, 1.0)); w.add("time_embed.0.bias", g.normal((D,), 0.02))
+    w.add("time_embed.2.weight", g.lecun((D, D), D, 1.0)); w.add("time_embed.2.bias", g.normal((D,), 0.02))
+    for i in range(n_integ):
+        _add_res(w, g, "conditioning_timestep_integrator.%d.resblk" % i)
+        _add_attn(w, g, "conditioning_timestep_integrator.%d.attn" % i)
+    w.add("inp_block.weight", g.lecun((D, 100, 3), 300, 1.0)); w.add("inp_block.bias", g.normal((D,), 0.02))
+    w.add("integrating_conv.weight", g.lecun((D, 2 * D), 2 * D, 1.0)); w.add("integrating_conv.bias", g.normal((D,), 0.02))
+    for i in range(n_main):
+        _add_res(w, g, "layers.%d.resblk" % i)
+        _add_attn(w, g, "layers.%d.attn" % i)
+    for i in range(n_main, n_main + n_tail):
+        _add_res(w, g, "layers.%d" % i)
+    w.add("out.0.weight", g.gamma(D)); w.add("out.0.bias", g.beta(D))
+    w.add("out.2.weight", g.lecun((200, D, 3), 3 * D, 0.5)); w.add("out.2.bias", g.normal((200,), 0.02))
+    w.add("unconditioned_embedding", g.normal((1, D, 1), 0.5).reshape(D))
+    w.close()
+
+
+def write_vocoder(path, seed=1236):
+    """ggml-vocoder-model.bin: UnivNet (main.cpp:1808-1923)."""
+    g = _Gen(seed)
+    w = GgmlWriter(path)
+    w.add("conv_pre.weight", g.lecun((32, 64, 7), 448, 1.0)); w.add("conv_pre.bias", g.normal((32,), 0.02))
+    strides = [8, 8, 4]
+    for i in range(3):
+        p = "res_stack.%d." % i
+        kp = p + "kernel_predictor."
+        w.add(kp + "input_conv.0.weight", g.lecun((64, 100, 5), 500, 0.3)); w.add(kp + "input_conv.0.bias", g.normal((64,), 0.02))
+        for c in range(3):
+            for j in (1, 3):
+                w.add(kp + "residual_convs.%d.%d.weight" % (c, j), g.lecun((64, 64, 3), 192, 0.7))
+                w.add(kp + "residual_convs.%d.%d.bias" % (c, j), g.normal((64,), 0.02))
+        w.add(kp + "kernel_conv.weight", g.lecun((24576, 64, 3), 192, 0.1)); w.add(kp + "kernel_conv.bias", g.normal((24576,), 0.02))
+        w.add(kp + "bias_conv.weight", g.lecun((256, 64, 3), 192, 0.3)); w.add(kp + "bias_conv.bias", g.normal((256,), 0.02))
+        K = 2 * strides[i]
+        # ConvTranspose1d: PyTorch [Cin][Cout][K]
+        w.add(p + "convt_pre.1.weight", g.lecun((32, 32, K), 32 * 2, 1.0)); w.add(p + "convt_pre.1.bias", g.normal((32,), 0.02))
+        for c in range(4):
+            w.add(p + "conv_blocks.%d.1.weight" % c, g.lecun((32, 32, 3), 96, 1.0)); w.add(p + "conv_blocks.%d.1.bias" % c, g.normal((32,), 0.02))
+    w.add("conv_post.1.weight", g.lecun((1, 32, 7), 224, 0.5).reshape(32, 7)); w.add("conv_post.1.bias", g.normal((1,), 0.02))
+    w.close()
+
+
+def write_all(out_dir, ar_layers=30, diff_main=10, diff_tail=3, diff_integ=3, diff_lc=4, seed=1234):
+    import os
+    os.makedirs(out_dir, exist_ok=True)
+    write_ar(os.path.join(out_dir, "ggml-model.bin"), ar_layers, seed)
+    write_diffusion(os.path.join(out_dir, "ggml-diffusion-model.bin"), diff_main, diff_tail, diff_integ, diff_lc, seed + 1)
+    write_vocoder(os.path.join(out_dir, "ggml-vocoder-model.bin"), seed + 2)
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("out_dir")
+    ap.add_argument("--ar-layers", type=int, default=30)
+    ap.add_argument("--diff-main", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=1234)
+    a = ap.parse_args()
+    write_all(a.out_dir, a.ar_layers, a.diff_main, seed=a.seed)
