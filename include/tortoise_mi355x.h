@@ -1,0 +1,152 @@
+/*
+ * tortoise_mi355x.h — C ABI of the MI355X-native Tortoise-TTS hot path.
+ *
+ * The reference (balisujohn/tortoise.cpp) exports no library API: its three stage drivers talk to
+ * the tensor runtime through the ggml backend seam — named graph inputs set with
+ * ggml_backend_tensor_set, one blocking ggml_backend_graph_compute, the result fetched with
+ * ggml_backend_tensor_get. Each entry point below replaces one such
+ * {set inputs, compute, get output} group; the reference call sites are cited per function
+ * (file:line in /root/reference). INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions: plain C types only; the caller owns every host buffer; all calls are synchronous
+ * (results are valid on return); no exceptions cross the boundary — functions return TTS_OK (0)
+ * or a negative tts_status and tts_last_error() describes the failure. One tts_ctx per GPU and
+ * per host thread (the reference is single-threaded with global state, main.cpp:47-50).
+ *
+ * Layouts follow the reference's host vectors: logits [B][8194]; latents [rows][1024];
+ * x_t / mel [100][T] (time fastest); network output [200][T]; vocoder noise [64][T+10]; audio
+ * [(T+10)*256-6].
+ */
+#ifndef TORTOISE_MI355X_H
+#define TORTOISE_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tts_ctx tts_ctx;
+
+typedef enum {
+  TTS_OK = 0,
+  TTS_ERR_ARG = -1,    /* bad argument / call order */
+  TTS_ERR_IO = -2,     /* cannot open / truncated file */
+  TTS_ERR_FORMAT = -3, /* bad magic, unknown tensor name, wrong shape (main.cpp:834-873) */
+  TTS_ERR_HIP = -4,    /* HIP runtime failure (no device, OOM, launch error) */
+  TTS_ERR_STATE = -5,  /* stage not loaded / begin() not called */
+  TTS_ERR_LIMIT = -6   /* exceeds a reference limit (404 text/608 mel positions, 500 codes) */
+} tts_status;
+
+enum { TTS_VOCAB_MEL = 8194, TTS_DMODEL = 1024, TTS_MEL_CH = 100, TTS_CODES = 502 };
+
+/* ---- lifecycle --------------------------------------------------------------------------- */
+/* replaces ggml_backend_cuda_init(0) (main.cpp:651, 1213, 1777). device = HIP ordinal; returns NULL
+ * when there is no such device. device = -1 gives a host-only context (tokenizer, RNG, sampler):
+ * every stage call on it fails with TTS_ERR_HIP — there is no CPU compute path. */
+tts_ctx *tts_create(int device);
+void tts_destroy(tts_ctx *ctx);
+const char *tts_last_error(const tts_ctx *ctx);
+/* Options (all have reference defaults): "gn_eps" (1e-6; ggml's GroupNorm epsilon),
+ * "ggml_lut" (0/1: emulate ggml-CPU fp16 lookup tables for GELU/SiLU),
+ * "ar_exact_prefill" (1: prefill/latent GEMMs in exact f32; 0: split-fp16 MFMA). */
+int tts_set_option(tts_ctx *ctx, const char *key, double value);
+
+/* ---- weight files (drop-in format: magic 0x67676d6c + name-keyed F32 records) ------------- */
+/* autoregressive_model_load, main.cpp:482-897 */
+int tts_load_ar(tts_ctx *ctx, const char *path);
+/* diffusion_model_load, main.cpp:931-1634 */
+int tts_load_diffusion(tts_ctx *ctx, const char *path);
+/* vocoder_model_load, main.cpp:1665-2021 */
+int tts_load_vocoder(tts_ctx *ctx, const char *path);
+/* number of transformer / main diffusion layers found in the file (30 / 10 for real weights) */
+int tts_ar_layers(const tts_ctx *ctx);
+int tts_diffusion_layers(const tts_ctx *ctx);
+
+/* ---- RNG (main.cpp:47-50, 6546): std::mt19937 + uniform<float> + normal<double> ------------ */
+void tts_seed(tts_ctx *ctx, uint32_t seed);
+/* libstdc++ text state ("fin >> generator", main.cpp:6260-6262, 6475-6477) */
+int tts_rng_load_state(tts_ctx *ctx, const char *path);
+float tts_rng_uniform(tts_ctx *ctx);
+void tts_rng_normal(tts_ctx *ctx, float *out, int64_t n);
+
+/* ---- host front-end (common.cpp:166-339, main.cpp:6559-6567) ------------------------------- */
+int tts_tokenizer_load(tts_ctx *ctx, const char *tokenizer_json);
+/* " " -> "[SPACE]", greedy longest match, wrapped with 255 ... 0. Returns the id count. */
+int tts_tokenize(tts_ctx *ctx, const char *message, int32_t *ids_out, int cap);
+
+/* ---- autoregressive stage ------------------------------------------------------------------ */
+/* Sets the graph inputs of the prefill (input_tokens, input_position, auto_conditioning;
+ * main.cpp:5136-5184) and sizes the per-candidate KV cache for P + max_steps positions
+ * (the reference: fixed 404 x batch 4, main.cpp:794-797). */
+int tts_ar_begin(tts_ctx *ctx, const int32_t *text_ids, int n_text, const float *voice1024,
+                 int n_candidates, int max_steps);
+/* autoregressive_graph(fake_inputs=true) + compute + tensor_get("next token logits")
+ * (main.cpp:5131-5186, 4766-4768). logits_out: [B][8194] host floats. */
+int tts_ar_prefill(tts_ctx *ctx, float *logits_out);
+/* autoregressive_graph(false, n_past=P+i, fixed_position=i+2) + compute (main.cpp:5227-5247):
+ * prev_ids[B] = input_mel_tokens, step index i. logits_out as above. */
+int tts_ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out);
+/* autoregressive_latent_graph + compute + extract "cur" (main.cpp:5286-5352). codes: [B][502].
+ * Only the first n_mel (<=502) mel positions are evaluated (causal => identical rows);
+ * latents_out: [B][min(500,n_mel)][1024]. */
+int tts_ar_latents(tts_ctx *ctx, const int32_t *codes502, int n_candidates, int n_mel,
+                   float *latents_out);
+/* process_logits_and_sample (main.cpp:4753-4806) on host logits with the ctx RNG:
+ * penalty 2.0 on `penalty_ids` ([B][ids_per_cand]), temperature .8, top-k 50, top-p .8,
+ * multinomial (2 draws). */
+int tts_sample(tts_ctx *ctx, const float *logits, const int32_t *penalty_ids, int ids_per_cand,
+               int n_candidates, int32_t *samples_out);
+/* The whole autoregressive() driver (main.cpp:5042-5367): prefill, sample/decode loop with the
+ * reference's stop rule, apply_padding, latent pass, trim_latents.
+ *   flags: TTS_AR_MASK_STOP -> stop token never sampled, exactly max_steps codes (bench workload).
+ *   codes_out [B][502]; rows_out [B] trimmed latent rows; latents_out: the trimmed latents of all
+ *   candidates back to back (capacity B*500*1024 floats); steps_out: sampling iterations run. */
+enum { TTS_AR_MASK_STOP = 1 };
+int tts_autoregressive(tts_ctx *ctx, const int32_t *text_ids, int n_text, const float *voice1024,
+                       int n_candidates, int max_steps, unsigned flags, int32_t *codes_out,
+                       int32_t *rows_out, float *latents_out, int32_t *steps_out);
+
+/* ---- diffusion stage ----------------------------------------------------------------------- */
+/* T = L*4*24000/22050 (main.cpp:5616-5617) */
+int tts_diffusion_frames(int latent_rows);
+/* One diffusion_graph evaluation (main.cpp:5749-5841 cond / 5866-5961 uncond): inputs
+ * input_latent_tensor [L][1024], noise_tensor = x_t [100][T], timestep (raw 0..3999 value whose
+ * sinusoidal embedding the reference uploads as time_embedding_{i}); conditioning_free as the
+ * graph flag; out [200][T]. */
+int tts_diffusion_forward(tts_ctx *ctx, const float *latents, int latent_rows, const float *x_t,
+                          int timestep, int conditioning_free, float *out);
+/* diffusion() for n_candidates independent latents (main.cpp:5614-6042; the reference runs one).
+ *   latents: candidates back to back, rows[c] rows each; n_steps (reference: 80).
+ *   noise: NULL -> noise_mode decides; else [sum_c (n_steps+1)*100*T_c] floats, per candidate
+ *   x_T followed by one vector per step (the reference draws the last one too, 6020-6021).
+ *   noise_mode (when noise==NULL): TTS_NOISE_REFERENCE draws from the ctx RNG in the reference's
+ *   order, candidate by candidate; TTS_NOISE_DEVICE uses a counter-based device generator
+ *   (seed = ctx seed, stream = candidate) — not the reference's noise, documented in DESIGN.md.
+ *   mel_out: per candidate [100][T_c] back to back. */
+enum { TTS_NOISE_REFERENCE = 0, TTS_NOISE_DEVICE = 1 };
+int tts_diffusion(tts_ctx *ctx, const float *latents, const int32_t *rows, int n_candidates,
+                  int n_steps, const float *noise, int noise_mode, float *mel_out);
+
+/* ---- vocoder stage -------------------------------------------------------------------------- */
+int tts_vocoder_samples(int mel_frames); /* (T+10)*256-6, main.cpp:6051, 4459-4478 */
+/* vocoder() (main.cpp:6044-6127): mel per candidate [100][T_c] (normalised, as returned by
+ * tts_diffusion); noise NULL (see noise_mode above) or per candidate [64][T_c+10];
+ * audio_out per candidate tts_vocoder_samples(T_c) floats back to back. */
+int tts_vocoder(tts_ctx *ctx, const float *mel, const int32_t *frames, int n_candidates,
+                const float *noise, int noise_mode, float *audio_out);
+
+/* ---- output -------------------------------------------------------------------------------- */
+/* writeWav (main.cpp:4821-4868): RIFF, fmt 16 B, tag 3 (IEEE float), mono, 32-bit. */
+int tts_write_wav(const char *path, const float *samples, int64_t n, int sample_rate);
+
+/* ---- measurement hooks (bench.py; not part of the reference seam) -------------------------- */
+/* Accumulated device time (ms, HIP events on the ctx stream) and launch count of the named
+ * kernel family since the last reset: "ar_gemv", "diff_gemm", "diff_attn", "voc_lvc", ... */
+int tts_prof_reset(tts_ctx *ctx, int enable);
+int tts_prof_get(tts_ctx *ctx, const char *family, double *ms_out, int64_t *launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TORTOISE_MI355X_H */

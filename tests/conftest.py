@@ -1,0 +1,67 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import tortoise_cpp_amd_loader  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+MODELS = os.path.join(ROOT, "models")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return tortoise_cpp_amd_loader.load()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def voice():
+    return np.fromfile(os.path.join(MODELS, "mol.bin"), np.float32)
+
+
+def _synth_dir(pkg, name, **kw):
+    """Synthetic weights (reference file format), generated once per machine under /tmp."""
+    d = os.path.join(os.environ.get("TTS_SYNTH_DIR", "/tmp/tts_synth"), name)
+    stamp = os.path.join(d, ".done")
+    if not os.path.exists(stamp):
+        from tortoise_cpp_amd import synth_weights as sw
+        sw.write_all(d, **kw)
+        open(stamp, "w").write("ok")
+    return d
+
+
+@pytest.fixture(scope="session")
+def small_models(pkg):
+    # 2 GPT-2 layers, 1+1+1+1 diffusion blocks: same tensor shapes, seconds on the CPU oracle
+    return _synth_dir(pkg, "small", ar_layers=2, diff_main=1, diff_tail=1, diff_integ=1, diff_lc=1, seed=4321)
+
+
+@pytest.fixture(scope="session")
+def mid_models(pkg):
+    return _synth_dir(pkg, "mid", ar_layers=6, diff_main=3, diff_tail=1, diff_integ=1, diff_lc=2, seed=777)
+
+
+@pytest.fixture(scope="session")
+def engine(pkg):
+    eng = pkg.Engine(0)
+    yield eng
+    eng.close()
+
+
+DEFAULT_TOKENS = np.array([255, 147, 2, 54, 2, 14, 2, 136, 63, 2, 80, 32, 150, 112, 9, 0], np.int32)

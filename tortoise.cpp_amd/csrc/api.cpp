@@ -1,0 +1,236 @@
+// C ABI of libtortoise_mi355x.so (see include/tortoise_mi355x.h for the reference call sites).
+#include "common.h"
+#include <algorithm>
+#include <chrono>
+#include <fstream>
+
+namespace tts {
+int ar_begin(tts_ctx *, const int32_t *, int, const float *, int, int);
+int ar_prefill(tts_ctx *, float *);
+int ar_step(tts_ctx *, const int32_t *, int, float *);
+int ar_latents(tts_ctx *, const int32_t *, int, int, float *);
+int ar_layers(const tts_ctx *);
+int diff_layers(const tts_ctx *);
+int diff_forward(tts_ctx *, const float *, int, const float *, int, int, float *);
+int diff_sample(tts_ctx *, const float *, const int32_t *, int, int, const float *, int, float *);
+int voc_run(tts_ctx *, const float *, const int32_t *, int, const float *, int, float *);
+} // namespace tts
+
+using namespace tts;
+
+extern "C" {
+
+tts_ctx *tts_create(int device) {
+  if (device == -1) { // host-only context: tokenizer / RNG / sampler; every device stage fails loudly
+    tts_ctx *c = new tts_ctx();
+    c->device = -1;
+    c->seed_value = (uint32_t)std::chrono::duration_cast<std::chrono::milliseconds>(
+                        std::chrono::system_clock::now().time_since_epoch()).count();
+    c->generator.seed(c->seed_value);
+    return c;
+  }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return nullptr; // no CPU fallback
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  tts_ctx *c = new tts_ctx();
+  c->device = device;
+  if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+      hipEventCreate(&c->ev1) != hipSuccess) {
+    delete c;
+    return nullptr;
+  }
+  // the reference seeds with wall-clock ms unless --seed is given (main.cpp:39-47)
+  c->seed_value = (uint32_t)std::chrono::duration_cast<std::chrono::milliseconds>(
+                      std::chrono::system_clock::now().time_since_epoch()).count();
+  c->generator.seed(c->seed_value);
+  return c;
+}
+
+void tts_destroy(tts_ctx *c) {
+  if (!c) return;
+  if (c->device < 0) { delete c->tok; delete c; return; }
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->ar) ar_free(c->ar);
+  if (c->diff) diff_free(c->diff);
+  if (c->voc) voc_free(c->voc);
+  delete c->tok;
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char *tts_last_error(const tts_ctx *c) { return c ? c->err.c_str() : "no context (no HIP device?)"; }
+
+int tts_set_option(tts_ctx *c, const char *key, double value) {
+  if (!c || !key) return TTS_ERR_ARG;
+  std::string k(key);
+  if (k == "gn_eps") c->gn_eps = (float)value;
+  else if (k == "ggml_lut") c->ggml_lut = value != 0;
+  else return fail(c, TTS_ERR_ARG, "unknown option '%s'", key);
+  return TTS_OK;
+}
+
+#define NEED_CTX(c)                                                                              \
+  do {                                                                                         \
+    if (!(c)) return TTS_ERR_ARG;                                                              \
+    if ((c)->device < 0) return fail((c), TTS_ERR_HIP, "host-only context: no HIP device, no CPU fallback"); \
+    (void)hipSetDevice((c)->device);                                                           \
+  } while (0)
+
+int tts_load_ar(tts_ctx *c, const char *path) { NEED_CTX(c); return ar_load(c, path); }
+int tts_load_diffusion(tts_ctx *c, const char *path) { NEED_CTX(c); return diff_load(c, path); }
+int tts_load_vocoder(tts_ctx *c, const char *path) { NEED_CTX(c); return voc_load(c, path); }
+int tts_ar_layers(const tts_ctx *c) { return c ? ar_layers(c) : 0; }
+int tts_diffusion_layers(const tts_ctx *c) { return c ? diff_layers(c) : 0; }
+
+void tts_seed(tts_ctx *c, uint32_t seed) {
+  if (!c) return;
+  c->seed_value = seed;
+  c->generator.seed(seed);
+  c->distribution.reset();
+  c->normal_distribution.reset();
+}
+int tts_rng_load_state(tts_ctx *c, const char *path) {
+  if (!c) return TTS_ERR_ARG;
+  std::ifstream fin(path);
+  if (!fin) return fail(c, TTS_ERR_IO, "cannot open '%s'", path);
+  fin >> c->generator;
+  c->distribution.reset();
+  c->normal_distribution.reset();
+  return fin ? TTS_OK : fail(c, TTS_ERR_FORMAT, "bad RNG state file '%s'", path);
+}
+float tts_rng_uniform(tts_ctx *c) { return c->distribution(c->generator); }
+void tts_rng_normal(tts_ctx *c, float *out, int64_t n) { // sample_normal_noise, main.cpp:4695-4701
+  for (int64_t i = 0; i < n; i++) out[i] = c->normal_distribution(c->generator);
+}
+
+int tts_tokenizer_load(tts_ctx *c, const char *path) {
+  if (!c) return TTS_ERR_ARG;
+  std::unique_ptr<Tokenizer> t(new Tokenizer());
+  if (!t->load(path)) return fail(c, TTS_ERR_IO, "Failed to open %s", path);
+  delete c->tok;
+  c->tok = t.release();
+  return (int)c->tok->vocab.size();
+}
+int tts_tokenize(tts_ctx *c, const char *message, int32_t *out, int cap) {
+  if (!c || !c->tok) return c ? fail(c, TTS_ERR_STATE, "tokenizer not loaded") : TTS_ERR_ARG;
+  std::vector<int> ids = c->tok->encode(message);
+  for (int i = 0; i < (int)ids.size() && i < cap; i++) out[i] = ids[i];
+  return (int)ids.size();
+}
+
+int tts_ar_begin(tts_ctx *c, const int32_t *ids, int n, const float *voice, int B, int max_steps) {
+  NEED_CTX(c);
+  return ar_begin(c, ids, n, voice, B, max_steps);
+}
+int tts_ar_prefill(tts_ctx *c, float *logits) { NEED_CTX(c); return ar_prefill(c, logits); }
+int tts_ar_step(tts_ctx *c, const int32_t *prev, int i, float *logits) { NEED_CTX(c); return ar_step(c, prev, i, logits); }
+int tts_ar_latents(tts_ctx *c, const int32_t *codes, int nb, int n_mel, float *out) {
+  NEED_CTX(c);
+  return ar_latents(c, codes, nb, n_mel, out);
+}
+int tts_sample(tts_ctx *c, const float *logits, const int32_t *ids, int ids_per_cand, int B, int32_t *out) {
+  if (!c || !logits || !ids || !out || B < 1 || ids_per_cand < 1) return TTS_ERR_ARG;
+  for (int i = 0; i < B * ids_per_cand; i++)
+    if (ids[i] < 0 || ids[i] >= TTS_VOCAB_MEL) return fail(c, TTS_ERR_ARG, "penalty id out of range");
+  sample_candidates(c, logits, ids, ids_per_cand, B, out);
+  return TTS_OK;
+}
+
+// autoregressive(), main.cpp:5042-5367.
+int tts_autoregressive(tts_ctx *c, const int32_t *text_ids, int n_text, const float *voice, int B, int max_steps,
+                       unsigned flags, int32_t *codes_out, int32_t *rows_out, float *latents_out, int32_t *steps_out) {
+  NEED_CTX(c);
+  if (!codes_out || !rows_out) return fail(c, TTS_ERR_ARG, "tts_autoregressive: null output");
+  if (max_steps > 500) return fail(c, TTS_ERR_LIMIT, "max_steps %d exceeds the 500 codes apply_padding accepts", max_steps);
+  int rc = ar_begin(c, text_ids, n_text, voice, B, max_steps);
+  if (rc) return rc;
+  const int V = TTS_VOCAB_MEL;
+  std::vector<float> logits((size_t)B * V);
+  if ((rc = ar_prefill(c, logits.data()))) return rc;
+  // mel_transformer_inputs_vector: [1 ... 1, 8192] per candidate at step 0 (5095-5105), afterwards
+  // the previous samples (5208-5217).
+  const int P = n_text + 2;
+  std::vector<int32_t> ids((size_t)P * B, 1);
+  for (int b = 0; b < B; b++) ids[(size_t)b * P + P - 1] = 8192;
+  int ids_per_cand = P;
+  std::vector<std::vector<int>> seq(B);
+  std::vector<int32_t> samples(B);
+  int i = 0;
+  for (;;) {
+    if (flags & TTS_AR_MASK_STOP)
+      for (int b = 0; b < B; b++) logits[(size_t)b * V + 8193] = -1e30f;
+    sample_candidates(c, logits.data(), ids.data(), ids_per_cand, B, samples.data());
+    int stops = 0;
+    for (int b = 0; b < B; b++) {
+      if (!(seq[b].size() > 0 && seq[b].back() == 8193)) seq[b].push_back(samples[b]);
+      if (samples[b] == 8193) stops++;
+    }
+    ids.assign(samples.begin(), samples.end());
+    ids_per_cand = 1;
+    i++;
+    if (stops == B) break;
+    if (i >= max_steps) {
+      if (flags & TTS_AR_MASK_STOP) break;
+      return fail(c, TTS_ERR_LIMIT, "no stop token within %d steps", max_steps);
+    }
+    if ((rc = ar_step(c, samples.data(), i - 1, logits.data()))) return rc;
+  }
+  if (steps_out) *steps_out = i;
+  int max_rows = 0;
+  for (int b = 0; b < B; b++) {
+    if (seq[b].size() > 500) seq[b].resize(500); // the reference asserts (main.cpp:4517)
+    pad_codes(seq[b]);
+    std::copy(seq[b].begin(), seq[b].end(), codes_out + (size_t)b * 502);
+    rows_out[b] = trimmed_latent_rows(codes_out + (size_t)b * 502);
+    max_rows = std::max(max_rows, rows_out[b]);
+  }
+  if (!latents_out) return TTS_OK;
+  // latent pass over the mel prefix that trim_latents keeps (causal: rows beyond it cannot matter)
+  const int n_mel = std::min(502, max_rows + 1);
+  const int n_out = std::min(500, n_mel);
+  std::vector<float> lat((size_t)B * n_out * TTS_DMODEL);
+  if ((rc = ar_latents(c, codes_out, B, n_mel, lat.data()))) return rc;
+  size_t off = 0;
+  for (int b = 0; b < B; b++) {
+    std::copy(lat.begin() + (size_t)b * n_out * TTS_DMODEL, lat.begin() + ((size_t)b * n_out + rows_out[b]) * TTS_DMODEL,
+              latents_out + off);
+    off += (size_t)rows_out[b] * TTS_DMODEL;
+  }
+  return TTS_OK;
+}
+
+int tts_diffusion_frames(int L) { return L * 4 * 24000 / 22050; }
+int tts_diffusion_forward(tts_ctx *c, const float *latents, int L, const float *x_t, int timestep, int cond_free, float *out) {
+  NEED_CTX(c);
+  return diff_forward(c, latents, L, x_t, timestep, cond_free, out);
+}
+int tts_diffusion(tts_ctx *c, const float *latents, const int32_t *rows, int B, int n_steps, const float *noise,
+                  int noise_mode, float *mel_out) {
+  NEED_CTX(c);
+  return diff_sample(c, latents, rows, B, n_steps, noise, noise_mode, mel_out);
+}
+int tts_vocoder_samples(int T) { return (T + 10) * 256 - 6; }
+int tts_vocoder(tts_ctx *c, const float *mel, const int32_t *frames, int B, const float *noise, int noise_mode, float *audio) {
+  NEED_CTX(c);
+  return voc_run(c, mel, frames, B, noise, noise_mode, audio);
+}
+
+int tts_prof_reset(tts_ctx *c, int enable) {
+  if (!c) return TTS_ERR_ARG;
+  c->prof.clear();
+  c->prof_on = enable != 0;
+  return TTS_OK;
+}
+int tts_prof_get(tts_ctx *c, const char *family, double *ms, int64_t *launches) {
+  if (!c || !family) return TTS_ERR_ARG;
+  auto it = c->prof.find(family);
+  if (it == c->prof.end()) { if (ms) *ms = 0; if (launches) *launches = 0; return TTS_OK; }
+  if (ms) *ms = it->second.ms;
+  if (launches) *launches = it->second.launches;
+  return TTS_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,534 @@
+// Autoregressive stage (GPT-2, 30 x 1024, 16 heads x 64) on gfx950.
+//
+// Replaces: autoregressive_model_load (main.cpp:482-897), autoregressive_graph (2545-3040),
+// autoregressive_latent_graph (2053-2519) and the autoregressive() driver (5042-5367).
+//
+// Numerics follow the reference graph: F32 weights and F32 accumulation for every weight matmul,
+// QKV activations rounded to fp16 (main.cpp:2789-2790) — so the KV cache is *stored* as fp16
+// without changing a bit — F32 softmax, tanh-GELU, LayerNorm eps 1e-5.
+//
+// Decode is HBM-bound weight streaming: all weights are read exactly once per step for
+// up to 16 candidates (split-K GEMV, deterministic two-level reduction, no atomics, so token ids
+// are run-to-run reproducible). Layouts are fixed once at load time (the reference re-transposes
+// every weight matrix inside every graph execution, main.cpp:2769-2777).
+#include "common.h"
+#include <hip/hip_fp16.h>
+#include <algorithm>
+#include <cmath>
+
+namespace tts {
+
+static constexpr int D = 1024, NH = 16, HD = 64, FF = 4096, V = TTS_VOCAB_MEL, VPAD = 8256;
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float f16_round(float v) { return __half2float(__float2half_rn(v)); }
+
+__device__ __forceinline__ float gelu_tanh(float x, int lut) {
+  const float A = 0.044715f, S = 0.79788456080286535587989211986876f;
+  if (lut) {
+    float xr = f16_round(x);
+    return f16_round(0.5f * xr * (1.0f + tanhf(S * xr * (1.0f + A * xr * xr))));
+  }
+  return 0.5f * x * (1.0f + tanhf(S * x * (1.0f + A * x * x)));
+}
+
+// rows of the transformer input: out[r] = tabA[ia[r]] + tabB[ib[r]]  (ib < 0: no second term).
+// tables: 0 voice(1 row), 1 text_emb, 2 mel_emb ; 0 text_pos, 1 mel_pos.
+struct EmbedTables { const float *a[3]; const float *b[2]; };
+__global__ __launch_bounds__(256) void embed_rows_kernel(EmbedTables t, const int4 *__restrict__ desc,
+                                                         float *__restrict__ out) {
+  const int r = blockIdx.x;
+  const int4 d = desc[r]; // {tableA, idxA, tableB (-1 none), idxB}
+  const float4 *pa = (const float4 *)(t.a[d.x] + (size_t)d.y * D);
+  float4 v = pa[threadIdx.x];
+  if (d.z >= 0) {
+    const float4 *pb = (const float4 *)(t.b[d.z] + (size_t)d.w * D);
+    float4 w = pb[threadIdx.x];
+    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+  }
+  ((float4 *)(out + (size_t)r * D))[threadIdx.x] = v;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float *sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// LayerNorm over 1024 (ggml_norm eps 1e-5, then *g + b). One block (256 thr x float4) per row.
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                                        const float *__restrict__ b, float *__restrict__ y) {
+  __shared__ float sh[4];
+  const size_t row = blockIdx.x;
+  float4 v = ((const float4 *)(x + row * D))[threadIdx.x];
+  float mean = block_sum_256(v.x + v.y + v.z + v.w, sh) * (1.0f / D);
+  v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+  float var = block_sum_256(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w, sh) * (1.0f / D);
+  float sc = 1.0f / sqrtf(var + 1e-5f);
+  float4 gg = ((const float4 *)g)[threadIdx.x], bb = ((const float4 *)b)[threadIdx.x];
+  v.x = v.x * sc * gg.x + bb.x; v.y = v.y * sc * gg.y + bb.y;
+  v.z = v.z * sc * gg.z + bb.z; v.w = v.w * sc * gg.w + bb.w;
+  ((float4 *)(y + row * D))[threadIdx.x] = v;
+}
+
+// Split-K GEMV/skinny GEMM: part[ks][rows][N] = X[rows][k-chunk] * W[k-chunk][N].
+// W is [K][N] row-major (N contiguous, N % 64 == 0). Block = 64 columns x one K chunk x RT rows;
+// thread (cx = tid&15, ky = tid>>4) owns 4 columns and every 16th k of the chunk, so a wave's load
+// instruction covers 4 consecutive W rows x 256 B. Reduction over ky: shuffles inside a wave, LDS
+// across the 4 waves; the K chunks are summed in order by the epilogue kernel (deterministic).
+template <int RT>
+__global__ __launch_bounds__(256) void gemv_kn_kernel(const float *__restrict__ X, int ldx, int rows,
+                                                      const float *__restrict__ W, int N, int kspan,
+                                                      float *__restrict__ part) {
+  __shared__ float xs[256 * RT];
+  __shared__ float red[4 * RT * 64];
+  const int tid = threadIdx.x, cx = tid & 15, ky = tid >> 4;
+  const int col0 = blockIdx.x * 64 + cx * 4;
+  const int r0 = blockIdx.z * RT;
+  float acc[RT][4];
+#pragma unroll
+  for (int r = 0; r < RT; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
+  // the block's K range [blockIdx.y*kspan, +kspan) is staged through LDS in chunks of <= 256
+  for (int k0 = blockIdx.y * kspan, kend = k0 + kspan; k0 < kend; k0 += 256) {
+    const int kchunk = min(256, kend - k0);
+    __syncthreads();
+    for (int idx = tid; idx < kchunk * RT; idx += 256) {
+      int r = idx / kchunk, k = idx - r * kchunk;
+      xs[k * RT + r] = (r0 + r < rows) ? X[(size_t)(r0 + r) * ldx + k0 + k] : 0.f;
+    }
+    __syncthreads();
+    const float *wp = W + (size_t)(k0 + ky) * N + col0;
+#pragma unroll 4
+    for (int k = ky; k < kchunk; k += 16) {
+      const float4 w = *(const float4 *)wp;
+      wp += (size_t)16 * N;
+#pragma unroll
+      for (int r = 0; r < RT; r++) {
+        const float xv = xs[k * RT + r];
+        acc[r][0] = fmaf(xv, w.x, acc[r][0]); acc[r][1] = fmaf(xv, w.y, acc[r][1]);
+        acc[r][2] = fmaf(xv, w.z, acc[r][2]); acc[r][3] = fmaf(xv, w.w, acc[r][3]);
+      }
+    }
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int r = 0; r < RT; r++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float v = acc[r][j];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lane < 16) red[(wave * RT + r) * 64 + cx * 4 + j] = v;
+    }
+  __syncthreads();
+  for (int idx = tid; idx < RT * 16; idx += 256) {
+    int r = idx >> 4, c4 = idx & 15;
+    if (r0 + r < rows) {
+      float4 s;
+      const float *p0 = &red[(0 * RT + r) * 64 + c4 * 4], *p1 = &red[(1 * RT + r) * 64 + c4 * 4];
+      const float *p2 = &red[(2 * RT + r) * 64 + c4 * 4], *p3 = &red[(3 * RT + r) * 64 + c4 * 4];
+      s.x = ((p0[0] + p1[0]) + p2[0]) + p3[0]; s.y = ((p0[1] + p1[1]) + p2[1]) + p3[1];
+      s.z = ((p0[2] + p1[2]) + p2[2]) + p3[2]; s.w = ((p0[3] + p1[3]) + p2[3]) + p3[3];
+      *(float4 *)&part[((size_t)blockIdx.y * rows + r0 + r) * N + blockIdx.x * 64 + c4 * 4] = s;
+    }
+  }
+}
+
+enum { EPI_BIAS = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RESID = 3 };
+struct KvDst {          // where EPI_QKV writes K/V as fp16
+  __half *k, *v;        // base of this layer's cache: [cand][max_pos][1024]
+  int S;                // positions per candidate in this launch (row = cand*S + s)
+  int n_past, max_pos;
+  int replicate;        // >0: the single candidate's rows are written for `replicate` candidates
+};
+// out[r][n] = epilogue(sum_s part[s][r][n] + bias[n]); one block per row, columns strided by 256.
+template <int MODE>
+__global__ __launch_bounds__(256) void epilogue_kernel(const float *__restrict__ part, int ks, int rows, int N,
+                                                       int n_valid, const float *__restrict__ bias,
+                                                       float *__restrict__ out, int ldo, KvDst kv, int lut) {
+  const int r = blockIdx.x;
+  for (int n = threadIdx.x; n < n_valid; n += 256) {
+    float v = part[(size_t)r * N + n];
+    for (int s = 1; s < ks; s++) v += part[((size_t)s * rows + r) * N + n];
+    v += bias[n];
+    if (MODE == EPI_QKV) {
+      v = f16_round(v);
+      out[(size_t)r * ldo + n] = v;
+      if (n >= D) {
+        const int c = r / kv.S, s = r - c * kv.S, pos = kv.n_past + s;
+        __half hv = __float2half_rn(v);
+        __half *base = (n < 2 * D) ? kv.k : kv.v;
+        const int ch = (n < 2 * D) ? n - D : n - 2 * D;
+        if (kv.replicate > 0) {
+          for (int cc = 0; cc < kv.replicate; cc++) base[((size_t)cc * kv.max_pos + pos) * D + ch] = hv;
+        } else {
+          base[((size_t)c * kv.max_pos + pos) * D + ch] = hv;
+        }
+      }
+    } else if (MODE == EPI_GELU) {
+      out[(size_t)r * ldo + n] = gelu_tanh(v, lut);
+    } else if (MODE == EPI_RESID) {
+      out[(size_t)r * ldo + n] += v;
+    } else {
+      out[(size_t)r * ldo + n] = v;
+    }
+  }
+}
+
+// Causal attention for one (row, head): q from the f16-rounded qkv buffer, K/V from an fp16 cache
+// [cand][max_pos][1024]. Row r = cand*S + s sees keys 0 .. n_past+s (ggml_diag_mask_inf(n_past)).
+// One wave per (row, head). Scores in LDS (<= 1024 keys).
+__global__ __launch_bounds__(64) void attention_kernel(const float *__restrict__ qkv, const __half *__restrict__ kc,
+                                                       const __half *__restrict__ vc, float *__restrict__ out, int S,
+                                                       int n_past, int max_pos, int lut) {
+  __shared__ float sc[1024];
+  __shared__ float qs[HD];
+  const int r = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+  const int c = r / S, s = r - c * S;
+  const int nk = n_past + s + 1;
+  qs[lane] = qkv[(size_t)r * 3 * D + h * HD + lane];
+  __syncthreads();
+  const __half *kb = kc + (size_t)c * max_pos * D + h * HD;
+  float mx = -INFINITY;
+  for (int j = lane; j < nk; j += 64) {
+    const uint4 *kp = (const uint4 *)(kb + (size_t)j * D);
+    float dot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      uint4 u = kp[q];
+      const __half2 *h2 = (const __half2 *)&u;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float2 f = __half22float2(h2[e]);
+        dot = fmaf(qs[q * 8 + e * 2], f.x, dot);
+        dot = fmaf(qs[q * 8 + e * 2 + 1], f.y, dot);
+      }
+    }
+    dot *= 0.125f; // 1/sqrt(64)
+    sc[j] = dot;
+    mx = fmaxf(mx, dot);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+  for (int j = lane; j < nk; j += 64) {
+    float e = lut ? f16_round(expf(f16_round(sc[j] - mx))) : expf(sc[j] - mx);
+    sc[j] = e;
+    sum += e;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  __syncthreads();
+  const float inv = 1.0f / sum;
+  const __half *vb = vc + (size_t)c * max_pos * D + h * HD + lane;
+  float acc = 0.f;
+  for (int j = 0; j < nk; j++) acc = fmaf(sc[j] * inv, __half2float(vb[(size_t)j * D]), acc);
+  out[(size_t)r * D + h * HD + lane] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct ArLayerDev {
+  float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+  float *w_attn, *b_attn, *w_proj, *b_proj, *w_fc, *b_fc, *w_fc2, *b_fc2;
+};
+
+struct ArState {
+  int n_layers = 0;
+  std::vector<ArLayerDev> L;
+  float *text_emb = nullptr, *text_pos = nullptr, *mel_emb = nullptr, *mel_pos = nullptr;
+  float *lnf_g = nullptr, *lnf_b = nullptr, *lmh_g = nullptr, *lmh_b = nullptr;
+  float *lm_w = nullptr /*[1024][VPAD]*/, *lm_b = nullptr /*[VPAD]*/;
+  std::vector<void *> owned;
+  // run state
+  int B = 0, n_text = 0, P = 0, max_pos = 0;
+  std::vector<int> tokens;
+  DevBuf voice, kcache, vcache, lat_k, lat_v;
+  DevBuf h, xn, qkv, att, ff, part, desc, logits, hn;
+  ~ArState() { for (void *p : owned) (void)hipFree(p); }
+};
+
+void ar_free(ArState *s) { delete s; }
+
+static int upload(tts_ctx *ctx, ArState *st, const std::vector<float> &src, float **dst) {
+  void *p = nullptr;
+  TTS_HIP(ctx, hipMalloc(&p, src.size() * sizeof(float)));
+  st->owned.push_back(p);
+  TTS_HIP(ctx, hipMemcpy(p, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+  *dst = (float *)p;
+  return TTS_OK;
+}
+
+static int fetch(tts_ctx *ctx, ArState *st, const WeightFile &wf, const std::string &name, int64_t ne0, int64_t ne1,
+                 float **dst) {
+  auto it = wf.t.find(name);
+  if (it == wf.t.end()) return fail(ctx, TTS_ERR_FORMAT, "tensor '%s' missing from AR model file", name.c_str());
+  const HostTensor &t = it->second;
+  if (t.ne[0] != ne0 || t.ne[1] != ne1 || t.nelem() != ne0 * ne1)
+    return fail(ctx, TTS_ERR_FORMAT, "tensor '%s' has wrong shape in model file: got [%d, %d], expected [%d, %d]",
+                name.c_str(), (int)t.ne[0], (int)t.ne[1], (int)ne0, (int)ne1);
+  return upload(ctx, st, t.data, dst);
+}
+
+int ar_load(tts_ctx *ctx, const char *path) {
+  WeightFile wf;
+  std::string err;
+  int rc = read_weight_file(path, wf, err);
+  if (rc != TTS_OK) return fail(ctx, rc, "autoregressive_model_load: %s", err.c_str());
+  std::unique_ptr<ArState> st(new ArState());
+  const std::string hp = "inference_model.transformer.h.";
+  while (wf.has(hp + std::to_string(st->n_layers) + ".ln_1.weight")) st->n_layers++;
+  if (st->n_layers == 0) return fail(ctx, TTS_ERR_FORMAT, "no transformer layers in '%s'", path);
+  // every tensor in the file must be known (main.cpp:834-838)
+  for (auto &kv : wf.t) {
+    const std::string &n = kv.first;
+    bool ok = n == "text_embedding.weight" || n == "text_pos_embedding.emb.weight" || n == "mel_embedding.weight" ||
+              n == "mel_pos_embedding.emb.weight" || n.rfind("inference_model.", 0) == 0;
+    if (!ok) return fail(ctx, TTS_ERR_FORMAT, "unknown tensor '%s' in model file", n.c_str());
+  }
+#define FETCH(name, a, b, dst) do { int _r = fetch(ctx, st.get(), wf, name, a, b, dst); if (_r) return _r; } while (0)
+  FETCH("text_embedding.weight", D, 256, &st->text_emb);
+  FETCH("text_pos_embedding.emb.weight", D, 404, &st->text_pos);
+  FETCH("mel_embedding.weight", D, V, &st->mel_emb);
+  FETCH("mel_pos_embedding.emb.weight", D, 608, &st->mel_pos);
+  FETCH("inference_model.transformer.ln_f.weight", D, 1, &st->lnf_g);
+  FETCH("inference_model.transformer.ln_f.bias", D, 1, &st->lnf_b);
+  FETCH("inference_model.lm_head.0.weight", D, 1, &st->lmh_g);
+  FETCH("inference_model.lm_head.0.bias", D, 1, &st->lmh_b);
+  st->L.resize(st->n_layers);
+  for (int i = 0; i < st->n_layers; i++) {
+    std::string p = hp + std::to_string(i);
+    ArLayerDev &l = st->L[i];
+    FETCH(p + ".ln_1.weight", D, 1, &l.ln1_g); FETCH(p + ".ln_1.bias", D, 1, &l.ln1_b);
+    FETCH(p + ".ln_2.weight", D, 1, &l.ln2_g); FETCH(p + ".ln_2.bias", D, 1, &l.ln2_b);
+    FETCH(p + ".attn.c_attn.weight", 3 * D, D, &l.w_attn); FETCH(p + ".attn.c_attn.bias", 3 * D, 1, &l.b_attn);
+    FETCH(p + ".attn.c_proj.weight", D, D, &l.w_proj); FETCH(p + ".attn.c_proj.bias", D, 1, &l.b_proj);
+    FETCH(p + ".mlp.c_fc.weight", FF, D, &l.w_fc); FETCH(p + ".mlp.c_fc.bias", FF, 1, &l.b_fc);
+    FETCH(p + ".mlp.c_proj.weight", D, FF, &l.w_fc2); FETCH(p + ".mlp.c_proj.bias", D, 1, &l.b_fc2);
+  }
+#undef FETCH
+  { // lm_head.1: nn.Linear [8194][1024] -> [1024][VPAD] so that it streams like the Conv1D weights
+    auto it = wf.t.find("inference_model.lm_head.1.weight");
+    auto ib = wf.t.find("inference_model.lm_head.1.bias");
+    if (it == wf.t.end() || ib == wf.t.end()) return fail(ctx, TTS_ERR_FORMAT, "lm_head.1 missing from model file");
+    if (it->second.ne[0] != D || it->second.ne[1] != V || ib->second.nelem() != V)
+      return fail(ctx, TTS_ERR_FORMAT, "tensor 'inference_model.lm_head.1.weight' has wrong shape in model file");
+    std::vector<float> wt((size_t)D * VPAD, 0.f), bt(VPAD, 0.f);
+    const float *w = it->second.data.data();
+    for (int n = 0; n < V; n++)
+      for (int k = 0; k < D; k++) wt[(size_t)k * VPAD + n] = w[(size_t)n * D + k];
+    std::copy(ib->second.data.begin(), ib->second.data.end(), bt.begin());
+    int r = upload(ctx, st.get(), wt, &st->lm_w); if (r) return r;
+    r = upload(ctx, st.get(), bt, &st->lm_b); if (r) return r;
+  }
+  if (ctx->ar) ar_free(ctx->ar);
+  ctx->ar = st.release();
+  return TTS_OK;
+}
+
+// ---- launch helpers -----------------------------------------------------------------------------
+static int pick_rt(int rows) { int rt = 1; while (rt < rows && rt < 16) rt <<= 1; return rt; }
+
+// part <- X[rows][K] * W[K][N]; returns ks through *ks_out.
+static int launch_gemv(tts_ctx *ctx, ArState *st, const float *X, int ldx, int rows, const float *W, int N, int K,
+                       int *ks_out) {
+  const int rt = pick_rt(rows);
+  const int ztiles = (rows + rt - 1) / rt, strips = N / 64;
+  int ks = 1;
+  while (ks * 2 * strips * ztiles <= 768 && K / (ks * 2) >= 32) ks *= 2;
+  const int kchunk = K / ks; // K range per block (staged through LDS in chunks of <= 256)
+  TTS_HIP(ctx, st->part.reserve((size_t)ks * rows * N * sizeof(float)));
+  dim3 grid(strips, ks, ztiles);
+  float *part = st->part.as<float>();
+  ProfScope ps(ctx, "ar_gemv");
+  switch (rt) {
+    case 1: gemv_kn_kernel<1><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, kchunk, part); break;
+    case 2: gemv_kn_kernel<2><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, kchunk, part); break;
+    case 4: gemv_kn_kernel<4><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, kchunk, part); break;
+    case 8: gemv_kn_kernel<8><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, kchunk, part); break;
+    default: gemv_kn_kernel<16><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, kchunk, part); break;
+  }
+  TTS_HIP(ctx, hipGetLastError());
+  *ks_out = ks;
+  return TTS_OK;
+}
+
+template <int MODE>
+static int launch_epilogue(tts_ctx *ctx, ArState *st, int ks, int rows, int N, int n_valid, const float *bias, float *out,
+                           int ldo, KvDst kv) {
+  ProfScope ps(ctx, "ar_epilogue");
+  epilogue_kernel<MODE><<<rows, 256, 0, ctx->stream>>>(st->part.as<float>(), ks, rows, N, n_valid, bias, out, ldo, kv,
+                                                       ctx->ggml_lut);
+  TTS_HIP(ctx, hipGetLastError());
+  return TTS_OK;
+}
+
+#define CHECK(x) do { int _r = (x); if (_r) return _r; } while (0)
+
+// Transformer stack over rows = n_cand_rows * S laid out [cand][pos] in st->h.
+//   kc/vc: fp16 K/V destination [cand][kv_max_pos][1024] per layer (layer_stride halves apart).
+static int run_layers(tts_ctx *ctx, ArState *st, int rows, int S, int n_past, __half *kc, __half *vc,
+                      size_t layer_stride, int kv_max_pos, int replicate) {
+  float *h = st->h.as<float>(), *xn = st->xn.as<float>(), *qkv = st->qkv.as<float>();
+  float *att = st->att.as<float>(), *ff = st->ff.as<float>();
+  KvDst nokv{nullptr, nullptr, 1, 0, 0, 0};
+  for (int l = 0; l < st->n_layers; l++) {
+    const ArLayerDev &w = st->L[l];
+    int ks;
+    { ProfScope ps(ctx, "ar_layernorm");
+      layernorm_kernel<<<rows, 256, 0, ctx->stream>>>(h, w.ln1_g, w.ln1_b, xn); }
+    CHECK(launch_gemv(ctx, st, xn, D, rows, w.w_attn, 3 * D, D, &ks));
+    KvDst kv{kc + l * layer_stride, vc + l * layer_stride, S, n_past, kv_max_pos, replicate};
+    CHECK(launch_epilogue<EPI_QKV>(ctx, st, ks, rows, 3 * D, 3 * D, w.b_attn, qkv, 3 * D, kv));
+    { ProfScope ps(ctx, "ar_attention");
+      attention_kernel<<<dim3(rows, NH), 64, 0, ctx->stream>>>(qkv, kv.k, kv.v, att, S, n_past, kv_max_pos, ctx->ggml_lut); }
+    CHECK(launch_gemv(ctx, st, att, D, rows, w.w_proj, D, D, &ks));
+    CHECK(launch_epilogue<EPI_RESID>(ctx, st, ks, rows, D, D, w.b_proj, h, D, nokv));
+    { ProfScope ps(ctx, "ar_layernorm");
+      layernorm_kernel<<<rows, 256, 0, ctx->stream>>>(h, w.ln2_g, w.ln2_b, xn); }
+    CHECK(launch_gemv(ctx, st, xn, D, rows, w.w_fc, FF, D, &ks));
+    CHECK(launch_epilogue<EPI_GELU>(ctx, st, ks, rows, FF, FF, w.b_fc, ff, FF, nokv));
+    CHECK(launch_gemv(ctx, st, ff, FF, rows, w.w_fc2, D, FF, &ks));
+    CHECK(launch_epilogue<EPI_RESID>(ctx, st, ks, rows, D, D, w.b_fc2, h, D, nokv));
+  }
+  TTS_HIP(ctx, hipGetLastError());
+  return TTS_OK;
+}
+
+static int reserve_rows(tts_ctx *ctx, ArState *st, int rows) {
+  TTS_HIP(ctx, st->h.reserve((size_t)rows * D * 4));
+  TTS_HIP(ctx, st->xn.reserve((size_t)rows * D * 4));
+  TTS_HIP(ctx, st->hn.reserve((size_t)rows * D * 4));
+  TTS_HIP(ctx, st->qkv.reserve((size_t)rows * 3 * D * 4));
+  TTS_HIP(ctx, st->att.reserve((size_t)rows * D * 4));
+  TTS_HIP(ctx, st->ff.reserve((size_t)rows * FF * 4));
+  TTS_HIP(ctx, st->desc.reserve((size_t)rows * sizeof(int4)));
+  return TTS_OK;
+}
+
+static int embed(tts_ctx *ctx, ArState *st, const std::vector<int4> &desc) {
+  TTS_HIP(ctx, hipMemcpyAsync(st->desc.p, desc.data(), desc.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+  EmbedTables t{{st->voice.as<float>(), st->text_emb, st->mel_emb}, {st->text_pos, st->mel_pos}};
+  embed_rows_kernel<<<(int)desc.size(), 256, 0, ctx->stream>>>(t, st->desc.as<int4>(), st->h.as<float>());
+  TTS_HIP(ctx, hipGetLastError());
+  return TTS_OK;
+}
+
+// ln_f -> lm_head.0 LayerNorm -> lm_head.1 on `rows` rows starting at h_rows; logits to host.
+static int head_logits(tts_ctx *ctx, ArState *st, const float *h_rows, int rows, float *logits_host, int replicate) {
+  float *xn = st->xn.as<float>(), *hn = st->hn.as<float>();
+  layernorm_kernel<<<rows, 256, 0, ctx->stream>>>(h_rows, st->lnf_g, st->lnf_b, xn);
+  layernorm_kernel<<<rows, 256, 0, ctx->stream>>>(xn, st->lmh_g, st->lmh_b, hn);
+  int ks;
+  CHECK(launch_gemv(ctx, st, hn, D, rows, st->lm_w, VPAD, D, &ks));
+  TTS_HIP(ctx, st->logits.reserve((size_t)rows * V * 4));
+  KvDst nokv{nullptr, nullptr, 1, 0, 0, 0};
+  CHECK(launch_epilogue<EPI_BIAS>(ctx, st, ks, rows, VPAD, V, st->lm_b, st->logits.as<float>(), V, nokv));
+  if (logits_host) {
+    TTS_HIP(ctx, hipMemcpyAsync(logits_host, st->logits.p, (size_t)rows * V * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int c = 1; c < replicate; c++) memcpy(logits_host + (size_t)c * V, logits_host, (size_t)V * 4);
+  } else {
+    TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return TTS_OK;
+}
+
+int ar_begin(tts_ctx *ctx, const int32_t *text_ids, int n_text, const float *voice, int B, int max_steps) {
+  ArState *st = ctx->ar;
+  if (!st) return fail(ctx, TTS_ERR_STATE, "AR model not loaded");
+  if (n_text < 1 || B < 1 || max_steps < 1 || !text_ids || !voice) return fail(ctx, TTS_ERR_ARG, "tts_ar_begin: bad argument");
+  if (n_text > 404) return fail(ctx, TTS_ERR_LIMIT, "text has %d ids; the model has 404 text positions", n_text);
+  if (max_steps + 2 > 608) return fail(ctx, TTS_ERR_LIMIT, "max_steps %d exceeds the 608 mel positions", max_steps);
+  for (int i = 0; i < n_text; i++)
+    if (text_ids[i] < 0 || text_ids[i] >= 256) return fail(ctx, TTS_ERR_ARG, "text id %d out of range", text_ids[i]);
+  st->B = B; st->n_text = n_text; st->P = n_text + 2;
+  st->max_pos = st->P + max_steps + 1;
+  if (st->max_pos > 1024) return fail(ctx, TTS_ERR_LIMIT, "context of %d positions exceeds 1024", st->max_pos);
+  st->tokens.assign(text_ids, text_ids + n_text);
+  TTS_HIP(ctx, st->voice.reserve(D * 4));
+  TTS_HIP(ctx, hipMemcpy(st->voice.p, voice, D * 4, hipMemcpyHostToDevice));
+  size_t cache = (size_t)st->n_layers * B * st->max_pos * D * sizeof(__half);
+  TTS_HIP(ctx, st->kcache.reserve(cache));
+  TTS_HIP(ctx, st->vcache.reserve(cache));
+  return reserve_rows(ctx, st, std::max(B, st->P));
+}
+
+// Prefill (main.cpp:2586-2665): [voice | text_emb+pos | mel_emb(8192)+mel_pos(0)] — identical for all
+// candidates, so it is evaluated once and its K/V rows are written into every candidate's cache.
+int ar_prefill(tts_ctx *ctx, float *logits_out) {
+  ArState *st = ctx->ar;
+  if (!st || st->B == 0) return fail(ctx, TTS_ERR_STATE, "tts_ar_begin not called");
+  const int P = st->P;
+  std::vector<int4> desc(P);
+  desc[0] = make_int4(0, 0, -1, 0);
+  for (int i = 0; i < st->n_text; i++) desc[1 + i] = make_int4(1, st->tokens[i], 0, i);
+  desc[P - 1] = make_int4(2, 8192, 1, 0);
+  CHECK(embed(ctx, st, desc));
+  const size_t layer_stride = (size_t)st->B * st->max_pos * D;
+  CHECK(run_layers(ctx, st, P, P, 0, st->kcache.as<__half>(), st->vcache.as<__half>(), layer_stride, st->max_pos, st->B));
+  return head_logits(ctx, st, st->h.as<float>() + (size_t)(P - 1) * D, 1, logits_out, st->B);
+}
+
+// Decode step i (main.cpp:2667-2693, 5227-5247): mel_emb[tok] + mel_pos[i+2], n_past = P + i.
+int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out) {
+  ArState *st = ctx->ar;
+  if (!st || st->B == 0) return fail(ctx, TTS_ERR_STATE, "tts_ar_begin not called");
+  if (step_i < 0 || st->P + step_i >= st->max_pos) return fail(ctx, TTS_ERR_LIMIT, "step %d beyond the KV cache", step_i);
+  std::vector<int4> desc(st->B);
+  for (int c = 0; c < st->B; c++) {
+    if (prev_ids[c] < 0 || prev_ids[c] >= V) return fail(ctx, TTS_ERR_ARG, "mel token %d out of range", prev_ids[c]);
+    desc[c] = make_int4(2, prev_ids[c], 1, step_i + 2);
+  }
+  CHECK(embed(ctx, st, desc));
+  const size_t layer_stride = (size_t)st->B * st->max_pos * D;
+  CHECK(run_layers(ctx, st, st->B, 1, st->P + step_i, st->kcache.as<__half>(), st->vcache.as<__half>(), layer_stride,
+                   st->max_pos, 0));
+  return head_logits(ctx, st, st->h.as<float>(), st->B, logits_out, 1);
+}
+
+// Latent pass (main.cpp:2053-2519, 5280-5352): full causal forward without the decode cache.
+int ar_latents(tts_ctx *ctx, const int32_t *codes502, int nb, int n_mel, float *out) {
+  ArState *st = ctx->ar;
+  if (!st || st->n_text == 0) return fail(ctx, TTS_ERR_STATE, "tts_ar_begin not called");
+  if (nb < 1 || n_mel < 1 || n_mel > 502) return fail(ctx, TTS_ERR_ARG, "tts_ar_latents: bad argument");
+  const int S = 1 + st->n_text + n_mel, rows = nb * S;
+  if (S > 1024) return fail(ctx, TTS_ERR_LIMIT, "latent pass of %d positions exceeds 1024", S);
+  CHECK(reserve_rows(ctx, st, rows));
+  TTS_HIP(ctx, st->lat_k.reserve((size_t)rows * D * sizeof(__half)));
+  TTS_HIP(ctx, st->lat_v.reserve((size_t)rows * D * sizeof(__half)));
+  std::vector<int4> desc(rows);
+  for (int c = 0; c < nb; c++) {
+    int4 *d = desc.data() + (size_t)c * S;
+    d[0] = make_int4(0, 0, -1, 0);
+    for (int i = 0; i < st->n_text; i++) d[1 + i] = make_int4(1, st->tokens[i], 0, i);
+    for (int j = 0; j < n_mel; j++) {
+      int code = codes502[c * 502 + j];
+      if (code < 0 || code >= V) return fail(ctx, TTS_ERR_ARG, "mel code %d out of range", code);
+      d[1 + st->n_text + j] = make_int4(2, code, 1, j);
+    }
+  }
+  CHECK(embed(ctx, st, desc));
+  CHECK(run_layers(ctx, st, rows, S, 0, st->lat_k.as<__half>(), st->lat_v.as<__half>(), 0, S, 0));
+  float *xn = st->xn.as<float>(), *hn = st->hn.as<float>();
+  layernorm_kernel<<<rows, 256, 0, ctx->stream>>>(st->h.as<float>(), st->lnf_g, st->lnf_b, xn);
+  layernorm_kernel<<<rows, 256, 0, ctx->stream>>>(xn, st->lmh_g, st->lmh_b, hn);
+  TTS_HIP(ctx, hipGetLastError());
+  const int n_out = std::min(500, n_mel);
+  for (int c = 0; c < nb; c++)
+    TTS_HIP(ctx, hipMemcpyAsync(out + (size_t)c * n_out * D, hn + ((size_t)c * S + 1 + st->n_text) * D,
+                                (size_t)n_out * D * 4, hipMemcpyDeviceToHost, ctx->stream));
+  TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TTS_OK;
+}
+
+int ar_layers(const tts_ctx *ctx) { return ctx->ar ? ctx->ar->n_layers : 0; }
+
+} // namespace tts

@@ -1,0 +1,140 @@
+// Shared internals of libtortoise_mi355x.so (host side). gfx950 only; no CPU fallback anywhere:
+// every stage entry point fails with TTS_ERR_HIP if the device path is unavailable.
+#pragma once
+#include "../../include/tortoise_mi355x.h"
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+namespace tts {
+
+struct HostTensor {
+  std::vector<float> data;
+  int64_t ne[4] = {1, 1, 1, 1};
+  int n_dims = 0;
+  int64_t nelem() const { return ne[0] * ne[1] * ne[2] * ne[3]; }
+};
+// Name-keyed legacy-ggml container (format: main.cpp:811-888).
+struct WeightFile {
+  std::map<std::string, HostTensor> t;
+  bool has(const std::string &n) const { return t.count(n) != 0; }
+};
+int read_weight_file(const char *path, WeightFile &out, std::string &err);
+
+// Grow-only device buffer.
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  template <class T> T *as() const { return (T *)p; }
+};
+
+struct ProfEntry { double ms = 0; int64_t launches = 0; };
+
+struct ArState;
+struct DiffState;
+struct VocState;
+struct Tokenizer;
+
+} // namespace tts
+
+struct tts_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // options
+  float gn_eps = 1e-6f;
+  int ggml_lut = 0;
+  // RNG: the reference's three globals (main.cpp:47-50)
+  std::mt19937 generator;
+  std::uniform_real_distribution<float> distribution{0.0, 1.0};
+  std::normal_distribution<double> normal_distribution{0.0, 1.0};
+  uint32_t seed_value = 0;
+  // stages
+  tts::ArState *ar = nullptr;
+  tts::DiffState *diff = nullptr;
+  tts::VocState *voc = nullptr;
+  tts::Tokenizer *tok = nullptr;
+  // profiling
+  bool prof_on = false;
+  std::map<std::string, tts::ProfEntry> prof;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace tts {
+
+int fail(tts_ctx *ctx, int code, const char *fmt, ...);
+
+#define TTS_HIP(ctx, expr)                                                                      \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess)                                                                       \
+      return tts::fail(ctx, TTS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                       __FILE__, __LINE__);                                                     \
+  } while (0)
+
+// Brackets a kernel (family) with HIP events on the ctx stream when profiling is enabled.
+struct ProfScope {
+  tts_ctx *c; const char *fam;
+  ProfScope(tts_ctx *ctx, const char *family) : c(ctx), fam(family) {
+    if (c->prof_on) (void)hipEventRecord(c->ev0, c->stream);
+  }
+  ~ProfScope() {
+    if (c->prof_on) {
+      (void)hipEventRecord(c->ev1, c->stream);
+      (void)hipEventSynchronize(c->ev1);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+      auto &e = c->prof[fam];
+      e.ms += ms; e.launches++;
+    }
+  }
+};
+
+// host_logic.cpp
+struct Tokenizer {
+  std::map<std::string, int> vocab;
+  bool load(const char *path);
+  std::vector<int> encode(const std::string &message) const;
+};
+void sample_candidates(tts_ctx *ctx, const float *logits, const int32_t *ids, int ids_per_cand, int B,
+                       int32_t *out);
+void pad_codes(std::vector<int> &codes);            // apply_padding
+int trimmed_latent_rows(const int32_t *codes502);   // trim_latents row count
+struct DiffSchedule {
+  int n = 0;
+  std::vector<int> timestep_map;
+  // per sampled step t (already cast the way the reference casts them for the update)
+  std::vector<float> max_log, min_log, cfk, sqrt_recip, sqrt_recipm1, coef1, coef2;
+  void build(int n_steps);
+};
+void timestep_embedding(int t, float *out1024);
+int rel_bucket(int i, int c);
+
+// stage entry points implemented in the .hip files
+int ar_load(tts_ctx *ctx, const char *path);
+void ar_free(ArState *);
+int diff_load(tts_ctx *ctx, const char *path);
+void diff_free(DiffState *);
+int voc_load(tts_ctx *ctx, const char *path);
+void voc_free(VocState *);
+
+} // namespace tts

@@ -1,0 +1,346 @@
+// Host-side logic of the drop-in: weight container reader, tokenizer, sampler, diffusion schedule,
+// sequence bookkeeping, WAV writer. Reference behaviour is cited per function (file:line in
+// /root/reference); tests/test_host_parity.py checks each against the real reference code.
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+#include <fstream>
+#include <limits>
+#include <regex>
+
+namespace tts {
+
+int fail(tts_ctx *ctx, int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight container. Reference loaders: main.cpp:811-888 (AR), 1545-1625 (diffusion), 1932-2012
+// (vocoder): u32 magic 'ggml', then {i32 n_dims, i32 name_len, i32 ttype, i32 ne[n_dims], name,
+// data} until EOF. Only F32 (ttype 0) occurs in the published files.
+// ---------------------------------------------------------------------------------------------
+int read_weight_file(const char *path, WeightFile &out, std::string &err) {
+  FILE *f = fopen(path, "rb");
+  if (!f) { err = std::string("failed to open '") + path + "'"; return TTS_ERR_IO; }
+  uint32_t magic = 0;
+  if (fread(&magic, 4, 1, f) != 1 || magic != 0x67676d6cu) {
+    fclose(f);
+    err = std::string("invalid model file '") + path + "' (bad magic)";
+    return TTS_ERR_FORMAT;
+  }
+  for (;;) {
+    int32_t hdr[3];
+    size_t got = fread(hdr, 4, 3, f);
+    if (got == 0) break; // clean EOF
+    if (got != 3) { fclose(f); err = "truncated record header"; return TTS_ERR_IO; }
+    int n_dims = hdr[0], name_len = hdr[1], ttype = hdr[2];
+    if (n_dims < 1 || n_dims > 4 || name_len < 1 || name_len > 1024) {
+      fclose(f); err = "corrupt record header"; return TTS_ERR_FORMAT;
+    }
+    if (ttype != 0) { fclose(f); err = "unsupported tensor type (only F32)"; return TTS_ERR_FORMAT; }
+    HostTensor t;
+    t.n_dims = n_dims;
+    for (int i = 0; i < n_dims; i++) {
+      int32_t v;
+      if (fread(&v, 4, 1, f) != 1 || v < 1) { fclose(f); err = "corrupt shape"; return TTS_ERR_FORMAT; }
+      t.ne[i] = v;
+    }
+    std::string name(name_len, '\0');
+    if (fread(&name[0], 1, name_len, f) != (size_t)name_len) { fclose(f); err = "truncated name"; return TTS_ERR_IO; }
+    t.data.resize((size_t)t.nelem());
+    if (fread(t.data.data(), sizeof(float), t.data.size(), f) != t.data.size()) {
+      fclose(f);
+      err = "tensor '" + name + "' truncated";
+      return TTS_ERR_IO;
+    }
+    out.t.emplace(std::move(name), std::move(t));
+  }
+  fclose(f);
+  return TTS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tokenizer. The reference scrapes tokenizer.json with a character state machine rather than a
+// JSON parser (common.cpp:166-255) and the resulting map — quirks included, e.g. the first key of
+// every nested object is swallowed — *is* the vocabulary, so the same machine is restated here.
+// ---------------------------------------------------------------------------------------------
+static void subst(std::string &s, const char *from, const char *to) {
+  const size_t fl = strlen(from), tl = strlen(to);
+  for (size_t p = s.find(from); p != std::string::npos; p = s.find(from, p + tl)) s.replace(p, fl, to);
+}
+
+bool Tokenizer::load(const char *path) {
+  std::ifstream in(path);
+  if (!in) return false;
+  const std::string js((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  vocab.clear();
+  if (js.empty() || js[0] != '{') return true;
+  enum { OUTSIDE, IN_KEY, IN_STRVAL } st = OUTSIDE;
+  std::string key, val;
+  const int n = (int)js.size();
+  auto commit = [&]() {
+    subst(key, "\\u0120", " ");
+    subst(key, "\\u010a", "\n");
+    subst(key, "\\\"", "\"");
+    try { vocab[key] = std::stoi(val); } catch (...) { /* non-integer value: ignored */ }
+    key.clear();
+    val.clear();
+    st = OUTSIDE;
+  };
+  for (int i = 1; i < n; ++i) {
+    const char ch = js[i];
+    if (st == OUTSIDE) {
+      if (ch == '"') st = IN_KEY; // everything else between tokens is skipped
+      continue;
+    }
+    std::string &cur = (st == IN_KEY) ? key : val;
+    if (ch == '\\' && i + 1 < n) { // escapes are kept verbatim
+      cur += ch;
+      cur += js[++i];
+      continue;
+    }
+    if (ch != '"') { cur += ch; continue; }
+    if (st == IN_STRVAL) { commit(); continue; }
+    // closing quote of a key: expect [spaces] ':' [spaces] value
+    ++i;
+    while (js[i] == ' ') ++i;
+    ++i;
+    while (js[i] == ' ') ++i;
+    if (js[i] == '"') { st = IN_STRVAL; continue; }
+    while (js[i] != ',' && js[i] != '}') val += js[i++]; // (std::string[] past-the-end reads '\0')
+    commit();
+  }
+  return true;
+}
+
+// gpt_split_words + greedy longest match (common.cpp:268-339); main.cpp:6559-6567 wraps the
+// result with 255 ... 0 after replacing " " by "[SPACE]".
+std::vector<int> Tokenizer::encode(const std::string &message) const {
+  std::string text = message;
+  subst(text, " ", "[SPACE]");
+  static const std::regex word_re(
+      R"(\[SPACE\]|\[UNK\]|\[STOP\]|'s|'t|'re|'ve|'m|'ll|'d| ?[[:alpha:]]+| ?[[:digit:]]+| ?[^\s\[\][:alpha:][:digit:]]+|\s+(?!\S)|\s+)");
+  std::vector<int> ids{255};
+  std::smatch m;
+  while (std::regex_search(text, m, word_re)) {
+    const std::string word = m.str(0);
+    size_t i = 0;
+    while (i < word.size()) {
+      size_t len = word.size() - i;
+      for (; len > 0; --len) {
+        auto it = vocab.find(word.substr(i, len));
+        if (it != vocab.end()) { ids.push_back(it->second); break; }
+      }
+      if (len == 0) {
+        fprintf(stderr, "gpt_tokenize: unknown token '%s'\n", word.substr(i, 1).c_str());
+        len = 1;
+      }
+      i += len;
+    }
+    text = m.suffix();
+  }
+  ids.push_back(0);
+  return ids;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sampler: process_logits_and_sample (main.cpp:4753-4806) and helpers (4562-4720).
+// The reference sorts all 8194 logits three times per candidate; here only the top-k survivors
+// are processed, in the same float operation order, so the sampled ids and the RNG consumption
+// (two uniforms per candidate, the second used) are identical. Ties among survivors fall back to
+// the literal formulation so std::sort's tie order is inherited rather than re-invented.
+// ---------------------------------------------------------------------------------------------
+static inline float exp_like_reference(float v) { return (float)::exp((double)v); } // exp(float) -> ::exp(double)
+
+static int multinomial_literal(std::vector<float> &l, float sample) {
+  const int V = (int)l.size();
+  const float LOWEST = std::numeric_limits<float>::lowest();
+  std::vector<std::pair<float, int>> pairs(V);
+  for (int i = 0; i < V; i++) pairs[i] = {l[i], i};
+  std::sort(pairs.begin(), pairs.end(),
+            [](const std::pair<float, int> &a, const std::pair<float, int> &b) { return a.first < b.first; });
+  std::vector<float> sl(V);
+  float sum = 0;
+  for (int i = 0; i < V; i++) { sl[i] = exp_like_reference(pairs[i].first); sum += sl[i]; }
+  for (int i = 0; i < V; i++) sl[i] /= sum;
+  for (int i = 1; i < V; i++) sl[i] += sl[i - 1];
+  for (int i = 0; i < V - 1; i++)
+    if (sl[i] <= 0.2) l[pairs[i].second] = LOWEST;
+  sum = 0;
+  for (int i = 0; i < V; i++) { l[i] = exp_like_reference(l[i]); sum += l[i]; }
+  float cum = 0;
+  for (int i = 0; i < V; i++) {
+    cum += l[i] / sum;
+    if (cum >= sample) return i;
+  }
+  return V - 1;
+}
+
+void sample_candidates(tts_ctx *ctx, const float *logits, const int32_t *ids, int ids_per_cand, int B,
+                       int32_t *out) {
+  const int V = TTS_VOCAB_MEL, TOPK = 50;
+  const float LOWEST = std::numeric_limits<float>::lowest();
+  std::vector<float> l(V), tmp(V);
+  struct Surv { float v; int idx; float e; };
+  std::vector<Surv> s;
+  for (int c = 0; c < B; c++) {
+    const float *src = logits + (size_t)c * V;
+    std::copy(src, src + V, l.begin());
+    for (int j = 0; j < ids_per_cand; j++) { // gather -> apply_penalty(2.0) -> scatter
+      int id = ids[(size_t)c * ids_per_cand + j];
+      float g = src[id];
+      l[id] = (g < 0) ? g * 2.0f : g / 2.0f;
+    }
+    const float temp = 0.8;
+    for (int i = 0; i < V; i++) l[i] /= temp;
+    tmp = l;
+    std::nth_element(tmp.begin(), tmp.begin() + (V - TOPK), tmp.end());
+    const float kth = tmp[V - TOPK];
+    s.clear();
+    for (int i = 0; i < V; i++) {
+      if (l[i] < kth) l[i] = LOWEST;
+      else s.push_back({l[i], i, 0.f});
+    }
+    float sample = ctx->distribution(ctx->generator); // first draw discarded (main.cpp:4708-4709)
+    sample = ctx->distribution(ctx->generator);
+    std::vector<Surv> asc(s);
+    std::sort(asc.begin(), asc.end(), [](const Surv &a, const Surv &b) { return a.v < b.v; });
+    bool tie = false;
+    for (size_t i = 1; i < asc.size(); i++) tie |= (asc[i].v == asc[i - 1].v);
+    if (tie) { out[c] = multinomial_literal(l, sample); continue; }
+    // top-p over the ascending survivors (non-survivors contribute exp(lowest) = +0)
+    float sum = 0;
+    for (auto &a : asc) { a.e = exp_like_reference(a.v); sum += a.e; }
+    float cum = 0;
+    std::vector<char> cut(V, 0);
+    for (size_t i = 0; i < asc.size(); i++) {
+      cum += asc[i].e / sum;
+      if (i + 1 < asc.size() && cum <= 0.2) cut[asc[i].idx] = 1;
+    }
+    // final softmax + multinomial in index order
+    sum = 0;
+    for (auto &a : s) { a.e = cut[a.idx] ? 0.f : exp_like_reference(a.v); sum += a.e; }
+    int pick = V - 1;
+    if (!(0.0f < sample)) pick = 0; // cumulative(=0) >= sample already at index 0
+    else {
+      cum = 0;
+      for (auto &a : s) {
+        cum += a.e / sum;
+        if (cum >= sample) { pick = a.idx; break; }
+      }
+    }
+    out[c] = pick;
+  }
+}
+
+// apply_padding, main.cpp:4510-4532 (the 8139 is the reference's literal, not 8193)
+void pad_codes(std::vector<int> &codes) {
+  while (!codes.empty() && codes.back() == 8139) codes.pop_back();
+  codes.resize(500, 83);
+  codes[497] = 45;
+  codes[498] = 45;
+  codes[499] = 248;
+  codes.push_back(8193);
+  codes.insert(codes.begin(), 8192);
+}
+
+// trim_latents, main.cpp:4873-4915: rows kept until more than 8 consecutive 83s.
+int trimmed_latent_rows(const int32_t *codes502) {
+  int run = 0;
+  for (int c = 0; c < 500; c++) {
+    run = (codes502[1 + c] == 83) ? run + 1 : 0;
+    if (run > 8) return c;
+  }
+  return 500;
+}
+
+// get_relative_position_buckets, main.cpp:4722-4749 (i = query, c = key)
+int rel_bucket(int i, int c) {
+  const int dist = std::abs(c - i);
+  int b = (i < c) ? 16 : 0;
+  if (dist < 8) return b + dist;
+  int big = 8 + (int)(::log((double)(float(dist) / 8)) / ::log(64.0 / 8.0) * (16.0 - 8.0));
+  return b + std::min(big, 15);
+}
+
+// generate_timestep_embedding, main.cpp:5496-5521 (dim 1024, max_period 10000; cos half first)
+void timestep_embedding(int t, float *out) {
+  for (int i = 0; i < 512; ++i) {
+    float freq = ::exp(-::log((double)10000) * static_cast<float>(i) / 512);
+    float arg = static_cast<float>(t) * freq;
+    out[i] = (float)::cos((double)arg);
+    out[512 + i] = (float)::sin((double)arg);
+  }
+}
+
+// Schedule: main.cpp:5370-5493 + 5641-5716, then the per-step scalars of 5988-6015 in the exact
+// types the reference uses (double tables, float at the point of use).
+void DiffSchedule::build(int n_steps) {
+  n = n_steps;
+  timestep_map.resize(n);
+  for (int i = 0; i < n; i++) timestep_map[i] = (int)std::lround((double)i * 3999.0 / (n - 1)); // == literal table for n=80
+  const int NT = 4000;
+  const double scale = 1000.0 / NT, beta_start = scale * 0.0001, beta_end = scale * 0.02;
+  std::vector<double> acp4000(NT);
+  double prod = 1.0;
+  for (int i = 0; i < NT; ++i) {
+    double beta = beta_start + i * (float)(beta_end - beta_start) / (NT - 1);
+    double alpha = 1.0f - beta;
+    prod = (i == 0) ? alpha : prod * alpha;
+    acp4000[i] = prod;
+  }
+  std::vector<double> beta(n), acp(n), prev(n), pvar(n), plv(n);
+  float last = 1.0; // float on purpose (main.cpp:5663)
+  for (int k = 0; k < n; k++) {
+    beta[k] = 1 - (acp4000[timestep_map[k]] / last);
+    last = acp4000[timestep_map[k]];
+  }
+  prod = 1.0;
+  for (int k = 0; k < n; k++) {
+    double alpha = 1.0f - beta[k];
+    prod = (k == 0) ? alpha : prod * alpha;
+    acp[k] = prod;
+    prev[k] = (k == 0) ? 1.0f : acp[k - 1];
+  }
+  for (int k = 0; k < n; k++) pvar[k] = beta[k] * (1.0 - prev[k]) / (1.0 - acp[k]);
+  plv[0] = std::log(pvar[1]);
+  for (int k = 1; k < n; k++) plv[k] = std::log(pvar[k]);
+  max_log.resize(n); min_log.resize(n); cfk.resize(n); sqrt_recip.resize(n); sqrt_recipm1.resize(n);
+  coef1.resize(n); coef2.resize(n);
+  const float base_k = 2.0;
+  for (int t = 0; t < n; t++) {
+    max_log[t] = std::log(beta[t]);
+    min_log[t] = plv[t];
+    cfk[t] = base_k * (1 - (float)t / float(n));
+    sqrt_recip[t] = std::sqrt(1.0f / acp[t]);
+    sqrt_recipm1[t] = std::sqrt(1.0f / acp[t] - 1);
+    coef1[t] = beta[t] * std::sqrt(prev[t]) / (1.0 - acp[t]);
+    coef2[t] = (1.0 - prev[t]) * std::sqrt(1.0 - beta[t]) / (1.0 - acp[t]);
+  }
+}
+
+} // namespace tts
+
+// writeWav, main.cpp:4821-4868
+extern "C" int tts_write_wav(const char *path, const float *samples, int64_t n, int sample_rate) {
+  FILE *f = fopen(path, "wb");
+  if (!f) return TTS_ERR_IO;
+  const int32_t channels = 1, bits = 32;
+  const int32_t byte_rate = sample_rate * channels * bits / 8, block_align = channels * bits / 8;
+  const int32_t data_size = (int32_t)(n * sizeof(float)), file_size = 36 + data_size, fmt_size = 16;
+  const int32_t format = 3;
+  fwrite("RIFF", 1, 4, f); fwrite(&file_size, 4, 1, f); fwrite("WAVE", 1, 4, f);
+  fwrite("fmt ", 1, 4, f); fwrite(&fmt_size, 4, 1, f);
+  fwrite(&format, 2, 1, f); fwrite(&channels, 2, 1, f); fwrite(&sample_rate, 4, 1, f);
+  fwrite(&byte_rate, 4, 1, f); fwrite(&block_align, 2, 1, f); fwrite(&bits, 2, 1, f);
+  fwrite("data", 1, 4, f); fwrite(&data_size, 4, 1, f);
+  fwrite(samples, sizeof(float), (size_t)n, f);
+  fclose(f);
+  return TTS_OK;
+}
