@@ -9,6 +9,9 @@ import os
 import subprocess
 import numpy as np
 
+# the oracle's loops are small; a 256-thread OpenMP team on the GPU box's host is slower than 16
+os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
