@@ -1,0 +1,887 @@
+// Diffusion decoder stage on gfx950.
+//
+// Replaces diffusion_model_load (main.cpp:931-1634), diffusion_graph (3066-4044) and the diffusion()
+// driver (5614-6042).
+//
+// Design (vs. the reference, which rebuilds/re-uploads everything for each of the 160 forwards):
+//  * all candidates and both guidance branches run as ONE batch: 2*B sequences packed along the GEMM
+//    M dimension ([rows][channels], channels contiguous) with zero guard rows between sequences, so a
+//    k=3 convolution is three row-shifted GEMM segments — no im2col, no boundary code;
+//  * every convolution is an fp16 x fp16 -> f32 MFMA GEMM — exactly the reference's conv1d numerics
+//    (fp16 weights, fp16 im2col, f32 accumulation). proj_out and attention are F32 in the
+//    reference and run here on fp16 MFMA inputs with f32 accumulation (north-star choice; gated by the
+//    parity tests at 1e-3 of the output range);
+//  * the timestep-independent latent conditioner is evaluated once per utterance, the time-embedding
+//    MLP and all 16 emb_layers once per run for all steps;
+//  * x_t never leaves the device: the ancestral update runs in a kernel, noise comes either from the
+//    host (reference stream) or from a counter-based device generator.
+#include "common.h"
+#include "gemm_f16.h"
+#include <algorithm>
+#include <cmath>
+
+namespace tts {
+
+static constexpr int C = 1024, NHEAD = 16, XTC = 128 /* x_t channels padded 100 -> 128 */;
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_dev(float x, int lut) {
+  if (lut) {
+    float xr = __half2float(__float2half_rn(x));
+    return __half2float(__float2half_rn(xr / (1.0f + expf(-xr))));
+  }
+  return x / (1.0f + expf(-x));
+}
+
+// GroupNorm statistics, 32 groups of 32 channels over the T rows of one sequence (ggml_group_norm on
+// [T,1,1024]; eps inside rstd). grid (32, ns), block 256: 8 threads x float4 per row.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, const int *__restrict__ seq_start,
+                                                       const int *__restrict__ seq_len, float eps, float2 *__restrict__ stats) {
+  __shared__ float sh[4];
+  const int grp = blockIdx.x, s = blockIdx.y, T = seq_len[s];
+  const float *base = x + (size_t)seq_start[s] * C + grp * 32 + (threadIdx.x & 7) * 4;
+  float sum = 0.f;
+  for (int t = threadIdx.x >> 3; t < T; t += 32) {
+    float4 v = *(const float4 *)(base + (size_t)t * C);
+    sum += (v.x + v.y) + (v.z + v.w);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  const float mean = (sh[0] + sh[1] + sh[2] + sh[3]) / ((float)T * 32.f);
+  __syncthreads();
+  float sq = 0.f;
+  for (int t = threadIdx.x >> 3; t < T; t += 32) {
+    float4 v = *(const float4 *)(base + (size_t)t * C);
+    v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+    sq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float var = (sh[0] + sh[1] + sh[2] + sh[3]) / ((float)T * 32.f);
+    stats[s * 32 + grp] = make_float2(mean, 1.0f / sqrtf(var + eps));
+  }
+}
+
+// y = [silu]( (((x-mean)*rstd)*g + b) [* (1+scale) + shift] ) -> fp16 GEMM operand (the reference's
+// im2col rounds conv inputs to fp16). Guard/padding rows are written as zeros. One block per row.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const int *__restrict__ row_seq,
+                                                       const float2 *__restrict__ stats, const float *__restrict__ g,
+                                                       const float *__restrict__ b, const float *__restrict__ ss /*[2048] or null*/,
+                                                       int do_silu, int lut, __half *__restrict__ y) {
+  const int r = blockIdx.x, c = threadIdx.x * 4, s = row_seq[r];
+  uint2 o = make_uint2(0u, 0u);
+  if (s >= 0) {
+    const float2 st = stats[s * 32 + (c >> 5)];
+    float4 v = *(const float4 *)(x + (size_t)r * C + c);
+    const float4 gg = *(const float4 *)(g + c), bb = *(const float4 *)(b + c);
+    float e[4] = {v.x, v.y, v.z, v.w};
+    const float ge[4] = {gg.x, gg.y, gg.z, gg.w}, be[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float t = (e[i] - st.x) * st.y;
+      t = t * ge[i];
+      t = t + be[i];
+      if (ss) {
+        t = t * (ss[c + i] + 1.0f); // conditioning_scale_offset = 1.0 (main.cpp:5778)
+        t = t + ss[C + c + i];
+      }
+      if (do_silu) t = silu_dev(t, lut);
+      e[i] = t;
+    }
+    __half2 p0 = __floats2half2_rn(e[0], e[1]), p1 = __floats2half2_rn(e[2], e[3]);
+    o.x = *(unsigned *)&p0;
+    o.y = *(unsigned *)&p1;
+  }
+  *(uint2 *)(y + (size_t)r * C + c) = o;
+}
+
+// Same normalisation but f32 output with the conditioning-latent scale/shift: code_norm at the end of
+// the latent conditioner (main.cpp:3291-3319).
+__global__ __launch_bounds__(256) void gn_apply_f32_kernel(const float *__restrict__ x, const int *__restrict__ row_seq,
+                                                           const float2 *__restrict__ stats, const float *__restrict__ g,
+                                                           const float *__restrict__ b, const float *__restrict__ ss,
+                                                           float *__restrict__ y) {
+  const int r = blockIdx.x, c = threadIdx.x * 4, s = row_seq[r];
+  float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (s >= 0) {
+    const float2 st = stats[s * 32 + (c >> 5)];
+    float4 v = *(const float4 *)(x + (size_t)r * C + c);
+    float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float t = (e[i] - st.x) * st.y;
+      t = t * g[c + i];
+      t = t + b[c + i];
+      t = t * (ss[c + i] + 1.0f);
+      t = t + ss[C + c + i];
+      e[i] = t;
+    }
+    out = make_float4(e[0], e[1], e[2], e[3]);
+  }
+  *(float4 *)(y + (size_t)r * C + c) = out;
+}
+
+// f32 -> fp16 copy of [rows][1024] with guard rows zeroed.
+__global__ __launch_bounds__(256) void to_f16_kernel(const float *__restrict__ x, const int *__restrict__ row_seq,
+                                                     __half *__restrict__ y) {
+  const int r = blockIdx.x, c = threadIdx.x * 4;
+  uint2 o = make_uint2(0u, 0u);
+  if (row_seq[r] >= 0) {
+    float4 v = *(const float4 *)(x + (size_t)r * C + c);
+    __half2 p0 = __floats2half2_rn(v.x, v.y), p1 = __floats2half2_rn(v.z, v.w);
+    o.x = *(unsigned *)&p0;
+    o.y = *(unsigned *)&p1;
+  }
+  *(uint2 *)(y + (size_t)r * C + c) = o;
+}
+
+// Multi-head attention with T5 relative-position bias (AttentionBlock, main.cpp:3232-3275).
+// One block = 128 queries of one (sequence, head): 4 waves x 32 queries; keys stream through LDS in
+// tiles of 64. S = Q K^T and O += P V on fp16 MFMA, online softmax in f32. bias = tab[(q<k)*64 +
+// min(|k-q|,63)] (the 32-bucket table pre-multiplied by 8 and expanded per distance at load time).
+__device__ __forceinline__ int attn_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+__global__ __launch_bounds__(256) void diff_attn_kernel(const __half *__restrict__ qk, const __half *__restrict__ vt, int ldvt,
+                                                        const int *__restrict__ seq_start, const int *__restrict__ seq_len,
+                                                        const float *__restrict__ bias_tab, __half *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
+  __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
+  __shared__ __attribute__((aligned(16))) char Ps[4 * 32 * 128];
+  __shared__ float tab[128];
+  const int s = blockIdx.z, h = blockIdx.y, T = seq_len[s], r0 = seq_start[s], q0 = blockIdx.x * 128;
+  if (q0 >= T) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  if (tid < 128) tab[tid] = bias_tab[h * 128 + tid];
+  const int qw = q0 + wave * 32;
+  half8 qf[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+      qf[i][ks] = *(const half8 *)(qk + (size_t)(r0 + qw + i * 16 + fr) * 2048 + h * 128 + ks * 32 + fq * 8);
+  floatx4 o[2][4];
+  float mrow[2][4], lrow[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      o[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+      mrow[i][j] = -INFINITY;
+      lrow[i][j] = 0.f;
+    }
+  char *pw = Ps + wave * 4096;
+  const int nkb = (T + 63) >> 6;
+  for (int kb = 0; kb < nkb; kb++) {
+    __syncthreads();
+    // stage K [64 keys][64 d] and V^T [64 d][64 keys]; 512 16-byte chunks each, 2 per thread
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int ch = tid + i * 256, row = ch >> 3, c8 = ch & 7;
+      uint4 kv = *(const uint4 *)(qk + (size_t)(r0 + kb * 64 + row) * 2048 + h * 128 + 64 + c8 * 8);
+      *(uint4 *)(Ks + attn_off(row, c8)) = kv;
+      uint4 vv = *(const uint4 *)(vt + (size_t)(h * 64 + row) * ldvt + r0 + kb * 64 + c8 * 8);
+      *(uint4 *)(Vs + attn_off(row, c8)) = vv;
+    }
+    __syncthreads();
+    // S = Q K^T for 2 m-tiles x 4 key tiles
+    floatx4 sc[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      half8 kf0 = *(const half8 *)(Ks + attn_off(j * 16 + fr, fq));
+      half8 kf1 = *(const half8 *)(Ks + attn_off(j * 16 + fr, 4 + fq));
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        floatx4 a = (floatx4){0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[i][0], kf0, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[i][1], kf1, a, 0, 0, 0);
+        sc[i][j] = a;
+      }
+    }
+    // scale, relative-position bias, key mask, online softmax
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int qi = qw + i * 16 + fq * 4 + r;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int ki = kb * 64 + j * 16 + fr;
+          const int d = ki - qi, ad = d < 0 ? -d : d;
+          float v = sc[i][j][r] * 0.125f + tab[(d > 0 ? 64 : 0) + (ad < 63 ? ad : 63)];
+          v = (ki < T) ? v : -INFINITY;
+          sc[i][j][r] = v;
+          mx = fmaxf(mx, v);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        mx = fmaxf(mx, __shfl_xor(mx, 2));
+        mx = fmaxf(mx, __shfl_xor(mx, 4));
+        mx = fmaxf(mx, __shfl_xor(mx, 8));
+        const float mnew = fmaxf(mrow[i][r], mx);
+        const float alpha = __expf(mrow[i][r] - mnew);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float p = __expf(sc[i][j][r] - mnew);
+          sc[i][j][r] = p;
+          sum += p;
+        }
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        sum += __shfl_xor(sum, 4);
+        sum += __shfl_xor(sum, 8);
+        lrow[i][r] = lrow[i][r] * alpha + sum;
+        mrow[i][r] = mnew;
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[i][j][r] *= alpha;
+        // P (fp16) -> this wave's LDS tile [32 q][64 keys]
+        const int prow = i * 16 + fq * 4 + r;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int key = j * 16 + fr;
+          *(__half *)(pw + attn_off(prow, key >> 3) + (key & 7) * 2) = __float2half_rn(sc[i][j][r]);
+        }
+      }
+    __syncthreads();
+    // O += P V : A = P [16 q][32 keys], B = V^T [16 d][32 keys]
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      half8 pf[2], vf[4];
+#pragma unroll
+      for (int i = 0; i < 2; i++) pf[i] = *(const half8 *)(pw + attn_off(i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < 4; j++) vf[j] = *(const half8 *)(Vs + attn_off(j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) o[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf[i], vf[j], o[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int qi = qw + i * 16 + fq * 4 + r;
+      if (qi < T) {
+        const float inv = 1.0f / lrow[i][r];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          out[(size_t)(r0 + qi) * C + h * 64 + j * 16 + fr] = __float2half_rn(o[i][j][r] * inv);
+      }
+    }
+}
+
+// nearest-neighbour upsample of the code embedding L -> T (ggml_upscale_ext: src = (int)(dst / ((float)T/L)))
+// for the conditioned sequences, unconditioned_embedding broadcast for the others. One block per row.
+__global__ __launch_bounds__(256) void build_code_emb_kernel(const float *__restrict__ lat_emb, const int *__restrict__ lat_start,
+                                                             const int *__restrict__ lat_len, const float *__restrict__ uncond,
+                                                             const int *__restrict__ row_seq, const int *__restrict__ row_t,
+                                                             const int *__restrict__ seq_len, const int *__restrict__ seq_src /* latent seq or -1 */,
+                                                             float *__restrict__ out) {
+  const int r = blockIdx.x, c = threadIdx.x * 4, s = row_seq[r];
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (s >= 0) {
+    const int src = seq_src[s];
+    if (src < 0) v = *(const float4 *)(uncond + c);
+    else {
+      const int L = lat_len[src], T = seq_len[s];
+      const float sf = (float)T / (float)L;
+      int sr = (int)((float)row_t[r] / sf);
+      sr = sr > L - 1 ? L - 1 : sr;
+      v = *(const float4 *)(lat_emb + (size_t)(lat_start[src] + sr) * C + c);
+    }
+  }
+  *(float4 *)(out + (size_t)r * C + c) = v;
+}
+
+// x_t [cand][100][T] (f32, reference layout) -> fp16 GEMM operand rows [row][128] for the conditioned
+// and the unconditioned copy of the sequence. grid: rows of the cond sequences; block 128.
+__global__ __launch_bounds__(128) void xt_to_rows_kernel(const float *__restrict__ x, const int64_t *__restrict__ x_off,
+                                                         const int *__restrict__ row_seq, const int *__restrict__ row_t,
+                                                         const int *__restrict__ seq_len, const int *__restrict__ seq_start,
+                                                         int ncand, int has_uncond, __half *__restrict__ xt16) {
+  const int r = blockIdx.x, s = row_seq[r], ch = threadIdx.x;
+  if (s < 0 || s >= ncand) return;
+  const int T = seq_len[s], t = row_t[r];
+  float v = (ch < 100) ? x[x_off[s] + (size_t)ch * T + t] : 0.f;
+  const __half hv = __float2half_rn(v);
+  xt16[(size_t)r * XTC + ch] = hv;
+  if (has_uncond) xt16[(size_t)(seq_start[s + ncand] + t) * XTC + ch] = hv;
+}
+
+// Philox4x32-10 + Box-Muller (device noise mode).
+__device__ __forceinline__ void philox_round(uint32_t &c0, uint32_t &c1, uint32_t &c2, uint32_t &c3, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0, hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+  uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+  c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+}
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint32_t stream, uint32_t step, uint32_t idx) {
+  uint32_t c0 = idx >> 1, c1 = step, c2 = stream, c3 = 0x7715u, k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const float u1 = ((float)c0 + 1.0f) * 2.3283064365386963e-10f, u2 = (float)c1 * 2.3283064365386963e-10f;
+  const float rad = sqrtf(-2.0f * logf(u1));
+  float sn, cs;
+  sincosf(6.283185307179586f * u2, &sn, &cs);
+  return (idx & 1) ? rad * sn : rad * cs;
+}
+
+// Ancestral sampling step (main.cpp:5970-6030) for every candidate, in place on x [cand][100][T].
+// net: [rows][256] f32 (channels 0..99 eps, 100..199 variance logits). grid: cond rows; block 128.
+struct StepScalars { float max_log, min_log, cfk, sqrt_recip, sqrt_recipm1, coef1, coef2; int is_last; };
+__global__ __launch_bounds__(128) void ddpm_update_kernel(const float *__restrict__ net, float *__restrict__ x,
+                                                          const int64_t *__restrict__ x_off, const int *__restrict__ row_seq,
+                                                          const int *__restrict__ row_t, const int *__restrict__ seq_len,
+                                                          const int *__restrict__ seq_start, int ncand, StepScalars sc,
+                                                          const float *__restrict__ noise /* same layout as x, or null */,
+                                                          uint64_t seed, uint32_t step) {
+  const int r = blockIdx.x, s = row_seq[r], ch = threadIdx.x;
+  if (s < 0 || s >= ncand || ch >= 100) return;
+  const int T = seq_len[s], t = row_t[r];
+  const size_t xi = x_off[s] + (size_t)ch * T + t;
+  const float eps_c = net[(size_t)r * 256 + ch], var_c = net[(size_t)r * 256 + 100 + ch];
+  const float eps_u = net[(size_t)(seq_start[s + ncand] + t) * 256 + ch];
+  const float xv = x[xi];
+  const float frac = (var_c + 1) / 2;
+  // calculate_model_variance is called with (min_log, max_log) swapped (main.cpp:5998-5999)
+  const float model_log_variance = frac * sc.min_log + (1 - frac) * sc.max_log;
+  const float eps = (1 + sc.cfk) * eps_c - sc.cfk * eps_u;
+  float x0 = sc.sqrt_recip * xv - sc.sqrt_recipm1 * eps;
+  x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+  const float mean = sc.coef1 * x0 + sc.coef2 * xv;
+  float outv = mean;
+  if (!sc.is_last) {
+    const float nz = noise ? noise[xi] : philox_normal(seed, (uint32_t)s, step, (uint32_t)(ch * T + t));
+    outv = (float)((double)mean + exp(0.5 * (double)model_log_variance) * (double)nz);
+  }
+  x[xi] = outv;
+}
+
+__global__ void philox_fill_kernel(float *__restrict__ x, int64_t n, uint64_t seed, uint32_t stream, uint32_t step) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = philox_normal(seed, stream, step, (uint32_t)i);
+}
+
+// net output [rows][256] -> reference layout [200][T] for one sequence.
+__global__ void rows_to_ct_kernel(const float *__restrict__ net, int row0, int T, int nch, int ld, float *__restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nch * T) {
+    int ch = i / T, t = i - ch * T;
+    out[i] = net[(size_t)(row0 + t) * ld + ch];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct AttnDev { float *norm_g, *norm_b, *qkv_b, *proj_b, *bias_tab; __half *qkv_w, *proj_w; };
+struct ResDev { float *in_g, *in_b, *in_bias, *emb_w, *emb_b, *out_g, *out_b, *out_bias; __half *in_w, *out_w; };
+
+// Packed row layout: sequence s occupies rows [start[s], start[s]+len[s]); start % 8 == 0; at least one
+// zero guard row before and after every sequence; total padded to a multiple of 128.
+struct Layout {
+  int ns = 0, rows = 0;
+  std::vector<int> start, len;
+  DevBuf d_row_seq, d_row_t, d_start, d_len;
+  int build(tts_ctx *ctx, const std::vector<int> &lens) {
+    ns = (int)lens.size();
+    len = lens;
+    start.resize(ns);
+    int r = 8;
+    for (int s = 0; s < ns; s++) { start[s] = r; r = (r + lens[s] + 1 + 7) & ~7; }
+    rows = (r + 127) & ~127;
+    std::vector<int> rs(rows, -1), rt(rows, 0);
+    for (int s = 0; s < ns; s++)
+      for (int t = 0; t < lens[s]; t++) { rs[start[s] + t] = s; rt[start[s] + t] = t; }
+    TTS_HIP(ctx, d_row_seq.reserve(rows * 4)); TTS_HIP(ctx, d_row_t.reserve(rows * 4));
+    TTS_HIP(ctx, d_start.reserve(ns * 4)); TTS_HIP(ctx, d_len.reserve(ns * 4));
+    TTS_HIP(ctx, hipMemcpy(d_row_seq.p, rs.data(), rows * 4, hipMemcpyHostToDevice));
+    TTS_HIP(ctx, hipMemcpy(d_row_t.p, rt.data(), rows * 4, hipMemcpyHostToDevice));
+    TTS_HIP(ctx, hipMemcpy(d_start.p, start.data(), ns * 4, hipMemcpyHostToDevice));
+    TTS_HIP(ctx, hipMemcpy(d_len.p, len.data(), ns * 4, hipMemcpyHostToDevice));
+    return TTS_OK;
+  }
+  int max_len() const { return len.empty() ? 0 : *std::max_element(len.begin(), len.end()); }
+};
+
+// Activation workspace for one layout. fp16 GEMM operands carry a 1-row zero halo on both sides (the
+// k=3 taps read rows -1 and `rows`) plus 128 rows of slack for the attention tiles.
+struct Work {
+  int rows = 0;
+  DevBuf x, hbuf, a16, att16, qk16, vt16, stats;
+  float *X() { return x.as<float>(); }
+  float *H() { return hbuf.as<float>(); }
+  __half *A16() { return a16.as<__half>() + C; }
+  __half *ATT16() { return att16.as<__half>() + C; }
+  int reserve(tts_ctx *ctx, int r, int ns) {
+    auto rz = [&](DevBuf &b, size_t bytes) -> hipError_t {
+      size_t old = b.cap;
+      hipError_t e = b.reserve(bytes);
+      if (e == hipSuccess && b.cap != old) e = hipMemset(b.p, 0, b.cap);
+      return e;
+    };
+    rows = r;
+    TTS_HIP(ctx, rz(x, (size_t)r * C * 4));
+    TTS_HIP(ctx, rz(hbuf, (size_t)r * C * 4));
+    TTS_HIP(ctx, rz(a16, (size_t)(r + 2) * C * 2));
+    TTS_HIP(ctx, rz(att16, (size_t)(r + 2) * C * 2));
+    TTS_HIP(ctx, rz(qk16, (size_t)(r + 128) * 2048 * 2));
+    TTS_HIP(ctx, rz(vt16, (size_t)C * (r + 128) * 2));
+    TTS_HIP(ctx, rz(stats, (size_t)ns * 32 * sizeof(float2)));
+    return TTS_OK;
+  }
+};
+
+struct DiffState {
+  int n_lc = 0, n_integ = 0, n_main = 0, n_tail = 0;
+  std::vector<AttnDev> lc_attn, integ_attn, main_attn;
+  std::vector<ResDev> integ_res, main_res, tail_res; // emb order: integ.., main.., tail..
+  float *cond_latent = nullptr, *uncond_emb = nullptr, *lc_bias = nullptr, *code_g = nullptr, *code_b = nullptr;
+  float *te0_w = nullptr, *te0_b = nullptr, *te2_w = nullptr, *te2_b = nullptr;
+  float *inp_bias = nullptr, *integ_bias = nullptr, *outn_g = nullptr, *outn_b = nullptr, *out_bias = nullptr;
+  __half *lc_w = nullptr, *inp_w = nullptr, *integ_w = nullptr, *out_w = nullptr;
+  std::vector<void *> owned;
+  // run state
+  Layout lay, lat_lay;
+  Work wk, lat_wk;
+  DevBuf code_emb, ce, ce16, xt16, inp16, net, temb, e1, emb, ss_all, xbuf, xoff, noise, seq_src, lat_in16, out_ct;
+  ~DiffState() { for (void *p : owned) (void)hipFree(p); }
+  int n_res() const { return n_integ + n_main + n_tail; }
+};
+
+void diff_free(DiffState *s) { delete s; }
+int diff_layers(const tts_ctx *ctx) { return ctx->diff ? ctx->diff->n_main : 0; }
+
+namespace {
+struct Loader {
+  tts_ctx *ctx; DiffState *st; const WeightFile &wf; std::map<std::string, bool> used;
+  const HostTensor *get(const std::string &name, int64_t nelem) {
+    auto it = wf.t.find(name);
+    if (it == wf.t.end()) { fail(ctx, TTS_ERR_FORMAT, "tensor '%s' missing from diffusion model file", name.c_str()); return nullptr; }
+    if (it->second.nelem() != nelem) {
+      fail(ctx, TTS_ERR_FORMAT, "tensor '%s' has wrong size in model file: got %lld, expected %lld", name.c_str(),
+           (long long)it->second.nelem(), (long long)nelem);
+      return nullptr;
+    }
+    used[name] = true;
+    return &it->second;
+  }
+  template <class T> int put(const std::vector<T> &h, T **dst) {
+    void *p = nullptr;
+    TTS_HIP(ctx, hipMalloc(&p, h.size() * sizeof(T)));
+    st->owned.push_back(p);
+    TTS_HIP(ctx, hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dst = (T *)p;
+    return TTS_OK;
+  }
+  int f32(const std::string &name, int64_t n, float **dst) {
+    const HostTensor *t = get(name, n);
+    if (!t) return TTS_ERR_FORMAT;
+    return put(t->data, dst);
+  }
+  // conv weight file layout w[(co*cin + ci)*k + tap] -> fp16 [co_pad][tap*cin_pad + ci] (zero padded)
+  int conv16(const std::string &name, int cout, int cin, int k, int cout_pad, int cin_pad, __half **dst) {
+    const HostTensor *t = get(name, (int64_t)cout * cin * k);
+    if (!t) return TTS_ERR_FORMAT;
+    std::vector<__half> h((size_t)cout_pad * k * cin_pad, __float2half(0.f));
+    const float *w = t->data.data();
+    for (int co = 0; co < cout; co++)
+      for (int ci = 0; ci < cin; ci++)
+        for (int tap = 0; tap < k; tap++)
+          h[(size_t)co * k * cin_pad + (size_t)tap * cin_pad + ci] = __float2half_rn(w[((size_t)co * cin + ci) * k + tap]);
+    return put(h, dst);
+  }
+  int attn(const std::string &p, AttnDev &a) {
+    int r;
+    if ((r = f32(p + ".norm.weight", C, &a.norm_g))) return r;
+    if ((r = f32(p + ".norm.bias", C, &a.norm_b))) return r;
+    if ((r = conv16(p + ".qkv.weight", 3 * C, C, 1, 3 * C, C, &a.qkv_w))) return r;
+    if ((r = f32(p + ".qkv.bias", 3 * C, &a.qkv_b))) return r;
+    if ((r = conv16(p + ".proj_out.weight", C, C, 1, C, C, &a.proj_w))) return r;
+    if ((r = f32(p + ".proj_out.bias", C, &a.proj_b))) return r;
+    const HostTensor *t = get(p + ".relative_pos_embeddings.relative_attention_bias.weight", 32 * 16);
+    if (!t) return TTS_ERR_FORMAT;
+    // bias(q,k) = 8 * table[bucket(q,k)][h]; expanded per signed distance: tab[h][(q<k)*64 + min(|k-q|,63)]
+    std::vector<float> tab(16 * 128);
+    for (int h = 0; h < 16; h++)
+      for (int sgn = 0; sgn < 2; sgn++)
+        for (int d = 0; d < 64; d++) {
+          int bucket = sgn ? rel_bucket(0, d) : rel_bucket(d, 0);
+          if (d == 0) bucket = rel_bucket(0, 0);
+          tab[h * 128 + sgn * 64 + d] = t->data[(size_t)bucket * 16 + h] * 8.0f;
+        }
+    return put(tab, &a.bias_tab);
+  }
+  int res(const std::string &p, ResDev &w) {
+    int r;
+    if ((r = f32(p + ".in_layers.0.weight", C, &w.in_g))) return r;
+    if ((r = f32(p + ".in_layers.0.bias", C, &w.in_b))) return r;
+    if ((r = conv16(p + ".in_layers.2.weight", C, C, 1, C, C, &w.in_w))) return r;
+    if ((r = f32(p + ".in_layers.2.bias", C, &w.in_bias))) return r;
+    if ((r = f32(p + ".emb_layers.1.weight", 2 * C * C, &w.emb_w))) return r;
+    if ((r = f32(p + ".emb_layers.1.bias", 2 * C, &w.emb_b))) return r;
+    if ((r = f32(p + ".out_layers.0.weight", C, &w.out_g))) return r;
+    if ((r = f32(p + ".out_layers.0.bias", C, &w.out_b))) return r;
+    if ((r = conv16(p + ".out_layers.3.weight", C, C, 3, C, C, &w.out_w))) return r;
+    if ((r = f32(p + ".out_layers.3.bias", C, &w.out_bias))) return r;
+    return TTS_OK;
+  }
+};
+} // namespace
+
+int diff_load(tts_ctx *ctx, const char *path) {
+  WeightFile wf;
+  std::string err;
+  int rc = read_weight_file(path, wf, err);
+  if (rc != TTS_OK) return fail(ctx, rc, "diffusion_model_load: %s", err.c_str());
+  std::unique_ptr<DiffState> st(new DiffState());
+  Loader ld{ctx, st.get(), wf, {}};
+#define R(x) do { int _r = (x); if (_r) return _r; } while (0)
+  while (wf.has("latent_conditioner." + std::to_string(st->n_lc + 1) + ".norm.weight")) st->n_lc++;
+  while (wf.has("conditioning_timestep_integrator." + std::to_string(st->n_integ) + ".resblk.in_layers.0.weight")) st->n_integ++;
+  while (wf.has("layers." + std::to_string(st->n_main) + ".resblk.in_layers.0.weight")) st->n_main++;
+  while (wf.has("layers." + std::to_string(st->n_main + st->n_tail) + ".in_layers.0.weight")) st->n_tail++;
+  R(ld.f32("diffusion_conditioning_latent", 2 * C, &st->cond_latent));
+  R(ld.f32("unconditioned_embedding", C, &st->uncond_emb));
+  R(ld.conv16("latent_conditioner.0.weight", C, C, 3, C, C, &st->lc_w));
+  R(ld.f32("latent_conditioner.0.bias", C, &st->lc_bias));
+  st->lc_attn.resize(st->n_lc);
+  for (int i = 0; i < st->n_lc; i++) R(ld.attn("latent_conditioner." + std::to_string(i + 1), st->lc_attn[i]));
+  R(ld.f32("code_norm.weight", C, &st->code_g));
+  R(ld.f32("code_norm.bias", C, &st->code_b));
+  R(ld.f32("time_embed.0.weight", C * C, &st->te0_w)); R(ld.f32("time_embed.0.bias", C, &st->te0_b));
+  R(ld.f32("time_embed.2.weight", C * C, &st->te2_w)); R(ld.f32("time_embed.2.bias", C, &st->te2_b));
+  st->integ_res.resize(st->n_integ); st->integ_attn.resize(st->n_integ);
+  for (int i = 0; i < st->n_integ; i++) {
+    std::string p = "conditioning_timestep_integrator." + std::to_string(i);
+    R(ld.res(p + ".resblk", st->integ_res[i]));
+    R(ld.attn(p + ".attn", st->integ_attn[i]));
+  }
+  R(ld.conv16("inp_block.weight", C, 100, 3, C, XTC, &st->inp_w));
+  R(ld.f32("inp_block.bias", C, &st->inp_bias));
+  R(ld.conv16("integrating_conv.weight", C, 2 * C, 1, C, 2 * C, &st->integ_w));
+  R(ld.f32("integrating_conv.bias", C, &st->integ_bias));
+  st->main_res.resize(st->n_main); st->main_attn.resize(st->n_main);
+  for (int i = 0; i < st->n_main; i++) {
+    std::string p = "layers." + std::to_string(i);
+    R(ld.res(p + ".resblk", st->main_res[i]));
+    R(ld.attn(p + ".attn", st->main_attn[i]));
+  }
+  st->tail_res.resize(st->n_tail);
+  for (int i = 0; i < st->n_tail; i++) R(ld.res("layers." + std::to_string(st->n_main + i), st->tail_res[i]));
+  R(ld.f32("out.0.weight", C, &st->outn_g)); R(ld.f32("out.0.bias", C, &st->outn_b));
+  R(ld.conv16("out.2.weight", 200, C, 3, 256, C, &st->out_w));
+  {
+    const HostTensor *t = ld.get("out.2.bias", 200);
+    if (!t) return TTS_ERR_FORMAT;
+    std::vector<float> b(256, 0.f);
+    std::copy(t->data.begin(), t->data.end(), b.begin());
+    R(ld.put(b, &st->out_bias));
+  }
+#undef R
+  for (auto &kv : wf.t)
+    if (!ld.used.count(kv.first)) return fail(ctx, TTS_ERR_FORMAT, "unknown tensor '%s' in model file", kv.first.c_str());
+  if (ctx->diff) diff_free(ctx->diff);
+  ctx->diff = st.release();
+  return TTS_OK;
+}
+
+#define CHECK(x) do { int _r = (x); if (_r) return _r; } while (0)
+
+static int gemm(tts_ctx *ctx, const char *fam, GemmArgs &g) {
+  ProfScope ps(ctx, fam);
+  TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream));
+  return TTS_OK;
+}
+
+static GemmArgs gemm_base(const Layout &lay, const __half *A, int lda, int nseg, int kseg, const __half *W, int N,
+                          const float *bias) {
+  GemmArgs g{};
+  for (int i = 0; i < 3; i++) { g.A[i] = A; g.row_off[i] = 0; }
+  if (nseg == 3) { g.row_off[0] = -1; g.row_off[1] = 0; g.row_off[2] = 1; }
+  g.nseg = nseg; g.kseg = kseg; g.lda = lda; g.W = W; g.M = lay.rows; g.N = N; g.bias = bias;
+  g.row_seq = lay.d_row_seq.as<int>();
+  return g;
+}
+
+static int gn_stats(tts_ctx *ctx, const Layout &lay, Work &wk, const float *x) {
+  ProfScope ps(ctx, "diff_gn_stats");
+  gn_stats_kernel<<<dim3(32, lay.ns), 256, 0, ctx->stream>>>(x, lay.d_start.as<int>(), lay.d_len.as<int>(), ctx->gn_eps,
+                                                             wk.stats.as<float2>());
+  TTS_HIP(ctx, hipGetLastError());
+  return TTS_OK;
+}
+static int gn_apply(tts_ctx *ctx, const Layout &lay, Work &wk, const float *x, const float *g, const float *b, const float *ss,
+                    int do_silu, __half *y) {
+  ProfScope ps(ctx, "diff_gn_apply");
+  gn_apply_kernel<<<lay.rows, 256, 0, ctx->stream>>>(x, lay.d_row_seq.as<int>(), wk.stats.as<float2>(), g, b, ss, do_silu,
+                                                     ctx->ggml_lut, y);
+  TTS_HIP(ctx, hipGetLastError());
+  return TTS_OK;
+}
+
+// AttentionBlock on X (in place).
+static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, float *X, const AttnDev &w) {
+  CHECK(gn_stats(ctx, lay, wk, X));
+  CHECK(gn_apply(ctx, lay, wk, X, w.norm_g, w.norm_b, nullptr, 0, wk.A16()));
+  GemmArgs g = gemm_base(lay, wk.A16(), C, 1, C, w.qkv_w, 3 * C, w.qkv_b);
+  g.mode = GEMM_OUT_QKV; g.outH = wk.qk16.as<__half>(); g.ldh = 2048; g.outVt = wk.vt16.as<__half>(); g.ldvt = wk.rows + 128;
+  CHECK(gemm(ctx, "diff_gemm", g));
+  {
+    ProfScope ps(ctx, "diff_attn");
+    dim3 grid((lay.max_len() + 127) / 128, NHEAD, lay.ns);
+    diff_attn_kernel<<<grid, 256, 0, ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128, lay.d_start.as<int>(),
+                                                    lay.d_len.as<int>(), w.bias_tab, wk.ATT16());
+    TTS_HIP(ctx, hipGetLastError());
+  }
+  GemmArgs p = gemm_base(lay, wk.ATT16(), C, 1, C, w.proj_w, C, w.proj_b);
+  p.mode = GEMM_OUT_F32; p.outF = X; p.ldo = C; p.resid = X;
+  return gemm(ctx, "diff_gemm", p);
+}
+
+// ResBlock on X (in place); ss = this step's [scale | shift] for this block (device, 2048 floats).
+static int res_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, float *X, const ResDev &w, const float *ss) {
+  CHECK(gn_stats(ctx, lay, wk, X));
+  CHECK(gn_apply(ctx, lay, wk, X, w.in_g, w.in_b, nullptr, 1, wk.A16()));
+  GemmArgs g = gemm_base(lay, wk.A16(), C, 1, C, w.in_w, C, w.in_bias);
+  g.mode = GEMM_OUT_F32; g.outF = wk.H(); g.ldo = C; g.resid = nullptr;
+  CHECK(gemm(ctx, "diff_gemm", g));
+  CHECK(gn_stats(ctx, lay, wk, wk.H()));
+  CHECK(gn_apply(ctx, lay, wk, wk.H(), w.out_g, w.out_b, ss, 1, wk.A16()));
+  GemmArgs c3 = gemm_base(lay, wk.A16(), C, 3, C, w.out_w, C, w.out_bias);
+  c3.mode = GEMM_OUT_F32; c3.outF = X; c3.ldo = C; c3.resid = X;
+  return gemm(ctx, "diff_gemm", c3);
+}
+
+// Timestep MLP + every emb_layers linear for `n` timesteps at once:
+//   emb = W2 silu(W0 te + b0) + b2 (main.cpp:3331-3343); ss[j] = Wemb_j silu(emb) + bemb_j (3410-3428).
+static int precompute_time(tts_ctx *ctx, DiffState *st, const std::vector<int> &timesteps) {
+  const int n = (int)timesteps.size(), nres = st->n_res();
+  std::vector<float> te((size_t)n * C);
+  for (int i = 0; i < n; i++) timestep_embedding(timesteps[i], te.data() + (size_t)i * C);
+  TTS_HIP(ctx, st->temb.reserve(te.size() * 4)); TTS_HIP(ctx, st->e1.reserve(te.size() * 4)); TTS_HIP(ctx, st->emb.reserve(te.size() * 4));
+  TTS_HIP(ctx, st->ss_all.reserve((size_t)n * nres * 2 * C * 4));
+  TTS_HIP(ctx, hipMemcpyAsync(st->temb.p, te.data(), te.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  linear_nk_kernel<0><<<C / 4, 256, 0, ctx->stream>>>(st->temb.as<float>(), C, n, st->te0_w, C, C, st->te0_b, st->e1.as<float>(), C, 0);
+  linear_nk_kernel<1><<<C / 4, 256, 0, ctx->stream>>>(st->e1.as<float>(), C, n, st->te2_w, C, C, st->te2_b, st->emb.as<float>(), C, ctx->ggml_lut);
+  for (int j = 0; j < nres; j++) {
+    const ResDev &w = j < st->n_integ ? st->integ_res[j] : j < st->n_integ + st->n_main ? st->main_res[j - st->n_integ]
+                                                                                        : st->tail_res[j - st->n_integ - st->n_main];
+    // out row i -> ss_all[(i*nres + j)*2048]
+    linear_nk_kernel<1><<<2 * C / 4, 256, 0, ctx->stream>>>(st->emb.as<float>(), C, n, w.emb_w, C, 2 * C, w.emb_b,
+                                                            st->ss_all.as<float>() + (size_t)j * 2 * C, nres * 2 * C, ctx->ggml_lut);
+  }
+  TTS_HIP(ctx, hipGetLastError());
+  return TTS_OK;
+}
+
+// Latent conditioner (main.cpp:3156-3319) for `lat_lens.size()` latents packed in st->lat_lay; result
+// (before the upsample) in st->lat_wk.H().
+static int latent_conditioner(tts_ctx *ctx, DiffState *st, const float *latents_host, const std::vector<int> &lat_lens) {
+  Layout &ll = st->lat_lay;
+  CHECK(ll.build(ctx, lat_lens));
+  Work &wk = st->lat_wk;
+  CHECK(wk.reserve(ctx, ll.rows, ll.ns));
+  // latents -> f32 rows of X, then fp16 operand
+  TTS_HIP(ctx, hipMemsetAsync(wk.X(), 0, (size_t)ll.rows * C * 4, ctx->stream));
+  size_t off = 0;
+  for (int s = 0; s < ll.ns; s++) {
+    TTS_HIP(ctx, hipMemcpyAsync(wk.X() + (size_t)ll.start[s] * C, latents_host + off, (size_t)lat_lens[s] * C * 4,
+                                hipMemcpyHostToDevice, ctx->stream));
+    off += (size_t)lat_lens[s] * C;
+  }
+  to_f16_kernel<<<ll.rows, 256, 0, ctx->stream>>>(wk.X(), ll.d_row_seq.as<int>(), wk.A16());
+  GemmArgs c3 = gemm_base(ll, wk.A16(), C, 3, C, st->lc_w, C, st->lc_bias);
+  c3.mode = GEMM_OUT_F32; c3.outF = wk.X(); c3.ldo = C; c3.resid = nullptr;
+  CHECK(gemm(ctx, "diff_gemm", c3));
+  for (int i = 0; i < st->n_lc; i++) CHECK(attention_block(ctx, st, ll, wk, wk.X(), st->lc_attn[i]));
+  CHECK(gn_stats(ctx, ll, wk, wk.X()));
+  gn_apply_f32_kernel<<<ll.rows, 256, 0, ctx->stream>>>(wk.X(), ll.d_row_seq.as<int>(), wk.stats.as<float2>(), st->code_g, st->code_b,
+                                                        st->cond_latent, wk.H());
+  TTS_HIP(ctx, hipGetLastError());
+  return TTS_OK;
+}
+
+// One network evaluation for every sequence of st->lay. Inputs: st->code_emb (f32 rows), st->xt16;
+// ss = this timestep's scale/shift block [n_res][2048]. Output: st->net [rows][256].
+static int network_forward(tts_ctx *ctx, DiffState *st, const float *ss) {
+  Layout &lay = st->lay;
+  Work &wk = st->wk;
+  float *ce = st->ce.as<float>();
+  TTS_HIP(ctx, hipMemcpyAsync(ce, st->code_emb.p, (size_t)lay.rows * C * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  int j = 0;
+  for (int i = 0; i < st->n_integ; i++, j++) {
+    CHECK(res_block(ctx, st, lay, wk, ce, st->integ_res[i], ss + (size_t)j * 2 * C));
+    CHECK(attention_block(ctx, st, lay, wk, ce, st->integ_attn[i]));
+  }
+  __half *ce16 = st->ce16.as<__half>(), *inp16 = st->inp16.as<__half>();
+  to_f16_kernel<<<lay.rows, 256, 0, ctx->stream>>>(ce, lay.d_row_seq.as<int>(), ce16);
+  // inp_block: conv k3 100(->128) -> 1024 on x_t, output rounded to fp16 (operand of the next conv)
+  GemmArgs gi = gemm_base(lay, st->xt16.as<__half>() + XTC, XTC, 3, XTC, st->inp_w, C, st->inp_bias);
+  gi.mode = GEMM_OUT_F16; gi.outH = inp16; gi.ldh = C;
+  CHECK(gemm(ctx, "diff_gemm", gi));
+  // integrating conv k1 over concat[inp | code_emb]
+  GemmArgs gc = gemm_base(lay, inp16, C, 2, C, st->integ_w, C, st->integ_bias);
+  gc.A[1] = ce16;
+  gc.mode = GEMM_OUT_F32; gc.outF = wk.X(); gc.ldo = C; gc.resid = nullptr;
+  CHECK(gemm(ctx, "diff_gemm", gc));
+  for (int i = 0; i < st->n_main; i++, j++) {
+    CHECK(res_block(ctx, st, lay, wk, wk.X(), st->main_res[i], ss + (size_t)j * 2 * C));
+    CHECK(attention_block(ctx, st, lay, wk, wk.X(), st->main_attn[i]));
+  }
+  for (int i = 0; i < st->n_tail; i++, j++) CHECK(res_block(ctx, st, lay, wk, wk.X(), st->tail_res[i], ss + (size_t)j * 2 * C));
+  CHECK(gn_stats(ctx, lay, wk, wk.X()));
+  CHECK(gn_apply(ctx, lay, wk, wk.X(), st->outn_g, st->outn_b, nullptr, 1, wk.A16()));
+  GemmArgs go = gemm_base(lay, wk.A16(), C, 3, C, st->out_w, 256, st->out_bias);
+  go.mode = GEMM_OUT_F32; go.outF = st->net.as<float>(); go.ldo = 256; go.resid = nullptr;
+  return gemm(ctx, "diff_gemm", go);
+}
+
+// Sets up layouts/buffers for B candidates (cond + optionally uncond copies) and the code embedding.
+static int setup_batch(tts_ctx *ctx, DiffState *st, const float *latents, const std::vector<int> &L, bool cond, bool uncond) {
+  const int B = (int)L.size();
+  std::vector<int> lens, src;
+  if (cond) for (int c = 0; c < B; c++) { lens.push_back(tts_diffusion_frames(L[c])); src.push_back(c); }
+  if (uncond) for (int c = 0; c < B; c++) { lens.push_back(tts_diffusion_frames(L[c])); src.push_back(-1); }
+  for (int t : lens) if (t < 1) return fail(ctx, TTS_ERR_ARG, "latent too short");
+  CHECK(st->lay.build(ctx, lens));
+  Layout &lay = st->lay;
+  CHECK(st->wk.reserve(ctx, lay.rows, lay.ns));
+  auto rz = [&](DevBuf &b, size_t bytes) -> hipError_t {
+    size_t old = b.cap;
+    hipError_t e = b.reserve(bytes);
+    if (e == hipSuccess && b.cap != old) e = hipMemset(b.p, 0, b.cap);
+    return e;
+  };
+  TTS_HIP(ctx, rz(st->code_emb, (size_t)lay.rows * C * 4));
+  TTS_HIP(ctx, rz(st->ce, (size_t)lay.rows * C * 4));
+  TTS_HIP(ctx, rz(st->ce16, (size_t)lay.rows * C * 2));
+  TTS_HIP(ctx, rz(st->inp16, (size_t)lay.rows * C * 2));
+  TTS_HIP(ctx, rz(st->xt16, (size_t)(lay.rows + 2) * XTC * 2));
+  TTS_HIP(ctx, hipMemset(st->xt16.p, 0, st->xt16.cap));
+  TTS_HIP(ctx, rz(st->net, (size_t)lay.rows * 256 * 4));
+  TTS_HIP(ctx, st->seq_src.reserve(lay.ns * 4));
+  TTS_HIP(ctx, hipMemcpy(st->seq_src.p, src.data(), lay.ns * 4, hipMemcpyHostToDevice));
+  if (cond) CHECK(latent_conditioner(ctx, st, latents, L));
+  else { // layout still needed by build_code_emb (never dereferenced for uncond rows)
+    CHECK(st->lat_lay.build(ctx, L));
+    CHECK(st->lat_wk.reserve(ctx, st->lat_lay.rows, st->lat_lay.ns));
+  }
+  build_code_emb_kernel<<<lay.rows, 256, 0, ctx->stream>>>(st->lat_wk.H(), st->lat_lay.d_start.as<int>(), st->lat_lay.d_len.as<int>(),
+                                                           st->uncond_emb, lay.d_row_seq.as<int>(), lay.d_row_t.as<int>(),
+                                                           lay.d_len.as<int>(), st->seq_src.as<int>(), st->code_emb.as<float>());
+  TTS_HIP(ctx, hipGetLastError());
+  return TTS_OK;
+}
+
+// tts_diffusion_forward: one evaluation of one branch (parity-test entry point).
+int diff_forward(tts_ctx *ctx, const float *latents, int L, const float *x_t, int timestep, int cond_free, float *out) {
+  DiffState *st = ctx->diff;
+  if (!st) return fail(ctx, TTS_ERR_STATE, "diffusion model not loaded");
+  if (!latents || !x_t || !out || L < 1) return fail(ctx, TTS_ERR_ARG, "tts_diffusion_forward: bad argument");
+  std::vector<int> Ls{L};
+  CHECK(setup_batch(ctx, st, latents, Ls, !cond_free, cond_free));
+  const int T = st->lay.len[0];
+  CHECK(precompute_time(ctx, st, std::vector<int>{timestep}));
+  TTS_HIP(ctx, st->xbuf.reserve((size_t)100 * T * 4));
+  TTS_HIP(ctx, hipMemcpyAsync(st->xbuf.p, x_t, (size_t)100 * T * 4, hipMemcpyHostToDevice, ctx->stream));
+  int64_t off0 = 0;
+  TTS_HIP(ctx, st->xoff.reserve(8));
+  TTS_HIP(ctx, hipMemcpyAsync(st->xoff.p, &off0, 8, hipMemcpyHostToDevice, ctx->stream));
+  Layout &lay = st->lay;
+  xt_to_rows_kernel<<<lay.rows, 128, 0, ctx->stream>>>(st->xbuf.as<float>(), st->xoff.as<int64_t>(), lay.d_row_seq.as<int>(),
+                                                       lay.d_row_t.as<int>(), lay.d_len.as<int>(), lay.d_start.as<int>(), 1, 0,
+                                                       st->xt16.as<__half>() + XTC);
+  CHECK(network_forward(ctx, st, st->ss_all.as<float>()));
+  TTS_HIP(ctx, st->out_ct.reserve((size_t)200 * T * 4));
+  rows_to_ct_kernel<<<(200 * T + 255) / 256, 256, 0, ctx->stream>>>(st->net.as<float>(), lay.start[0], T, 200, 256, st->out_ct.as<float>());
+  TTS_HIP(ctx, hipMemcpyAsync(out, st->out_ct.p, (size_t)200 * T * 4, hipMemcpyDeviceToHost, ctx->stream));
+  TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TTS_OK;
+}
+
+// tts_diffusion: the sampling loop for B candidates.
+int diff_sample(tts_ctx *ctx, const float *latents, const int32_t *rows, int B, int n_steps, const float *noise, int noise_mode,
+                float *mel_out) {
+  DiffState *st = ctx->diff;
+  if (!st) return fail(ctx, TTS_ERR_STATE, "diffusion model not loaded");
+  if (!latents || !rows || !mel_out || B < 1 || n_steps < 2) return fail(ctx, TTS_ERR_ARG, "tts_diffusion: bad argument");
+  std::vector<int> L(rows, rows + B);
+  for (int l : L) if (l < 1 || l > 500) return fail(ctx, TTS_ERR_ARG, "latent rows %d out of range", l);
+  CHECK(setup_batch(ctx, st, latents, L, true, true));
+  Layout &lay = st->lay;
+  DiffSchedule sched;
+  sched.build(n_steps);
+  std::vector<int> ts(n_steps);
+  for (int idx = 0; idx < n_steps; idx++) ts[idx] = sched.timestep_map[n_steps - 1 - idx]; // time_embedding_{idx} (5819-5825)
+  CHECK(precompute_time(ctx, st, ts));
+  // x state [cand][100][T_c]
+  std::vector<int64_t> xoff(B);
+  int64_t total = 0;
+  for (int c = 0; c < B; c++) { xoff[c] = total; total += (int64_t)100 * lay.len[c]; }
+  TTS_HIP(ctx, st->xbuf.reserve(total * 4));
+  TTS_HIP(ctx, st->xoff.reserve(B * 8));
+  TTS_HIP(ctx, hipMemcpy(st->xoff.p, xoff.data(), B * 8, hipMemcpyHostToDevice));
+  const bool host_noise = noise != nullptr || noise_mode == TTS_NOISE_REFERENCE;
+  std::vector<float> hn;
+  if (host_noise) {
+    // per step a [cand][100][T] block in the layout of x: block 0 = x_T, block 1+idx = step idx
+    hn.resize((size_t)total * (n_steps + 1));
+    if (noise) { // caller layout: per candidate (n_steps+1) consecutive vectors
+      size_t src = 0;
+      for (int c = 0; c < B; c++)
+        for (int k = 0; k <= n_steps; k++) {
+          memcpy(hn.data() + (size_t)k * total + xoff[c], noise + src, (size_t)100 * lay.len[c] * 4);
+          src += (size_t)100 * lay.len[c];
+        }
+    } else { // the reference's draw order, candidate after candidate (main.cpp:5638, 6020-6021)
+      for (int c = 0; c < B; c++)
+        for (int k = 0; k <= n_steps; k++) {
+          float *dst = hn.data() + (size_t)k * total + xoff[c];
+          for (int64_t i = 0; i < (int64_t)100 * lay.len[c]; i++) dst[i] = ctx->normal_distribution(ctx->generator);
+        }
+    }
+    TTS_HIP(ctx, st->noise.reserve(hn.size() * 4));
+    TTS_HIP(ctx, hipMemcpy(st->noise.p, hn.data(), hn.size() * 4, hipMemcpyHostToDevice));
+    TTS_HIP(ctx, hipMemcpyAsync(st->xbuf.p, st->noise.p, total * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  } else {
+    for (int c = 0; c < B; c++) {
+      int64_t n = (int64_t)100 * lay.len[c];
+      philox_fill_kernel<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(st->xbuf.as<float>() + xoff[c], n, ctx->seed_value, (uint32_t)c, 0xFFFFFFFFu);
+    }
+  }
+  const size_t ss_stride = (size_t)st->n_res() * 2 * C;
+  for (int idx = 0; idx < n_steps; idx++) {
+    const int t = n_steps - 1 - idx;
+    xt_to_rows_kernel<<<lay.rows, 128, 0, ctx->stream>>>(st->xbuf.as<float>(), st->xoff.as<int64_t>(), lay.d_row_seq.as<int>(),
+                                                         lay.d_row_t.as<int>(), lay.d_len.as<int>(), lay.d_start.as<int>(), B, 1,
+                                                         st->xt16.as<__half>() + XTC);
+    CHECK(network_forward(ctx, st, st->ss_all.as<float>() + (size_t)idx * ss_stride));
+    StepScalars sc{sched.max_log[t], sched.min_log[t], sched.cfk[t], sched.sqrt_recip[t], sched.sqrt_recipm1[t],
+                   sched.coef1[t], sched.coef2[t], t == 0 ? 1 : 0};
+    ProfScope ps(ctx, "diff_update");
+    ddpm_update_kernel<<<lay.rows, 128, 0, ctx->stream>>>(
+        st->net.as<float>(), st->xbuf.as<float>(), st->xoff.as<int64_t>(), lay.d_row_seq.as<int>(), lay.d_row_t.as<int>(),
+        lay.d_len.as<int>(), lay.d_start.as<int>(), B, sc, host_noise ? st->noise.as<float>() + (size_t)(idx + 1) * total : nullptr,
+        ctx->seed_value, (uint32_t)idx);
+    TTS_HIP(ctx, hipGetLastError());
+  }
+  TTS_HIP(ctx, hipMemcpyAsync(mel_out, st->xbuf.p, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+  TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TTS_OK;
+}
+
+} // namespace tts

@@ -1,0 +1,213 @@
+// fp16 x fp16 -> f32 MFMA GEMM for gfx950 (v_mfma_f32_16x16x32_f16), used by the diffusion and
+// vocoder stages for every convolution (the reference's conv1d IS an fp16 im2col GEMM with f32
+// accumulation) and for the attention projections.
+//
+//   C[m][n] = sum_seg sum_k A_seg[m + row_off_seg][k] * W[n][seg*kseg + k]
+//
+// A "segment" is one convolution tap (same activation buffer, row offset -1/0/+1: sequences are
+// packed along M with a zero guard row between them, so a k=3 convolution needs no im2col and no
+// boundary masking) or one half of a channel concat (two buffers, offset 0).
+//
+// Tile 128x128x64, 4 waves (2x2), each wave 4x4 MFMA tiles; LDS double buffered, register staged
+// (global -> VGPR under the MFMAs of the previous tile -> ds_write after them), 16-byte chunks
+// XOR-swizzled by (row>>1)&7 so ds_read_b128 fragment reads spread over all banks.
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+namespace tts {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+enum { GEMM_OUT_F32 = 0, GEMM_OUT_F16 = 1, GEMM_OUT_QKV = 2 };
+
+struct GemmArgs {
+  const __half *A[3];  // per segment base (row 0 of the packed layout)
+  int row_off[3];
+  int nseg, kseg;      // kseg % 64 == 0
+  int lda;             // halves
+  const __half *W;     // [N][nseg*kseg]
+  int M, N;            // multiples of 128 (buffers are padded)
+  const float *bias;   // [N] or nullptr
+  const int *row_seq;  // [M]: sequence id, <0 for guard/padding rows (output forced to 0); may be null
+  // GEMM_OUT_F32
+  float *outF; int ldo; const float *resid; // resid may alias outF
+  // GEMM_OUT_F16 (n_valid columns written) / GEMM_OUT_QKV
+  __half *outH; int ldh;
+  __half *outVt; int ldvt; // QKV: V channels transposed [h*64+d][row]
+  int mode;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+static __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[]; // 2 x (A 16 KB + B 16 KB)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order: blocks b, b+8, b+16 ... (same XCD) walk consecutive n-tiles of one m-tile
+  const int ntn = g.N >> 7, ntiles = (g.M >> 7) * ntn;
+  int bid = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (bid / ntn) << 7, n0 = (bid % ntn) << 7;
+  const int tiles_per_seg = g.kseg >> 6, nk = g.nseg * tiles_per_seg;
+  const int ldw = g.nseg * g.kseg;
+
+  const int lc = tid & 7, lr = tid >> 3; // staging: chunk lc of rows lr, lr+32, lr+64, lr+96
+  uint4 ra[4], rb[4];
+  auto gload = [&](int kt) {
+    const int seg = kt / tiles_per_seg, kk = (kt - seg * tiles_per_seg) << 6;
+    const __half *ap = g.A[seg] + (size_t)(m0 + g.row_off[seg] + lr) * g.lda + kk + lc * 8;
+    const __half *wp = g.W + (size_t)(n0 + lr) * ldw + seg * g.kseg + kk + lc * 8;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      ra[i] = *(const uint4 *)(ap + (size_t)i * 32 * g.lda);
+      rb[i] = *(const uint4 *)(wp + (size_t)i * 32 * ldw);
+    }
+  };
+  auto lstore = [&](int buf) {
+    char *sa = smem + buf * 32768, *sb = sa + 16384;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      *(uint4 *)(sa + lds_off(lr + 32 * i, lc)) = ra[i];
+      *(uint4 *)(sb + lds_off(lr + 32 * i, lc)) = rb[i];
+    }
+  };
+
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload(kt + 1);
+    const char *sa = smem + buf * 32768, *sb = sa + 16384;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      half8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        af[i] = *(const half8 *)(sa + lds_off(wm * 64 + i * 16 + fr, ks * 4 + fq));
+        bf[i] = *(const half8 *)(sb + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + fq*4 + r][n0 + wn*64 + j*16 + fr]
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int rbase = m0 + wm * 64 + i * 16 + fq * 4;
+    bool guard[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) guard[r] = g.row_seq ? (g.row_seq[rbase + r] < 0) : false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int col = n0 + wn * 64 + j * 16 + fr;
+      const float bv = g.bias ? g.bias[col] : 0.f;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = acc[i][j][r] + bv;
+      if (g.mode == GEMM_OUT_F32) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          float o = v[r];
+          if (g.resid) o += g.resid[(size_t)(rbase + r) * g.ldo + col];
+          g.outF[(size_t)(rbase + r) * g.ldo + col] = guard[r] ? 0.f : o;
+        }
+      } else if (g.mode == GEMM_OUT_F16) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          g.outH[(size_t)(rbase + r) * g.ldh + col] = __float2half_rn(guard[r] ? 0.f : v[r]);
+      } else { // QKV: col = h*192 + {q 0..63 | k 64..127 | v 128..191}
+        const int h = col / 192, w = col - h * 192;
+        if (w < 128) {
+#pragma unroll
+          for (int r = 0; r < 4; r++)
+            g.outH[(size_t)(rbase + r) * g.ldh + h * 128 + w] = __float2half_rn(guard[r] ? 0.f : v[r]);
+        } else {
+          __half2 p0 = __floats2half2_rn(guard[0] ? 0.f : v[0], guard[1] ? 0.f : v[1]);
+          __half2 p1 = __floats2half2_rn(guard[2] ? 0.f : v[2], guard[3] ? 0.f : v[3]);
+          uint2 u;
+          u.x = *(unsigned *)&p0;
+          u.y = *(unsigned *)&p1;
+          *(uint2 *)(g.outVt + (size_t)(h * 64 + (w - 128)) * g.ldvt + rbase) = u;
+        }
+      }
+    }
+  }
+}
+
+static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)gemm_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int ntiles = (g.M >> 7) * (g.N >> 7);
+  gemm_f16_kernel<<<ntiles, 256, 65536, s>>>(g);
+  return hipGetLastError();
+}
+
+// out[r][n] = act(sum_k x[r][k] * W[n][k] + b[n]) for small row counts (time MLP, emb_layers):
+// one wave per output column, 16-byte loads along K, shuffle reduction. F32 exact (reference: F32 mul_mat).
+template <int ACT_SILU_IN>
+static __global__ __launch_bounds__(256) void linear_nk_kernel(const float *__restrict__ x, int ldx, int rows, const float *__restrict__ W,
+                                                        int K, int N, const float *__restrict__ b, float *__restrict__ out, int ldo,
+                                                        int lut) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const float *wr = W + (size_t)n * K;
+  for (int r0 = 0; r0 < rows; r0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+      const float4 w = *(const float4 *)(wr + k);
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        if (r0 + i < rows) {
+          float4 xv = *(const float4 *)(x + (size_t)(r0 + i) * ldx + k);
+          if (ACT_SILU_IN) {
+            if (lut) {
+              xv.x = __half2float(__float2half_rn(xv.x)); xv.y = __half2float(__float2half_rn(xv.y));
+              xv.z = __half2float(__float2half_rn(xv.z)); xv.w = __half2float(__float2half_rn(xv.w));
+            }
+            xv.x = xv.x / (1.f + expf(-xv.x)); xv.y = xv.y / (1.f + expf(-xv.y));
+            xv.z = xv.z / (1.f + expf(-xv.z)); xv.w = xv.w / (1.f + expf(-xv.w));
+            if (lut) {
+              xv.x = __half2float(__float2half_rn(xv.x)); xv.y = __half2float(__float2half_rn(xv.y));
+              xv.z = __half2float(__float2half_rn(xv.z)); xv.w = __half2float(__float2half_rn(xv.w));
+            }
+          }
+          acc[i] = fmaf(xv.x, w.x, acc[i]); acc[i] = fmaf(xv.y, w.y, acc[i]);
+          acc[i] = fmaf(xv.z, w.z, acc[i]); acc[i] = fmaf(xv.w, w.w, acc[i]);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      float v = acc[i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0 && r0 + i < rows) out[(size_t)(r0 + i) * ldo + n] = v + (b ? b[n] : 0.f);
+    }
+  }
+}
+
+} // namespace tts
