@@ -49,7 +49,7 @@ void tts_destroy(tts_ctx *ctx);
 const char *tts_last_error(const tts_ctx *ctx);
 /* Options (all have reference defaults): "gn_eps" (1e-6; ggml's GroupNorm epsilon),
  * "ggml_lut" (0/1: emulate ggml-CPU fp16 lookup tables for GELU/SiLU),
- * "ar_exact_prefill" (1: prefill/latent GEMMs in exact f32; 0: split-fp16 MFMA). */
+ * "prof_only:<family>" (1: restrict profiling to one kernel family, 0: all). */
 int tts_set_option(tts_ctx *ctx, const char *key, double value);
 
 /* ---- weight files (drop-in format: magic 0x67676d6c + name-keyed F32 records) ------------- */
@@ -141,10 +141,13 @@ int tts_vocoder(tts_ctx *ctx, const float *mel, const int32_t *frames, int n_can
 int tts_write_wav(const char *path, const float *samples, int64_t n, int sample_rate);
 
 /* ---- measurement hooks (bench.py; not part of the reference seam) -------------------------- */
-/* Accumulated device time (ms, HIP events on the ctx stream) and launch count of the named
- * kernel family since the last reset: "ar_gemv", "diff_gemm", "diff_attn", "voc_lvc", ... */
+/* Accumulated device time (ms; HIP event pairs recorded on the ctx stream around every launch, resolved
+ * lazily so the timed region is not synchronised) and launch count of the named kernel family since the
+ * last reset: "ar_gemv", "ar_attention", "diff_gemm", "diff_attn", "diff_gn_apply", "voc_lvc", ... */
 int tts_prof_reset(tts_ctx *ctx, int enable);
-int tts_prof_get(tts_ctx *ctx, const char *family, double *ms_out, int64_t *launches_out);
+/* work_out: summed algorithmic work of those launches — FLOPs for the MFMA-bound families (diff_gemm,
+ * diff_attn, voc_kernel_gemm), bytes for the HBM-bound ones (ar_gemv: weight bytes streamed). */
+int tts_prof_get(tts_ctx *ctx, const char *family, double *ms_out, int64_t *launches_out, double *work_out);
 
 #ifdef __cplusplus
 }

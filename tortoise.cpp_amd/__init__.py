@@ -61,7 +61,7 @@ def lib():
         "tts_vocoder_samples": (ci, [ci]),
         "tts_vocoder": (ci, [vp, _f32p, _i32p, ci, vp, ci, _f32p]),
         "tts_write_wav": (ci, [C.c_char_p, _f32p, C.c_int64, ci]),
-        "tts_prof_reset": (ci, [vp, ci]), "tts_prof_get": (ci, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+        "tts_prof_reset": (ci, [vp, ci]), "tts_prof_get": (ci, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -244,9 +244,10 @@ class Engine:
         self.L.tts_prof_reset(self.h, 1 if enable else 0)
 
     def prof_get(self, family):
-        ms, n = C.c_double(0), C.c_int64(0)
-        self.L.tts_prof_get(self.h, family.encode(), C.byref(ms), C.byref(n))
-        return ms.value, n.value
+        """(device ms, launches, algorithmic work) of a kernel family since prof_reset."""
+        ms, n, w = C.c_double(0), C.c_int64(0), C.c_double(0)
+        self.L.tts_prof_get(self.h, family.encode(), C.byref(ms), C.byref(n), C.byref(w))
+        return ms.value, n.value, w.value
 
 
 def write_wav(path, samples, rate=24000):

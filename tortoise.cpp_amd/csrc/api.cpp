@@ -18,6 +18,13 @@ int voc_run(tts_ctx *, const float *, const int32_t *, int, const float *, int, 
 
 using namespace tts;
 
+hipEvent_t tts::prof_event(tts_ctx *c) {
+  if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
 extern "C" {
 
 tts_ctx *tts_create(int device) {
@@ -55,6 +62,9 @@ void tts_destroy(tts_ctx *c) {
   if (c->diff) diff_free(c->diff);
   if (c->voc) voc_free(c->voc);
   delete c->tok;
+  for (auto &kv : c->prof)
+    for (auto &pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -68,6 +78,7 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
   std::string k(key);
   if (k == "gn_eps") c->gn_eps = (float)value;
   else if (k == "ggml_lut") c->ggml_lut = value != 0;
+  else if (k.rfind("prof_only:", 0) == 0) c->prof_filter = value != 0 ? k.substr(10) : std::string();
   else return fail(c, TTS_ERR_ARG, "unknown option '%s'", key);
   return TTS_OK;
 }
@@ -218,18 +229,33 @@ int tts_vocoder(tts_ctx *c, const float *mel, const int32_t *frames, int B, cons
   return voc_run(c, mel, frames, B, noise, noise_mode, audio);
 }
 
+static void prof_resolve(tts_ctx *c) {
+  (void)hipStreamSynchronize(c->stream);
+  for (auto &kv : c->prof) {
+    for (auto &pr : kv.second.pending) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { kv.second.ms += ms; kv.second.launches++; }
+      c->ev_pool.push_back(pr.first);
+      c->ev_pool.push_back(pr.second);
+    }
+    kv.second.pending.clear();
+  }
+}
 int tts_prof_reset(tts_ctx *c, int enable) {
   if (!c) return TTS_ERR_ARG;
+  if (c->device >= 0) prof_resolve(c);
   c->prof.clear();
   c->prof_on = enable != 0;
   return TTS_OK;
 }
-int tts_prof_get(tts_ctx *c, const char *family, double *ms, int64_t *launches) {
+int tts_prof_get(tts_ctx *c, const char *family, double *ms, int64_t *launches, double *work) {
   if (!c || !family) return TTS_ERR_ARG;
+  if (c->device >= 0) prof_resolve(c);
   auto it = c->prof.find(family);
-  if (it == c->prof.end()) { if (ms) *ms = 0; if (launches) *launches = 0; return TTS_OK; }
+  if (it == c->prof.end()) { if (ms) *ms = 0; if (launches) *launches = 0; if (work) *work = 0; return TTS_OK; }
   if (ms) *ms = it->second.ms;
   if (launches) *launches = it->second.launches;
+  if (work) *work = it->second.work;
   return TTS_OK;
 }
 

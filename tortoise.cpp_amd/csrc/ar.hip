@@ -347,7 +347,7 @@ static int launch_gemv(tts_ctx *ctx, ArState *st, const float *X, int ldx, int r
   TTS_HIP(ctx, st->part.reserve((size_t)ks * rows * N * sizeof(float)));
   dim3 grid(strips, ks, ztiles);
   float *part = st->part.as<float>();
-  ProfScope ps(ctx, "ar_gemv");
+  ProfScope ps(ctx, "ar_gemv", (double)K * N * 4.0 * ztiles); // weight bytes streamed
   switch (rt) {
     case 1: gemv_kn_kernel<1><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, kchunk, part); break;
     case 2: gemv_kn_kernel<2><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, kchunk, part); break;

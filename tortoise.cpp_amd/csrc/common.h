@@ -47,7 +47,7 @@ struct DevBuf {
   template <class T> T *as() const { return (T *)p; }
 };
 
-struct ProfEntry { double ms = 0; int64_t launches = 0; };
+struct ProfEntry { double ms = 0, work = 0; int64_t launches = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
 
 struct ArState;
 struct DiffState;
@@ -73,9 +73,12 @@ struct tts_ctx {
   tts::DiffState *diff = nullptr;
   tts::VocState *voc = nullptr;
   tts::Tokenizer *tok = nullptr;
-  // profiling
+  // profiling: per kernel family, HIP event pairs recorded on the ctx stream around every launch and
+  // resolved lazily (no host sync inside the timed region)
   bool prof_on = false;
+  std::string prof_filter; // empty = every family
   std::map<std::string, tts::ProfEntry> prof;
+  std::vector<hipEvent_t> ev_pool;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -92,19 +95,22 @@ int fail(tts_ctx *ctx, int code, const char *fmt, ...);
   } while (0)
 
 // Brackets a kernel (family) with HIP events on the ctx stream when profiling is enabled.
+hipEvent_t prof_event(tts_ctx *c);
 struct ProfScope {
-  tts_ctx *c; const char *fam;
-  ProfScope(tts_ctx *ctx, const char *family) : c(ctx), fam(family) {
-    if (c->prof_on) (void)hipEventRecord(c->ev0, c->stream);
+  tts_ctx *c; const char *fam; hipEvent_t a = nullptr;
+  // work: algorithmic FLOPs (MFMA-bound families) or bytes (HBM-bound families) of this launch
+  ProfScope(tts_ctx *ctx, const char *family, double work = 0) : c(ctx), fam(family) {
+    if (c->prof_on && (c->prof_filter.empty() || c->prof_filter == fam)) {
+      a = prof_event(c);
+      (void)hipEventRecord(a, c->stream);
+      c->prof[fam].work += work;
+    }
   }
   ~ProfScope() {
-    if (c->prof_on) {
-      (void)hipEventRecord(c->ev1, c->stream);
-      (void)hipEventSynchronize(c->ev1);
-      float ms = 0;
-      (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-      auto &e = c->prof[fam];
-      e.ms += ms; e.launches++;
+    if (a) {
+      hipEvent_t b = prof_event(c);
+      (void)hipEventRecord(b, c->stream);
+      c->prof[fam].pending.emplace_back(a, b);
     }
   }
 };

@@ -600,8 +600,11 @@ int diff_load(tts_ctx *ctx, const char *path) {
 
 #define CHECK(x) do { int _r = (x); if (_r) return _r; } while (0)
 
-static int gemm(tts_ctx *ctx, const char *fam, GemmArgs &g) {
-  ProfScope ps(ctx, fam);
+// algorithmic FLOPs of one launch: valid rows (no guard/pad rows) x valid columns x valid K
+static int gemm(tts_ctx *ctx, const char *fam, GemmArgs &g, const Layout &lay, int n_valid = 0, int k_valid = 0) {
+  double mv = 0;
+  for (int l : lay.len) mv += l;
+  ProfScope ps(ctx, fam, 2.0 * mv * (n_valid ? n_valid : g.N) * (k_valid ? k_valid : g.nseg * g.kseg));
   TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream));
   return TTS_OK;
 }
@@ -638,9 +641,11 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
   CHECK(gn_apply(ctx, lay, wk, X, w.norm_g, w.norm_b, nullptr, 0, wk.A16()));
   GemmArgs g = gemm_base(lay, wk.A16(), C, 1, C, w.qkv_w, 3 * C, w.qkv_b);
   g.mode = GEMM_OUT_QKV; g.outH = wk.qk16.as<__half>(); g.ldh = 2048; g.outVt = wk.vt16.as<__half>(); g.ldvt = wk.rows + 128;
-  CHECK(gemm(ctx, "diff_gemm", g));
+  CHECK(gemm(ctx, "diff_gemm", g, lay));
   {
-    ProfScope ps(ctx, "diff_attn");
+    double aw = 0;
+    for (int l : lay.len) aw += 4.0 * l * (double)l * 64 * NHEAD; // QK^T + PV
+    ProfScope ps(ctx, "diff_attn", aw);
     dim3 grid((lay.max_len() + 127) / 128, NHEAD, lay.ns);
     diff_attn_kernel<<<grid, 256, 0, ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128, lay.d_start.as<int>(),
                                                     lay.d_len.as<int>(), w.bias_tab, wk.ATT16());
@@ -648,7 +653,7 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
   }
   GemmArgs p = gemm_base(lay, wk.ATT16(), C, 1, C, w.proj_w, C, w.proj_b);
   p.mode = GEMM_OUT_F32; p.outF = X; p.ldo = C; p.resid = X;
-  return gemm(ctx, "diff_gemm", p);
+  return gemm(ctx, "diff_gemm", p, lay);
 }
 
 // ResBlock on X (in place); ss = this step's [scale | shift] for this block (device, 2048 floats).
@@ -657,12 +662,12 @@ static int res_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, f
   CHECK(gn_apply(ctx, lay, wk, X, w.in_g, w.in_b, nullptr, 1, wk.A16()));
   GemmArgs g = gemm_base(lay, wk.A16(), C, 1, C, w.in_w, C, w.in_bias);
   g.mode = GEMM_OUT_F32; g.outF = wk.H(); g.ldo = C; g.resid = nullptr;
-  CHECK(gemm(ctx, "diff_gemm", g));
+  CHECK(gemm(ctx, "diff_gemm", g, lay));
   CHECK(gn_stats(ctx, lay, wk, wk.H()));
   CHECK(gn_apply(ctx, lay, wk, wk.H(), w.out_g, w.out_b, ss, 1, wk.A16()));
   GemmArgs c3 = gemm_base(lay, wk.A16(), C, 3, C, w.out_w, C, w.out_bias);
   c3.mode = GEMM_OUT_F32; c3.outF = X; c3.ldo = C; c3.resid = X;
-  return gemm(ctx, "diff_gemm", c3);
+  return gemm(ctx, "diff_gemm", c3, lay);
 }
 
 // Timestep MLP + every emb_layers linear for `n` timesteps at once:
@@ -706,7 +711,7 @@ static int latent_conditioner(tts_ctx *ctx, DiffState *st, const float *latents_
   to_f16_kernel<<<ll.rows, 256, 0, ctx->stream>>>(wk.X(), ll.d_row_seq.as<int>(), wk.A16());
   GemmArgs c3 = gemm_base(ll, wk.A16(), C, 3, C, st->lc_w, C, st->lc_bias);
   c3.mode = GEMM_OUT_F32; c3.outF = wk.X(); c3.ldo = C; c3.resid = nullptr;
-  CHECK(gemm(ctx, "diff_gemm", c3));
+  CHECK(gemm(ctx, "diff_gemm", c3, ll));
   for (int i = 0; i < st->n_lc; i++) CHECK(attention_block(ctx, st, ll, wk, wk.X(), st->lc_attn[i]));
   CHECK(gn_stats(ctx, ll, wk, wk.X()));
   gn_apply_f32_kernel<<<ll.rows, 256, 0, ctx->stream>>>(wk.X(), ll.d_row_seq.as<int>(), wk.stats.as<float2>(), st->code_g, st->code_b,
@@ -732,12 +737,12 @@ static int network_forward(tts_ctx *ctx, DiffState *st, const float *ss) {
   // inp_block: conv k3 100(->128) -> 1024 on x_t, output rounded to fp16 (operand of the next conv)
   GemmArgs gi = gemm_base(lay, st->xt16.as<__half>() + XTC, XTC, 3, XTC, st->inp_w, C, st->inp_bias);
   gi.mode = GEMM_OUT_F16; gi.outH = inp16; gi.ldh = C;
-  CHECK(gemm(ctx, "diff_gemm", gi));
+  CHECK(gemm(ctx, "diff_gemm", gi, lay, 0, 300));
   // integrating conv k1 over concat[inp | code_emb]
   GemmArgs gc = gemm_base(lay, inp16, C, 2, C, st->integ_w, C, st->integ_bias);
   gc.A[1] = ce16;
   gc.mode = GEMM_OUT_F32; gc.outF = wk.X(); gc.ldo = C; gc.resid = nullptr;
-  CHECK(gemm(ctx, "diff_gemm", gc));
+  CHECK(gemm(ctx, "diff_gemm", gc, lay));
   for (int i = 0; i < st->n_main; i++, j++) {
     CHECK(res_block(ctx, st, lay, wk, wk.X(), st->main_res[i], ss + (size_t)j * 2 * C));
     CHECK(attention_block(ctx, st, lay, wk, wk.X(), st->main_attn[i]));
@@ -747,7 +752,7 @@ static int network_forward(tts_ctx *ctx, DiffState *st, const float *ss) {
   CHECK(gn_apply(ctx, lay, wk, wk.X(), st->outn_g, st->outn_b, nullptr, 1, wk.A16()));
   GemmArgs go = gemm_base(lay, wk.A16(), C, 3, C, st->out_w, 256, st->out_bias);
   go.mode = GEMM_OUT_F32; go.outF = st->net.as<float>(); go.ldo = 256; go.resid = nullptr;
-  return gemm(ctx, "diff_gemm", go);
+  return gemm(ctx, "diff_gemm", go, lay, 200, 0);
 }
 
 // Sets up layouts/buffers for B candidates (cond + optionally uncond copies) and the code embedding.
