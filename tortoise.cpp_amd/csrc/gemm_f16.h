@@ -152,6 +152,136 @@ static __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
   }
 }
 
+// Variant 1: single 32 KB LDS stage filled by direct global->LDS DMA (global_load_lds_dwordx4): no
+// staging VGPRs, no ds_write pass; 3-4 workgroups per CU overlap each other's load/compute phases.
+// The LDS image of a DMA is lane-linear (base + lane*16), so the XOR swizzle is applied to the per-lane
+// SOURCE address and again on the fragment read.
+typedef const void __attribute__((address_space(1))) *gptr_t;
+typedef void __attribute__((address_space(3))) *lptr_t;
+
+// Epilogues. For F32/F16 outputs the MFMA operands are swapped (A-operand = weight rows, B-operand =
+// activation rows), so a lane's 4 accumulator registers are 4 CONSECUTIVE output columns of one row:
+// residual loads and stores are 16 bytes per lane instead of 4. The QKV mode keeps the natural order
+// (a lane holds 4 consecutive rows of one column) because V is stored transposed.
+template <int MODE>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, floatx4 (&acc)[4][4], int m0, int n0, int wm, int wn, int fr, int fq) {
+  if (MODE == GEMM_OUT_QKV) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int rbase = m0 + wm * 64 + i * 16 + fq * 4;
+      bool guard[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) guard[r] = g.row_seq ? (g.row_seq[rbase + r] < 0) : false;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int col = n0 + wn * 64 + j * 16 + fr;
+        const float bv = g.bias ? g.bias[col] : 0.f;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = guard[r] ? 0.f : acc[i][j][r] + bv;
+        const int h = col / 192, w = col - h * 192;
+        if (w < 128) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) g.outH[(size_t)(rbase + r) * g.ldh + h * 128 + w] = __float2half_rn(v[r]);
+        } else {
+          __half2 p0 = __floats2half2_rn(v[0], v[1]), p1 = __floats2half2_rn(v[2], v[3]);
+          uint2 u;
+          u.x = *(unsigned *)&p0;
+          u.y = *(unsigned *)&p1;
+          *(uint2 *)(g.outVt + (size_t)(h * 64 + (w - 128)) * g.ldvt + rbase) = u;
+        }
+      }
+    }
+  } else {
+    // acc[i][j][r] = C[m0 + wm*64 + i*16 + fr][n0 + wn*64 + j*16 + fq*4 + r]
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int row = m0 + wm * 64 + i * 16 + fr;
+      const bool guard = g.row_seq ? (g.row_seq[row] < 0) : false;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int col = n0 + wn * 64 + j * 16 + fq * 4;
+        float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (g.bias) {
+          const float4 b = *(const float4 *)(g.bias + col);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (MODE == GEMM_OUT_F32) {
+          if (g.resid) {
+            const float4 rr = *(const float4 *)(g.resid + (size_t)row * g.ldo + col);
+            v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+          }
+          if (guard) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          *(float4 *)(g.outF + (size_t)row * g.ldo + col) = v;
+        } else {
+          if (guard) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          __half2 p0 = __floats2half2_rn(v.x, v.y), p1 = __floats2half2_rn(v.z, v.w);
+          uint2 u;
+          u.x = *(unsigned *)&p0;
+          u.y = *(unsigned *)&p1;
+          *(uint2 *)(g.outH + (size_t)row * g.ldh + col) = u;
+        }
+      }
+    }
+  }
+}
+
+template <int MODE>
+static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) char smem[32768];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = g.N >> 7, ntiles = (g.M >> 7) * ntn;
+  int bid = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (bid / ntn) << 7, n0 = (bid % ntn) << 7;
+  const int tiles_per_seg = g.kseg >> 6, nk = g.nseg * tiles_per_seg;
+  const int ldw = g.nseg * g.kseg;
+  // DMA roles: wave w, piece i covers rows (w*4+i)*8 .. +7 of the A tile and of the B tile
+  const int prow = lane >> 3, pslot = lane & 7;
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  char *sa = smem, *sb = smem + 16384;
+  for (int kt = 0; kt < nk; kt++) {
+    const int seg = kt / tiles_per_seg, kk = (kt - seg * tiles_per_seg) << 6;
+    const __half *abase = g.A[seg] + (size_t)(m0 + g.row_off[seg]) * g.lda + kk;
+    const __half *wbase = g.W + (size_t)n0 * ldw + seg * g.kseg + kk;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int row = (wave * 4 + i) * 8 + prow;
+      const int c = pslot ^ ((row >> 1) & 7);
+      __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)row * g.lda + c * 8), (lptr_t)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (size_t)row * ldw + c * 8), (lptr_t)(sb + (wave * 4 + i) * 1024), 16, 0, 0);
+    }
+    __syncthreads(); // waits vmcnt(0) for the DMA, then barrier
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      half8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        af[i] = *(const half8 *)(sa + lds_off(wm * 64 + i * 16 + fr, ks * 4 + fq));
+        bf[i] = *(const half8 *)(sb + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (MODE == GEMM_OUT_QKV) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  gemm_epilogue<MODE>(g, acc, m0, n0, wm, wn, fr, fq);
+}
+
 static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -160,7 +290,13 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
     attr_set = true;
   }
   const int ntiles = (g.M >> 7) * (g.N >> 7);
-  gemm_f16_kernel<<<ntiles, 256, 65536, s>>>(g);
+#ifndef TTS_GEMM_VARIANT
+#define TTS_GEMM_VARIANT 1
+#endif
+  if (TTS_GEMM_VARIANT == 0) gemm_f16_kernel<<<ntiles, 256, 65536, s>>>(g);
+  else if (g.mode == GEMM_OUT_F32) gemm_f16_glds_kernel<GEMM_OUT_F32><<<ntiles, 256, 0, s>>>(g);
+  else if (g.mode == GEMM_OUT_F16) gemm_f16_glds_kernel<GEMM_OUT_F16><<<ntiles, 256, 0, s>>>(g);
+  else gemm_f16_glds_kernel<GEMM_OUT_QKV><<<ntiles, 256, 0, s>>>(g);
   return hipGetLastError();
 }
 
