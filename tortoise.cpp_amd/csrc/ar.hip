@@ -82,10 +82,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 // thread (cx = tid&15, ky = tid>>4) owns 4 columns and every 16th k of the chunk, so a wave's load
 // instruction covers 4 consecutive W rows x 256 B. Reduction over ky: shuffles inside a wave, LDS
 // across the 4 waves; the K chunks are summed in order by the epilogue kernel (deterministic).
-template <int RT>
+// PRO = 1: the input is itself a split-K partial buffer and x[r][k] = gelu(sum_s pin[s][r][k] + bin[k]) is
+// formed while staging (fuses the c_fc epilogue into the c_proj GEMV); X then points at pin, ldx = its N.
+template <int RT, int PRO>
 __global__ __launch_bounds__(256) void gemv_kn_kernel(const float *__restrict__ X, int ldx, int rows,
                                                       const float *__restrict__ W, int N, int kspan,
-                                                      float *__restrict__ part) {
+                                                      float *__restrict__ part, int pin_ks, const float *__restrict__ pin_bias,
+                                                      int lut) {
   __shared__ float xs[256 * RT];
   __shared__ float red[4 * RT * 64];
   const int tid = threadIdx.x, cx = tid & 15, ky = tid >> 4;
@@ -100,7 +103,15 @@ __global__ __launch_bounds__(256) void gemv_kn_kernel(const float *__restrict__ 
     __syncthreads();
     for (int idx = tid; idx < kchunk * RT; idx += 256) {
       int r = idx / kchunk, k = idx - r * kchunk;
-      xs[k * RT + r] = (r0 + r < rows) ? X[(size_t)(r0 + r) * ldx + k0 + k] : 0.f;
+      float xv = 0.f;
+      if (r0 + r < rows) {
+        xv = X[(size_t)(r0 + r) * ldx + k0 + k];
+        if (PRO) {
+          for (int sp = 1; sp < pin_ks; sp++) xv += X[((size_t)sp * rows + r0 + r) * ldx + k0 + k];
+          xv = gelu_tanh(xv + pin_bias[k0 + k], lut);
+        }
+      }
+      xs[k * RT + r] = xv;
     }
     __syncthreads();
     const float *wp = W + (size_t)(k0 + ky) * N + col0;
@@ -153,7 +164,7 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const float *__restrict__
                                                        int n_valid, const float *__restrict__ bias,
                                                        float *__restrict__ out, int ldo, KvDst kv, int lut) {
   const int r = blockIdx.x;
-  for (int n = threadIdx.x; n < n_valid; n += 256) {
+  for (int n = blockIdx.y * 256 + threadIdx.x; n < n_valid; n += 256 * gridDim.y) {
     float v = part[(size_t)r * N + n];
     for (int s = 1; s < ks; s++) v += part[((size_t)s * rows + r) * N + n];
     v += bias[n];
@@ -232,6 +243,244 @@ __global__ __launch_bounds__(64) void attention_kernel(const float *__restrict__
   out[(size_t)r * D + h * HD + lane] = acc;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Decode-step kernels (one new position per candidate). The step is captured in a hipGraph: the
+// position counters live in device memory so the same graph is replayed for every step.
+// ---------------------------------------------------------------------------------------------
+struct StepState { int n_past; int pos_id; };
+
+__global__ __launch_bounds__(256) void embed_step_kernel(const float *__restrict__ mel_emb, const float *__restrict__ mel_pos,
+                                                         const int *__restrict__ toks, const StepState *__restrict__ ss,
+                                                         float *__restrict__ h) {
+  const int r = blockIdx.x;
+  const float4 a = ((const float4 *)(mel_emb + (size_t)toks[r] * D))[threadIdx.x];
+  const float4 b = ((const float4 *)(mel_pos + (size_t)ss->pos_id * D))[threadIdx.x];
+  ((float4 *)(h + (size_t)r * D))[threadIdx.x] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+// h += sum_s part[s] + bias (when part != null), then xn = LayerNorm(h)*g + b. One block per row.
+__global__ __launch_bounds__(256) void reduce_ln_kernel(const float *__restrict__ part, int ks, int rows, const float *__restrict__ bias,
+                                                        float *__restrict__ h, const float *__restrict__ g, const float *__restrict__ b,
+                                                        float *__restrict__ xn) {
+  __shared__ float sh[4];
+  const size_t row = blockIdx.x;
+  float4 v = ((const float4 *)(h + row * D))[threadIdx.x];
+  if (part) {
+    // all partial loads are independent: issue them 8 at a time, add in s order (deterministic)
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = 0; s0 < ks; s0 += 8) {
+      float4 p[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        p[u] = (s0 + u < ks) ? ((const float4 *)(part + ((size_t)(s0 + u) * rows + row) * D))[threadIdx.x] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 8; u++) { a.x += p[u].x; a.y += p[u].y; a.z += p[u].z; a.w += p[u].w; }
+    }
+    const float4 bi = ((const float4 *)bias)[threadIdx.x];
+    v.x += a.x + bi.x; v.y += a.y + bi.y; v.z += a.z + bi.z; v.w += a.w + bi.w;
+    ((float4 *)(h + row * D))[threadIdx.x] = v;
+  }
+  const float mean = block_sum_256(v.x + v.y + v.z + v.w, sh) * (1.0f / D);
+  v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
+  const float var = block_sum_256(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w, sh) * (1.0f / D);
+  const float sc = 1.0f / sqrtf(var + 1e-5f);
+  const float4 gg = ((const float4 *)g)[threadIdx.x], bb = ((const float4 *)b)[threadIdx.x];
+  v.x = v.x * sc * gg.x + bb.x; v.y = v.y * sc * gg.y + bb.y;
+  v.z = v.z * sc * gg.z + bb.z; v.w = v.w * sc * gg.w + bb.w;
+  ((float4 *)(xn + row * D))[threadIdx.x] = v;
+}
+
+// Decode attention for one (candidate, head): reduces the QKV split-K partials (+bias, fp16 round, as
+// main.cpp:2789-2790), appends K/V to the fp16 cache at position n_past, then softmax(q.K/8) V over
+// n_past+1 keys. 4 waves: keys are spread over all 256 threads for the scores and over 4 groups for PV.
+__global__ __launch_bounds__(256) void attn_decode_kernel(const float *__restrict__ part, int ks, int B, const float *__restrict__ bias,
+                                                          __half *__restrict__ kc, __half *__restrict__ vc,
+                                                          const StepState *__restrict__ ss, int max_pos, float *__restrict__ out, int lut) {
+  __shared__ float sc[1024];
+  __shared__ float qs[HD];
+  __shared__ float red[16 * HD];
+  __shared__ float wred[8];
+  const int c = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_past = ss->n_past, nk = n_past + 1;
+  __half *kb = kc + (size_t)c * max_pos * D + h * HD;
+  __half *vb = vc + (size_t)c * max_pos * D + h * HD;
+  if (tid < 3 * HD) {
+    const int which = tid >> 6, d = tid & 63, n = which * D + h * HD + d;
+    float v = 0.f;
+    for (int s0 = 0; s0 < ks; s0 += 8) {
+      float p[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) p[u] = (s0 + u < ks) ? part[((size_t)(s0 + u) * B + c) * 3 * D + n] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; u++) v += p[u];
+    }
+    v += bias[n];
+    const __half hv = __float2half_rn(v);
+    if (which == 0) qs[d] = __half2float(hv);
+    else if (which == 1) kb[(size_t)n_past * D + d] = hv;
+    else vb[(size_t)n_past * D + d] = hv;
+  }
+  __threadfence_block();
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int j = tid; j < nk; j += 256) {
+    const uint4 *kp = (const uint4 *)(kb + (size_t)j * D);
+    uint4 u[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) u[q] = kp[q];
+    float dot = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const __half2 *h2 = (const __half2 *)&u[q];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float2 f = __half22float2(h2[e]);
+        dot = fmaf(qs[q * 8 + e * 2], f.x, dot);
+        dot = fmaf(qs[q * 8 + e * 2 + 1], f.y, dot);
+      }
+    }
+    dot *= 0.125f;
+    sc[j] = dot;
+    mx = fmaxf(mx, dot);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if (lane == 0) wred[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+  float sum = 0.f;
+  for (int j = tid; j < nk; j += 256) {
+    const float e = lut ? f16_round(expf(f16_round(sc[j] - mx))) : expf(sc[j] - mx);
+    sc[j] = e;
+    sum += e;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if (lane == 0) wred[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (((wred[4] + wred[5]) + wred[6]) + wred[7]);
+  // PV: 16 key groups x 16 lanes; a lane owns 4 consecutive dims (8-byte loads), keys j = grp, grp+16, ...
+  const int dl = tid & 15, grp = tid >> 4;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int j0 = grp; j0 < nk; j0 += 16 * 8) {
+    uint2 vv[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int j = j0 + u * 16;
+      vv[u] = (j < nk) ? *(const uint2 *)(vb + (size_t)j * D + dl * 4) : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int j = j0 + u * 16;
+      const float p = (j < nk) ? sc[j] * inv : 0.f;
+      const float2 f0 = __half22float2(*(const __half2 *)&vv[u].x), f1 = __half22float2(*(const __half2 *)&vv[u].y);
+      a0 = fmaf(p, f0.x, a0); a1 = fmaf(p, f0.y, a1); a2 = fmaf(p, f1.x, a2); a3 = fmaf(p, f1.y, a3);
+    }
+  }
+  red[grp * HD + dl * 4 + 0] = a0; red[grp * HD + dl * 4 + 1] = a1;
+  red[grp * HD + dl * 4 + 2] = a2; red[grp * HD + dl * 4 + 3] = a3;
+  __syncthreads();
+  if (tid < HD) {
+    float o = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < 16; g2++) o += red[g2 * HD + tid];
+    out[(size_t)c * D + h * HD + tid] = o;
+  }
+}
+
+// Decode GEMV (rows <= 16, one K span of NK*16 <= 256 per block): same split-K layout and summation order
+// as gemv_kn_kernel, but latency-oriented — every W load of the thread is issued before anything else,
+// the X staging loads are fully unrolled, and with PRO the c_fc epilogue (partial reduce + bias + GELU)
+// is evaluated while staging.
+template <int RT, int NK, int PRO>
+__global__ __launch_bounds__(256) void gemv_decode_kernel(const float *__restrict__ X, int ldx, int rows,
+                                                          const float *__restrict__ W, int N, float *__restrict__ part,
+                                                          int pin_ks, const float *__restrict__ pin_bias, int lut) {
+  constexpr int KS = NK * 16;
+  __shared__ float xs[KS * RT];
+  __shared__ float red[4 * RT * 64];
+  const int tid = threadIdx.x, cx = tid & 15, ky = tid >> 4;
+  const int col0 = blockIdx.x * 64 + cx * 4;
+  const int k0 = blockIdx.y * KS;
+  float4 w[NK];
+  {
+    const float *wp = W + (size_t)(k0 + ky) * N + col0;
+#pragma unroll
+    for (int i = 0; i < NK; i++) w[i] = *(const float4 *)(wp + (size_t)i * 16 * N);
+  }
+  constexpr int PER = (KS * RT + 255) / 256;
+  float xv[PER];
+#pragma unroll
+  for (int it = 0; it < PER; it++) {
+    const int idx = tid + it * 256, r = idx / KS, k = idx % KS;
+    xv[it] = (idx < KS * RT && r < rows) ? X[(size_t)r * ldx + k0 + k] : 0.f;
+  }
+  if (PRO) {
+    // c_fc partials: all pin_ks x PER loads are independent -> issue them in groups of 8 splits
+    for (int sp0 = 1; sp0 < pin_ks; sp0 += 8) {
+      float pv[8][PER];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+#pragma unroll
+        for (int it = 0; it < PER; it++) {
+          const int idx = tid + it * 256, r = idx / KS, k = idx % KS, sp = sp0 + u;
+          pv[u][it] = (sp < pin_ks && idx < KS * RT && r < rows) ? X[((size_t)sp * rows + r) * ldx + k0 + k] : 0.f;
+        }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+#pragma unroll
+        for (int it = 0; it < PER; it++) xv[it] += pv[u][it];
+    }
+#pragma unroll
+    for (int it = 0; it < PER; it++) {
+      const int idx = tid + it * 256, k = idx % KS;
+      if (idx < KS * RT) xv[it] = gelu_tanh(xv[it] + pin_bias[k0 + k], lut);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < PER; it++) {
+    const int idx = tid + it * 256, r = idx / KS, k = idx % KS;
+    if (idx < KS * RT) xs[k * RT + r] = xv[it];
+  }
+  __syncthreads();
+  float acc[RT][4];
+#pragma unroll
+  for (int r = 0; r < RT; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < NK; i++) {
+    const int k = ky + i * 16;
+#pragma unroll
+    for (int r = 0; r < RT; r++) {
+      const float x = xs[k * RT + r];
+      acc[r][0] = fmaf(x, w[i].x, acc[r][0]); acc[r][1] = fmaf(x, w[i].y, acc[r][1]);
+      acc[r][2] = fmaf(x, w[i].z, acc[r][2]); acc[r][3] = fmaf(x, w[i].w, acc[r][3]);
+    }
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int r = 0; r < RT; r++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float v = acc[r][j];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lane < 16) red[(wave * RT + r) * 64 + cx * 4 + j] = v;
+    }
+  __syncthreads();
+  for (int idx = tid; idx < RT * 16; idx += 256) {
+    const int r = idx >> 4, c4 = idx & 15;
+    if (r < rows) {
+      float4 sres;
+      const float *p0 = &red[(0 * RT + r) * 64 + c4 * 4], *p1 = &red[(1 * RT + r) * 64 + c4 * 4];
+      const float *p2 = &red[(2 * RT + r) * 64 + c4 * 4], *p3 = &red[(3 * RT + r) * 64 + c4 * 4];
+      sres.x = ((p0[0] + p1[0]) + p2[0]) + p3[0]; sres.y = ((p0[1] + p1[1]) + p2[1]) + p3[1];
+      sres.z = ((p0[2] + p1[2]) + p2[2]) + p3[2]; sres.w = ((p0[3] + p1[3]) + p2[3]) + p3[3];
+      *(float4 *)&part[((size_t)blockIdx.y * rows + r) * N + blockIdx.x * 64 + c4 * 4] = sres;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -252,7 +501,23 @@ struct ArState {
   std::vector<int> tokens;
   DevBuf voice, kcache, vcache, lat_k, lat_v;
   DevBuf h, xn, qkv, att, ff, part, desc, logits, hn;
-  ~ArState() { for (void *p : owned) (void)hipFree(p); }
+  // decode-step graph
+  DevBuf partA, partB, d_toks;
+  int32_t *h_toks = nullptr;   // pinned
+  float *h_logits = nullptr;   // pinned [B][8194]
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  void drop_graph() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    graph_exec = nullptr; graph = nullptr;
+  }
+  ~ArState() {
+    drop_graph();
+    if (h_toks) (void)hipHostFree(h_toks);
+    if (h_logits) (void)hipHostFree(h_logits);
+    for (void *p : owned) (void)hipFree(p);
+  }
 };
 
 void ar_free(ArState *s) { delete s; }
@@ -336,25 +601,46 @@ int ar_load(tts_ctx *ctx, const char *path) {
 // ---- launch helpers -----------------------------------------------------------------------------
 static int pick_rt(int rows) { int rt = 1; while (rt < rows && rt < 16) rt <<= 1; return rt; }
 
-// part <- X[rows][K] * W[K][N]; returns ks through *ks_out.
+// part <- X[rows][K] * W[K][N]; returns ks through *ks_out. pin_ks > 0: X is a partial buffer (see PRO).
 static int launch_gemv(tts_ctx *ctx, ArState *st, const float *X, int ldx, int rows, const float *W, int N, int K,
-                       int *ks_out) {
+                       int *ks_out, float *part = nullptr, int pin_ks = 0, const float *pin_bias = nullptr) {
   const int rt = pick_rt(rows);
   const int ztiles = (rows + rt - 1) / rt, strips = N / 64;
   int ks = 1;
   while (ks * 2 * strips * ztiles <= 768 && K / (ks * 2) >= 32) ks *= 2;
   const int kchunk = K / ks; // K range per block (staged through LDS in chunks of <= 256)
-  TTS_HIP(ctx, st->part.reserve((size_t)ks * rows * N * sizeof(float)));
-  dim3 grid(strips, ks, ztiles);
-  float *part = st->part.as<float>();
-  ProfScope ps(ctx, "ar_gemv", (double)K * N * 4.0 * ztiles); // weight bytes streamed
-  switch (rt) {
-    case 1: gemv_kn_kernel<1><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, kchunk, part); break;
-    case 2: gemv_kn_kernel<2><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, kchunk, part); break;
-    case 4: gemv_kn_kernel<4><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, kchunk, part); break;
-    case 8: gemv_kn_kernel<8><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, kchunk, part); break;
-    default: gemv_kn_kernel<16><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, kchunk, part); break;
+  if (!part) {
+    TTS_HIP(ctx, st->part.reserve((size_t)ks * rows * N * sizeof(float)));
+    part = st->part.as<float>();
   }
+  dim3 grid(strips, ks, ztiles);
+  ProfScope ps(ctx, "ar_gemv", (double)K * N * 4.0 * ztiles); // weight bytes streamed
+  if (ztiles == 1 && rows <= 16 && kchunk <= 256 && (kchunk == 32 || kchunk == 64 || kchunk == 128 || kchunk == 256)) {
+#define DEC_LAUNCH(NK_)                                                                                                      \
+  if (pin_ks > 0) gemv_decode_kernel<16, NK_, 1><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, part, pin_ks, pin_bias, ctx->ggml_lut); \
+  else gemv_decode_kernel<16, NK_, 0><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, part, 0, nullptr, 0)
+    switch (kchunk) {
+      case 32: DEC_LAUNCH(2); break;
+      case 64: DEC_LAUNCH(4); break;
+      case 128: DEC_LAUNCH(8); break;
+      default: DEC_LAUNCH(16); break;
+    }
+#undef DEC_LAUNCH
+    TTS_HIP(ctx, hipGetLastError());
+    *ks_out = ks;
+    return TTS_OK;
+  }
+#define GEMV_LAUNCH(RT_)                                                                                                   \
+  if (pin_ks > 0) gemv_kn_kernel<RT_, 1><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, kchunk, part, pin_ks, pin_bias, ctx->ggml_lut); \
+  else gemv_kn_kernel<RT_, 0><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, kchunk, part, 0, nullptr, 0)
+  switch (rt) {
+    case 1: GEMV_LAUNCH(1); break;
+    case 2: GEMV_LAUNCH(2); break;
+    case 4: GEMV_LAUNCH(4); break;
+    case 8: GEMV_LAUNCH(8); break;
+    default: GEMV_LAUNCH(16); break;
+  }
+#undef GEMV_LAUNCH
   TTS_HIP(ctx, hipGetLastError());
   *ks_out = ks;
   return TTS_OK;
@@ -364,8 +650,8 @@ template <int MODE>
 static int launch_epilogue(tts_ctx *ctx, ArState *st, int ks, int rows, int N, int n_valid, const float *bias, float *out,
                            int ldo, KvDst kv) {
   ProfScope ps(ctx, "ar_epilogue");
-  epilogue_kernel<MODE><<<rows, 256, 0, ctx->stream>>>(st->part.as<float>(), ks, rows, N, n_valid, bias, out, ldo, kv,
-                                                       ctx->ggml_lut);
+  epilogue_kernel<MODE><<<dim3(rows, (n_valid + 255) / 256), 256, 0, ctx->stream>>>(st->part.as<float>(), ks, rows, N, n_valid, bias,
+                                                                                    out, ldo, kv, ctx->ggml_lut);
   TTS_HIP(ctx, hipGetLastError());
   return TTS_OK;
 }
@@ -458,6 +744,16 @@ int ar_begin(tts_ctx *ctx, const int32_t *text_ids, int n_text, const float *voi
   size_t cache = (size_t)st->n_layers * B * st->max_pos * D * sizeof(__half);
   TTS_HIP(ctx, st->kcache.reserve(cache));
   TTS_HIP(ctx, st->vcache.reserve(cache));
+  st->drop_graph(); // buffers may have moved
+  // split-K partials: ks * N <= 768 * 64 columns per row by construction of launch_gemv
+  TTS_HIP(ctx, st->partA.reserve((size_t)65536 * B * 4));
+  TTS_HIP(ctx, st->partB.reserve((size_t)65536 * B * 4));
+  TTS_HIP(ctx, st->d_toks.reserve((size_t)(B + 2) * 4)); // [tokens | n_past, pos_id]
+  TTS_HIP(ctx, st->logits.reserve((size_t)B * V * 4));
+  if (st->h_toks) (void)hipHostFree(st->h_toks);
+  if (st->h_logits) (void)hipHostFree(st->h_logits);
+  TTS_HIP(ctx, hipHostMalloc((void **)&st->h_toks, (size_t)(B + 2) * 4));
+  TTS_HIP(ctx, hipHostMalloc((void **)&st->h_logits, (size_t)B * V * 4));
   return reserve_rows(ctx, st, std::max(B, st->P));
 }
 
@@ -477,21 +773,79 @@ int ar_prefill(tts_ctx *ctx, float *logits_out) {
   return head_logits(ctx, st, st->h.as<float>() + (size_t)(P - 1) * D, 1, logits_out, st->B);
 }
 
+// One decode step for all candidates, enqueued on the ctx stream (captured once into a hipGraph).
+// Per layer: reduce+LN1 | c_attn GEMV | attention (QKV reduce + KV append + softmax.V) | c_proj GEMV |
+// reduce+LN2 | c_fc GEMV | c_proj GEMV with fused bias+GELU prologue  -> 7 launches.
+static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
+  const int B = st->B;
+  float *h = st->h.as<float>(), *xn = st->xn.as<float>(), *hn = st->hn.as<float>(), *att = st->att.as<float>();
+  float *pA = st->partA.as<float>(), *pB = st->partB.as<float>();
+  const StepState *ss = (const StepState *)(st->d_toks.as<int>() + B);
+  const size_t layer_stride = (size_t)B * st->max_pos * D;
+  TTS_HIP(ctx, hipMemcpyAsync(st->d_toks.p, st->h_toks, (size_t)(B + 2) * 4, hipMemcpyHostToDevice, ctx->stream));
+  embed_step_kernel<<<B, 256, 0, ctx->stream>>>(st->mel_emb, st->mel_pos, st->d_toks.as<int>(), ss, h);
+  int ks_prev = 0, ks;
+  const float *bias_prev = nullptr;
+  for (int l = 0; l < st->n_layers; l++) {
+    const ArLayerDev &w = st->L[l];
+    { ProfScope ps(ctx, "ar_reduce_ln");
+      reduce_ln_kernel<<<B, 256, 0, ctx->stream>>>(l ? pB : nullptr, ks_prev, B, bias_prev, h, w.ln1_g, w.ln1_b, xn); }
+    CHECK(launch_gemv(ctx, st, xn, D, B, w.w_attn, 3 * D, D, &ks, pA));
+    { ProfScope ps(ctx, "ar_attention");
+      attn_decode_kernel<<<dim3(B, NH), 256, 0, ctx->stream>>>(pA, ks, B, w.b_attn, st->kcache.as<__half>() + l * layer_stride,
+                                                               st->vcache.as<__half>() + l * layer_stride, ss, st->max_pos, att,
+                                                               ctx->ggml_lut); }
+    CHECK(launch_gemv(ctx, st, att, D, B, w.w_proj, D, D, &ks, pB));
+    { ProfScope ps(ctx, "ar_reduce_ln");
+      reduce_ln_kernel<<<B, 256, 0, ctx->stream>>>(pB, ks, B, w.b_proj, h, w.ln2_g, w.ln2_b, xn); }
+    CHECK(launch_gemv(ctx, st, xn, D, B, w.w_fc, FF, D, &ks, pA));
+    const int ks_fc = ks;
+    CHECK(launch_gemv(ctx, st, pA, FF, B, w.w_fc2, D, FF, &ks, pB, ks_fc, w.b_fc));
+    ks_prev = ks;
+    bias_prev = w.b_fc2;
+  }
+  { ProfScope ps(ctx, "ar_reduce_ln");
+    reduce_ln_kernel<<<B, 256, 0, ctx->stream>>>(pB, ks_prev, B, bias_prev, h, st->lnf_g, st->lnf_b, xn);
+    layernorm_kernel<<<B, 256, 0, ctx->stream>>>(xn, st->lmh_g, st->lmh_b, hn); }
+  CHECK(launch_gemv(ctx, st, hn, D, B, st->lm_w, VPAD, D, &ks, pA));
+  {
+    ProfScope ps(ctx, "ar_epilogue");
+    KvDst nokv{nullptr, nullptr, 1, 0, 0, 0};
+    epilogue_kernel<EPI_BIAS><<<dim3(B, (V + 255) / 256), 256, 0, ctx->stream>>>(pA, ks, B, VPAD, V, st->lm_b, st->logits.as<float>(), V,
+                                                                             nokv, 0);
+  }
+  TTS_HIP(ctx, hipMemcpyAsync(st->h_logits, st->logits.p, (size_t)B * V * 4, hipMemcpyDeviceToHost, ctx->stream));
+  TTS_HIP(ctx, hipGetLastError());
+  return TTS_OK;
+}
+
 // Decode step i (main.cpp:2667-2693, 5227-5247): mel_emb[tok] + mel_pos[i+2], n_past = P + i.
 int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out) {
   ArState *st = ctx->ar;
   if (!st || st->B == 0) return fail(ctx, TTS_ERR_STATE, "tts_ar_begin not called");
   if (step_i < 0 || st->P + step_i >= st->max_pos) return fail(ctx, TTS_ERR_LIMIT, "step %d beyond the KV cache", step_i);
-  std::vector<int4> desc(st->B);
   for (int c = 0; c < st->B; c++) {
     if (prev_ids[c] < 0 || prev_ids[c] >= V) return fail(ctx, TTS_ERR_ARG, "mel token %d out of range", prev_ids[c]);
-    desc[c] = make_int4(2, prev_ids[c], 1, step_i + 2);
+    st->h_toks[c] = prev_ids[c];
   }
-  CHECK(embed(ctx, st, desc));
-  const size_t layer_stride = (size_t)st->B * st->max_pos * D;
-  CHECK(run_layers(ctx, st, st->B, 1, st->P + step_i, st->kcache.as<__half>(), st->vcache.as<__half>(), layer_stride,
-                   st->max_pos, 0));
-  return head_logits(ctx, st, st->h.as<float>(), st->B, logits_out, 1);
+  st->h_toks[st->B] = st->P + step_i; // n_past
+  st->h_toks[st->B + 1] = step_i + 2; // mel position id (main.cpp:5244)
+  if (ctx->prof_on) { // event records are not captured: run eagerly when profiling
+    CHECK(enqueue_decode_step(ctx, st));
+  } else {
+    if (!st->graph_exec) {
+      TTS_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+      int rc = enqueue_decode_step(ctx, st);
+      hipError_t e = hipStreamEndCapture(ctx->stream, &st->graph);
+      if (rc) return rc;
+      TTS_HIP(ctx, e);
+      TTS_HIP(ctx, hipGraphInstantiate(&st->graph_exec, st->graph, nullptr, nullptr, 0));
+    }
+    TTS_HIP(ctx, hipGraphLaunch(st->graph_exec, ctx->stream));
+  }
+  TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (logits_out) memcpy(logits_out, st->h_logits, (size_t)st->B * V * 4);
+  return TTS_OK;
 }
 
 // Latent pass (main.cpp:2053-2519, 5280-5352): full causal forward without the decode cache.
