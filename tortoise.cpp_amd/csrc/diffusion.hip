@@ -39,33 +39,30 @@ __device__ __forceinline__ float silu_dev(float x, int lut) {
 // [T,1,1024]; eps inside rstd). grid (32, ns), block 256: 8 threads x float4 per row.
 __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, const int *__restrict__ seq_start,
                                                        const int *__restrict__ seq_len, float eps, float2 *__restrict__ stats) {
-  __shared__ float sh[4];
+  // single pass: sums of (x - p) and (x - p)^2 around a pivot p (the group's first element) — the shift
+  // keeps E[d^2] - E[d]^2 well conditioned in f32 when |mean| >> std.
+  __shared__ float sh[8];
   const int grp = blockIdx.x, s = blockIdx.y, T = seq_len[s];
-  const float *base = x + (size_t)seq_start[s] * C + grp * 32 + (threadIdx.x & 7) * 4;
-  float sum = 0.f;
+  const float *g0 = x + (size_t)seq_start[s] * C + grp * 32;
+  const float pivot = g0[0];
+  const float *base = g0 + (threadIdx.x & 7) * 4;
+  float sum = 0.f, sq = 0.f;
+#pragma unroll 4
   for (int t = threadIdx.x >> 3; t < T; t += 32) {
     float4 v = *(const float4 *)(base + (size_t)t * C);
+    v.x -= pivot; v.y -= pivot; v.z -= pivot; v.w -= pivot;
     sum += (v.x + v.y) + (v.z + v.w);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sum;
-  __syncthreads();
-  const float mean = (sh[0] + sh[1] + sh[2] + sh[3]) / ((float)T * 32.f);
-  __syncthreads();
-  float sq = 0.f;
-  for (int t = threadIdx.x >> 3; t < T; t += 32) {
-    float4 v = *(const float4 *)(base + (size_t)t * C);
-    v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
     sq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sq;
+  for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); sq += __shfl_xor(sq, o); }
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = sum; sh[4 + (threadIdx.x >> 6)] = sq; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float var = (sh[0] + sh[1] + sh[2] + sh[3]) / ((float)T * 32.f);
-    stats[s * 32 + grp] = make_float2(mean, 1.0f / sqrtf(var + eps));
+    const float n = (float)T * 32.f;
+    const float md = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / n;
+    const float var = fmaxf(((sh[4] + sh[5]) + (sh[6] + sh[7])) / n - md * md, 0.f);
+    stats[s * 32 + grp] = make_float2(pivot + md, 1.0f / sqrtf(var + eps));
   }
 }
 
@@ -74,11 +71,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const int *__restrict__ row_seq,
                                                        const float2 *__restrict__ stats, const float *__restrict__ g,
                                                        const float *__restrict__ b, const float *__restrict__ ss /*[2048] or null*/,
-                                                       int do_silu, int lut, __half *__restrict__ y) {
+                                                       int do_silu, int lut, __half *__restrict__ y,
+                                                       const int *__restrict__ seq_len, float raw_eps) {
   const int r = blockIdx.x, c = threadIdx.x * 4, s = row_seq[r];
   uint2 o = make_uint2(0u, 0u);
   if (s >= 0) {
-    const float2 st = stats[s * 32 + (c >> 5)];
+    float2 st = stats[s * 32 + (c >> 5)];
+    if (seq_len) { // raw (sum, sum of squares) accumulated by the producing GEMM's epilogue
+      const float n = (float)seq_len[s] * 32.f, mean = st.x / n;
+      st = make_float2(mean, 1.0f / sqrtf(fmaxf(st.y / n - mean * mean, 0.f) + raw_eps));
+    }
     float4 v = *(const float4 *)(x + (size_t)r * C + c);
     const float4 gg = *(const float4 *)(g + c), bb = *(const float4 *)(b + c);
     float e[4] = {v.x, v.y, v.z, v.w};
@@ -143,139 +145,184 @@ __global__ __launch_bounds__(256) void to_f16_kernel(const float *__restrict__ x
 }
 
 // Multi-head attention with T5 relative-position bias (AttentionBlock, main.cpp:3232-3275).
-// One block = 128 queries of one (sequence, head): 4 waves x 32 queries; keys stream through LDS in
-// tiles of 64. S = Q K^T and O += P V on fp16 MFMA, online softmax in f32. bias = tab[(q<k)*64 +
-// min(|k-q|,63)] (the 32-bucket table pre-multiplied by 8 and expanded per distance at load time).
+// One block = 128 queries of one (sequence, head): 4 waves x 32 queries; keys stream through a double
+// buffered LDS stage (global->LDS DMA) in tiles of 64. Everything is computed TRANSPOSED so that a lane owns
+// ONE query and a quarter of the keys: S^T = K Q^T (D[key][query]) and O^T += V^T P^T (D[d][query]).
+//  * the softmax row reduction is 15 in-lane ops + two cross-lane steps (xor 16, 32) per query,
+//  * P^T is already in the MFMA B-operand layout of the second product (with the key order inside each
+//    32-key step permuted identically for V^T), so P never goes through LDS,
+//  * the output is 4 consecutive channels per lane (8-byte stores).
+// bias = tab[(q<k)*64 + min(|k-q|,63)] (32-bucket table x8, expanded per distance at load time); blocks
+// of keys at least 63 away from every query of the wave use the saturated constant.
 __device__ __forceinline__ int attn_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
+
+// all-reduce over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the gfx950 half/row swap
+// instructions (v_permlane32_swap / v_permlane16_swap) instead of ds_bpermute round trips through LDS.
+__device__ __forceinline__ float rows4_max(float x) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows4_sum(float x) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 
 __global__ __launch_bounds__(256) void diff_attn_kernel(const __half *__restrict__ qk, const __half *__restrict__ vt, int ldvt,
                                                         const int *__restrict__ seq_start, const int *__restrict__ seq_len,
-                                                        const float *__restrict__ bias_tab, __half *__restrict__ out) {
-  __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
-  __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
-  __shared__ __attribute__((aligned(16))) char Ps[4 * 32 * 128];
+                                                        const float *__restrict__ bias_tab, __half *__restrict__ out, int nq) {
+  __shared__ __attribute__((aligned(16))) char smem[3 * 16384]; // 3-deep ring of (K tile 8 KB | V^T tile 8 KB)
   __shared__ float tab[128];
-  const int s = blockIdx.z, h = blockIdx.y, T = seq_len[s], r0 = seq_start[s], q0 = blockIdx.x * 128;
+  // XCD-aware block order: workgroup id b runs on XCD b % 8, so all q-blocks of one (sequence, head) pair
+  // get ids congruent mod 8 and reuse that pair's K/V tiles from one L2 (16 heads => pairs % 8 == 0).
+  const int xcd = blockIdx.x & 7, tt = blockIdx.x >> 3;
+  const int pair = (tt / nq) * 8 + xcd, h = pair & 15, s = pair >> 4;
+  const int T = seq_len[s], r0 = seq_start[s], q0 = (tt % nq) * 128;
   if (q0 >= T) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
-  if (tid < 128) tab[tid] = bias_tab[h * 128 + tid];
+  const float L2E = 1.44269504088896f;
+  if (tid < 128) tab[tid] = bias_tab[h * 128 + tid] * L2E; // bias in log2 units (softmax via exp2)
   const int qw = q0 + wave * 32;
-  half8 qf[2][2];
+  half8 qf[2][2]; // Q[query = qw + i*16 + fr][d = ks*32 + fq*8 ..+7]
 #pragma unroll
   for (int i = 0; i < 2; i++)
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
       qf[i][ks] = *(const half8 *)(qk + (size_t)(r0 + qw + i * 16 + fr) * 2048 + h * 128 + ks * 32 + fq * 8);
-  floatx4 o[2][4];
-  float mrow[2][4], lrow[2][4];
+  floatx4 o[2][4]; // O^T[d = dt*16 + fq*4 + r][query = qw + i*16 + fr]
+  float mrow[2], lrow[2];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < 2; i++) {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      o[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
-      mrow[i][j] = -INFINITY;
-      lrow[i][j] = 0.f;
-    }
-  char *pw = Ps + wave * 4096;
+    for (int j = 0; j < 4; j++) o[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    mrow[i] = -INFINITY;
+    lrow[i] = 0.f;
+  }
   const int nkb = (T + 63) >> 6;
-  for (int kb = 0; kb < nkb; kb++) {
-    __syncthreads();
-    // stage K [64 keys][64 d] and V^T [64 d][64 keys]; 512 16-byte chunks each, 2 per thread
+  const int prow = lane >> 3, pslot = lane & 7;
+  const __half *kbase = qk + (size_t)r0 * 2048 + h * 128 + 64;
+  const __half *vbase = vt + (size_t)(h * 64) * ldvt + r0;
+  auto stage = [&](int kb, int buf) { // wave w moves rows w*16 .. w*16+15 of both tiles; swizzle on the source chunk
+    char *ks_ = smem + buf * 16384, *vs_ = ks_ + 8192;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      const int ch = tid + i * 256, row = ch >> 3, c8 = ch & 7;
-      uint4 kv = *(const uint4 *)(qk + (size_t)(r0 + kb * 64 + row) * 2048 + h * 128 + 64 + c8 * 8);
-      *(uint4 *)(Ks + attn_off(row, c8)) = kv;
-      uint4 vv = *(const uint4 *)(vt + (size_t)(h * 64 + row) * ldvt + r0 + kb * 64 + c8 * 8);
-      *(uint4 *)(Vs + attn_off(row, c8)) = vv;
+      const int row = wave * 16 + i * 8 + prow, c = pslot ^ (row & 7);
+      __builtin_amdgcn_global_load_lds((gptr_t)(kbase + (size_t)(kb * 64 + row) * 2048 + c * 8), (lptr_t)(ks_ + (wave * 2 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(vbase + (size_t)row * ldvt + kb * 64 + c * 8), (lptr_t)(vs_ + (wave * 2 + i) * 1024), 16, 0, 0);
     }
-    __syncthreads();
-    // S = Q K^T for 2 m-tiles x 4 key tiles
+  };
+  stage(0, 0);
+  if (nkb > 1) stage(1, 1);
+  const float SC = 0.125f * L2E; // 1/sqrt(64) in log2 units
+  for (int kb = 0; kb < nkb; kb++) {
+    // Tile kb must have landed; the 4 DMA pieces of tile kb+1 may stay in flight across the barrier
+    // (counted vmcnt + raw s_barrier: __syncthreads() would drain the prefetch).
+    if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // every wave has passed the barrier => nobody still reads tile kb-1, whose slot receives tile kb+2
+    if (kb + 2 < nkb) stage(kb + 2, (kb + 2) % 3);
+    const char *Ks = smem + (kb % 3) * 16384, *Vs = Ks + 8192;
+    // S^T: sc[i][jt][r] = S[query i*16+fr][key kb*64 + jt*16 + fq*4 + r]
     floatx4 sc[2][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      half8 kf0 = *(const half8 *)(Ks + attn_off(j * 16 + fr, fq));
-      half8 kf1 = *(const half8 *)(Ks + attn_off(j * 16 + fr, 4 + fq));
+    for (int jt = 0; jt < 4; jt++) {
+      const half8 kf0 = *(const half8 *)(Ks + attn_off(jt * 16 + fr, fq));
+      const half8 kf1 = *(const half8 *)(Ks + attn_off(jt * 16 + fr, 4 + fq));
 #pragma unroll
       for (int i = 0; i < 2; i++) {
         floatx4 a = (floatx4){0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[i][0], kf0, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[i][1], kf1, a, 0, 0, 0);
-        sc[i][j] = a;
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf0, qf[i][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf1, qf[i][1], a, 0, 0, 0);
+        sc[i][jt] = a;
       }
     }
-    // scale, relative-position bias, key mask, online softmax
+    const int kmin = kb * 64;
+    const bool far_hi = kmin - (qw + 31) >= 63, far_lo = qw - (kmin + 63) >= 63, tail = kmin + 64 > T;
+    half8 pf[2][2]; // P^T in B-operand layout: slot e<4 -> key (2*ks2)*16+fq*4+e ; e>=4 -> key (2*ks2+1)*16+fq*4+e-4
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 2; i++) {
+      const int qi = qw + i * 16 + fr;
+      float mx = -INFINITY, boff = 0.f; // v = sc*SC + bias; far tiles: bias is one constant (folded below)
+      if ((far_hi || far_lo) && !tail) {
+        boff = far_hi ? tab[64 + 63] : tab[63];
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int qi = qw + i * 16 + fq * 4 + r;
-        float mx = -INFINITY;
+        for (int jt = 0; jt < 4; jt++) mx = fmaxf(mx, fmaxf(fmaxf(sc[i][jt][0], sc[i][jt][1]), fmaxf(sc[i][jt][2], sc[i][jt][3])));
+        mx = fmaf(mx, SC, boff);
+      } else {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int ki = kb * 64 + j * 16 + fr;
-          const int d = ki - qi, ad = d < 0 ? -d : d;
-          float v = sc[i][j][r] * 0.125f + tab[(d > 0 ? 64 : 0) + (ad < 63 ? ad : 63)];
-          v = (ki < T) ? v : -INFINITY;
-          sc[i][j][r] = v;
-          mx = fmaxf(mx, v);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 1));
-        mx = fmaxf(mx, __shfl_xor(mx, 2));
-        mx = fmaxf(mx, __shfl_xor(mx, 4));
-        mx = fmaxf(mx, __shfl_xor(mx, 8));
-        const float mnew = fmaxf(mrow[i][r], mx);
-        const float alpha = __expf(mrow[i][r] - mnew);
-        float sum = 0.f;
+        for (int jt = 0; jt < 4; jt++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const float p = __expf(sc[i][j][r] - mnew);
-          sc[i][j][r] = p;
-          sum += p;
-        }
-        sum += __shfl_xor(sum, 1);
-        sum += __shfl_xor(sum, 2);
-        sum += __shfl_xor(sum, 4);
-        sum += __shfl_xor(sum, 8);
-        lrow[i][r] = lrow[i][r] * alpha + sum;
-        mrow[i][r] = mnew;
-#pragma unroll
-        for (int j = 0; j < 4; j++) o[i][j][r] *= alpha;
-        // P (fp16) -> this wave's LDS tile [32 q][64 keys]
-        const int prow = i * 16 + fq * 4 + r;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int key = j * 16 + fr;
-          *(__half *)(pw + attn_off(prow, key >> 3) + (key & 7) * 2) = __float2half_rn(sc[i][j][r]);
-        }
+          for (int r = 0; r < 4; r++) {
+            const int ki = kmin + jt * 16 + fq * 4 + r;
+            const int d = ki - qi, ad = d < 0 ? -d : d;
+            float v = sc[i][jt][r] + tab[(d > 0 ? 64 : 0) + (ad < 63 ? ad : 63)] * (1.0f / SC); // keep sc in raw units
+            v = (ki < T) ? v : -INFINITY;
+            sc[i][jt][r] = v;
+            mx = fmaxf(mx, v);
+          }
+        mx *= SC;
       }
-    __syncthreads();
-    // O += P V : A = P [16 q][32 keys], B = V^T [16 d][32 keys]
+      mx = rows4_max(mx);
+      const float mnew = fmaxf(mrow[i], mx);
+      const float alpha = __builtin_amdgcn_exp2f(mrow[i] - mnew);
+      const float sub = boff - mnew; // p = 2^(sc*SC + bias - mnew)
+      float sum = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      half8 pf[2], vf[4];
+      for (int jt = 0; jt < 4; jt++)
 #pragma unroll
-      for (int i = 0; i < 2; i++) pf[i] = *(const half8 *)(pw + attn_off(i * 16 + fr, ks * 4 + fq));
+        for (int r = 0; r < 4; r++) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sc[i][jt][r], SC, sub));
+          sc[i][jt][r] = pv;
+          sum += pv;
+        }
+      sum = rows4_sum(sum);
+      lrow[i] = lrow[i] * alpha + sum;
+      mrow[i] = mnew;
+      if (!__all(alpha == 1.0f)) { // the running max settles after the first tiles: usually nothing to rescale
 #pragma unroll
-      for (int j = 0; j < 4; j++) vf[j] = *(const half8 *)(Vs + attn_off(j * 16 + fr, ks * 4 + fq));
+        for (int dt = 0; dt < 4; dt++)
 #pragma unroll
-      for (int i = 0; i < 2; i++)
+          for (int r = 0; r < 4; r++) o[i][dt][r] *= alpha;
+      }
 #pragma unroll
-        for (int j = 0; j < 4; j++) o[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf[i], vf[j], o[i][j], 0, 0, 0);
+      for (int ks2 = 0; ks2 < 2; ks2++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) pf[i][ks2][e] = (_Float16)sc[i][2 * ks2 + (e >> 2)][e & 3];
+    }
+    // O^T += V^T P^T : A = V^T[d = dt*16 + fr][key slots of this lane group], B = P^T
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ks2++) {
+#pragma unroll
+      for (int dt = 0; dt < 4; dt++) {
+        const int row = dt * 16 + fr;
+        const uint2 lo = *(const uint2 *)(Vs + attn_off(row, 4 * ks2 + (fq >> 1)) + (fq & 1) * 8);
+        const uint2 hi = *(const uint2 *)(Vs + attn_off(row, 4 * ks2 + 2 + (fq >> 1)) + (fq & 1) * 8);
+        uint4 both = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        const half8 vf = *(const half8 *)&both;
+#pragma unroll
+        for (int i = 0; i < 2; i++) o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[i][ks2], o[i][dt], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < 2; i++) {
+    const int qi = qw + i * 16 + fr;
+    if (qi < T) {
+      const float inv = 1.0f / lrow[i];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int qi = qw + i * 16 + fq * 4 + r;
-      if (qi < T) {
-        const float inv = 1.0f / lrow[i][r];
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-          out[(size_t)(r0 + qi) * C + h * 64 + j * 16 + fr] = __float2half_rn(o[i][j][r] * inv);
+      for (int dt = 0; dt < 4; dt++) {
+        __half2 p0 = __floats2half2_rn(o[i][dt][0] * inv, o[i][dt][1] * inv), p1 = __floats2half2_rn(o[i][dt][2] * inv, o[i][dt][3] * inv);
+        uint2 u;
+        u.x = *(unsigned *)&p0;
+        u.y = *(unsigned *)&p1;
+        *(uint2 *)(out + (size_t)(r0 + qi) * C + h * 64 + dt * 16 + fq * 4) = u;
       }
     }
+  }
 }
 
 // nearest-neighbour upsample of the code embedding L -> T (ggml_upscale_ext: src = (int)(dst / ((float)T/L)))
@@ -420,7 +467,9 @@ struct Layout {
 // k=3 taps read rows -1 and `rows`) plus 128 rows of slack for the attention tiles.
 struct Work {
   int rows = 0;
-  DevBuf x, hbuf, a16, att16, qk16, vt16, stats;
+  DevBuf x, hbuf, a16, att16, qk16, vt16, stats, raw;
+  const float *raw_owner = nullptr; // tensor whose raw GroupNorm sums (from a GEMM epilogue) are in `raw`
+  bool use_raw = false;
   float *X() { return x.as<float>(); }
   float *H() { return hbuf.as<float>(); }
   __half *A16() { return a16.as<__half>() + C; }
@@ -440,6 +489,8 @@ struct Work {
     TTS_HIP(ctx, rz(qk16, (size_t)(r + 128) * 2048 * 2));
     TTS_HIP(ctx, rz(vt16, (size_t)C * (r + 128) * 2));
     TTS_HIP(ctx, rz(stats, (size_t)ns * 32 * sizeof(float2)));
+    TTS_HIP(ctx, rz(raw, (size_t)ns * 32 * sizeof(float2)));
+    raw_owner = nullptr;
     return TTS_OK;
   }
 };
@@ -601,9 +652,13 @@ int diff_load(tts_ctx *ctx, const char *path) {
 #define CHECK(x) do { int _r = (x); if (_r) return _r; } while (0)
 
 // algorithmic FLOPs of one launch: valid rows (no guard/pad rows) x valid columns x valid K
-static int gemm(tts_ctx *ctx, const char *fam, GemmArgs &g, const Layout &lay, int n_valid = 0, int k_valid = 0) {
+static int gemm(tts_ctx *ctx, const char *fam, GemmArgs &g, const Layout &lay, int n_valid = 0, int k_valid = 0,
+                Work *stats_wk = nullptr) {
   double mv = 0;
   for (int l : lay.len) mv += l;
+  // (GroupNorm statistics fused into this epilogue were tried and measured slower: +2.7 ms/step of GEMM
+  //  time for 1.0 ms/step of gn_stats saved — register pressure costs a resident workgroup per CU.)
+  (void)stats_wk;
   ProfScope ps(ctx, fam, 2.0 * mv * (n_valid ? n_valid : g.N) * (k_valid ? k_valid : g.nseg * g.kseg));
   TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream));
   return TTS_OK;
@@ -620,6 +675,8 @@ static GemmArgs gemm_base(const Layout &lay, const __half *A, int lda, int nseg,
 }
 
 static int gn_stats(tts_ctx *ctx, const Layout &lay, Work &wk, const float *x) {
+  wk.use_raw = (wk.raw_owner == x);
+  if (wk.use_raw) return TTS_OK; // sums were produced by the GEMM that wrote x
   ProfScope ps(ctx, "diff_gn_stats");
   gn_stats_kernel<<<dim3(32, lay.ns), 256, 0, ctx->stream>>>(x, lay.d_start.as<int>(), lay.d_len.as<int>(), ctx->gn_eps,
                                                              wk.stats.as<float2>());
@@ -629,8 +686,8 @@ static int gn_stats(tts_ctx *ctx, const Layout &lay, Work &wk, const float *x) {
 static int gn_apply(tts_ctx *ctx, const Layout &lay, Work &wk, const float *x, const float *g, const float *b, const float *ss,
                     int do_silu, __half *y) {
   ProfScope ps(ctx, "diff_gn_apply");
-  gn_apply_kernel<<<lay.rows, 256, 0, ctx->stream>>>(x, lay.d_row_seq.as<int>(), wk.stats.as<float2>(), g, b, ss, do_silu,
-                                                     ctx->ggml_lut, y);
+  gn_apply_kernel<<<lay.rows, 256, 0, ctx->stream>>>(x, lay.d_row_seq.as<int>(), wk.use_raw ? wk.raw.as<float2>() : wk.stats.as<float2>(), g, b,
+                                                     ss, do_silu, ctx->ggml_lut, y, wk.use_raw ? lay.d_len.as<int>() : nullptr, ctx->gn_eps);
   TTS_HIP(ctx, hipGetLastError());
   return TTS_OK;
 }
@@ -646,14 +703,14 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
     double aw = 0;
     for (int l : lay.len) aw += 4.0 * l * (double)l * 64 * NHEAD; // QK^T + PV
     ProfScope ps(ctx, "diff_attn", aw);
-    dim3 grid((lay.max_len() + 127) / 128, NHEAD, lay.ns);
-    diff_attn_kernel<<<grid, 256, 0, ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128, lay.d_start.as<int>(),
-                                                    lay.d_len.as<int>(), w.bias_tab, wk.ATT16());
+    const int nq = (lay.max_len() + 127) / 128;
+    diff_attn_kernel<<<nq * NHEAD * lay.ns, 256, 0, ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128,
+                                                                   lay.d_start.as<int>(), lay.d_len.as<int>(), w.bias_tab, wk.ATT16(), nq);
     TTS_HIP(ctx, hipGetLastError());
   }
   GemmArgs p = gemm_base(lay, wk.ATT16(), C, 1, C, w.proj_w, C, w.proj_b);
   p.mode = GEMM_OUT_F32; p.outF = X; p.ldo = C; p.resid = X;
-  return gemm(ctx, "diff_gemm", p, lay);
+  return gemm(ctx, "diff_gemm", p, lay, 0, 0, &wk);
 }
 
 // ResBlock on X (in place); ss = this step's [scale | shift] for this block (device, 2048 floats).
@@ -662,12 +719,12 @@ static int res_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, f
   CHECK(gn_apply(ctx, lay, wk, X, w.in_g, w.in_b, nullptr, 1, wk.A16()));
   GemmArgs g = gemm_base(lay, wk.A16(), C, 1, C, w.in_w, C, w.in_bias);
   g.mode = GEMM_OUT_F32; g.outF = wk.H(); g.ldo = C; g.resid = nullptr;
-  CHECK(gemm(ctx, "diff_gemm", g, lay));
+  CHECK(gemm(ctx, "diff_gemm", g, lay, 0, 0, &wk));
   CHECK(gn_stats(ctx, lay, wk, wk.H()));
   CHECK(gn_apply(ctx, lay, wk, wk.H(), w.out_g, w.out_b, ss, 1, wk.A16()));
   GemmArgs c3 = gemm_base(lay, wk.A16(), C, 3, C, w.out_w, C, w.out_bias);
   c3.mode = GEMM_OUT_F32; c3.outF = X; c3.ldo = C; c3.resid = X;
-  return gemm(ctx, "diff_gemm", c3, lay);
+  return gemm(ctx, "diff_gemm", c3, lay, 0, 0, &wk);
 }
 
 // Timestep MLP + every emb_layers linear for `n` timesteps at once:
@@ -711,8 +768,9 @@ static int latent_conditioner(tts_ctx *ctx, DiffState *st, const float *latents_
   to_f16_kernel<<<ll.rows, 256, 0, ctx->stream>>>(wk.X(), ll.d_row_seq.as<int>(), wk.A16());
   GemmArgs c3 = gemm_base(ll, wk.A16(), C, 3, C, st->lc_w, C, st->lc_bias);
   c3.mode = GEMM_OUT_F32; c3.outF = wk.X(); c3.ldo = C; c3.resid = nullptr;
-  CHECK(gemm(ctx, "diff_gemm", c3, ll));
+  CHECK(gemm(ctx, "diff_gemm", c3, ll, 0, 0, &wk));
   for (int i = 0; i < st->n_lc; i++) CHECK(attention_block(ctx, st, ll, wk, wk.X(), st->lc_attn[i]));
+  wk.raw_owner = nullptr; // code_norm uses the (mean, rstd) form of the standalone kernel
   CHECK(gn_stats(ctx, ll, wk, wk.X()));
   gn_apply_f32_kernel<<<ll.rows, 256, 0, ctx->stream>>>(wk.X(), ll.d_row_seq.as<int>(), wk.stats.as<float2>(), st->code_g, st->code_b,
                                                         st->cond_latent, wk.H());
@@ -726,6 +784,7 @@ static int network_forward(tts_ctx *ctx, DiffState *st, const float *ss) {
   Layout &lay = st->lay;
   Work &wk = st->wk;
   float *ce = st->ce.as<float>();
+  wk.raw_owner = nullptr;
   TTS_HIP(ctx, hipMemcpyAsync(ce, st->code_emb.p, (size_t)lay.rows * C * 4, hipMemcpyDeviceToDevice, ctx->stream));
   int j = 0;
   for (int i = 0; i < st->n_integ; i++, j++) {
@@ -742,7 +801,7 @@ static int network_forward(tts_ctx *ctx, DiffState *st, const float *ss) {
   GemmArgs gc = gemm_base(lay, inp16, C, 2, C, st->integ_w, C, st->integ_bias);
   gc.A[1] = ce16;
   gc.mode = GEMM_OUT_F32; gc.outF = wk.X(); gc.ldo = C; gc.resid = nullptr;
-  CHECK(gemm(ctx, "diff_gemm", gc, lay));
+  CHECK(gemm(ctx, "diff_gemm", gc, lay, 0, 0, &wk));
   for (int i = 0; i < st->n_main; i++, j++) {
     CHECK(res_block(ctx, st, lay, wk, wk.X(), st->main_res[i], ss + (size_t)j * 2 * C));
     CHECK(attention_block(ctx, st, lay, wk, wk.X(), st->main_attn[i]));

@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace tts {
 
@@ -166,29 +167,48 @@ typedef void __attribute__((address_space(3))) *lptr_t;
 template <int MODE>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, floatx4 (&acc)[4][4], int m0, int n0, int wm, int wn, int fr, int fq) {
   if (MODE == GEMM_OUT_QKV) {
+    // col = h*192 + {q 0..63 | k 64..127 | v 128..191}; a wave's 64-column span is entirely q, k or v.
+    const int c0 = n0 + wn * 64, h = c0 / 192, w0 = c0 - h * 192;
+    if (w0 >= 128) { // V, natural operand order: lane = 4 consecutive rows of one column -> 8-byte transposed store
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int rbase = m0 + wm * 64 + i * 16 + fq * 4;
-      bool guard[4];
+      for (int i = 0; i < 4; i++) {
+        const int rbase = m0 + wm * 64 + i * 16 + fq * 4;
+        bool guard[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) guard[r] = g.row_seq ? (g.row_seq[rbase + r] < 0) : false;
+        for (int r = 0; r < 4; r++) guard[r] = g.row_seq ? (g.row_seq[rbase + r] < 0) : false;
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int col = n0 + wn * 64 + j * 16 + fr;
-        const float bv = g.bias ? g.bias[col] : 0.f;
-        float v[4];
+        for (int j = 0; j < 4; j++) {
+          const int d = j * 16 + fr;
+          const float bv = g.bias ? g.bias[c0 + d] : 0.f;
+          float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) v[r] = guard[r] ? 0.f : acc[i][j][r] + bv;
-        const int h = col / 192, w = col - h * 192;
-        if (w < 128) {
-#pragma unroll
-          for (int r = 0; r < 4; r++) g.outH[(size_t)(rbase + r) * g.ldh + h * 128 + w] = __float2half_rn(v[r]);
-        } else {
+          for (int r = 0; r < 4; r++) v[r] = guard[r] ? 0.f : acc[i][j][r] + bv;
           __half2 p0 = __floats2half2_rn(v[0], v[1]), p1 = __floats2half2_rn(v[2], v[3]);
           uint2 u;
           u.x = *(unsigned *)&p0;
           u.y = *(unsigned *)&p1;
-          *(uint2 *)(g.outVt + (size_t)(h * 64 + (w - 128)) * g.ldvt + rbase) = u;
+          *(uint2 *)(g.outVt + (size_t)(h * 64 + d) * g.ldvt + rbase) = u;
+        }
+      }
+    } else { // Q or K, swapped operand order: lane = 4 consecutive columns of one row -> 8-byte store
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int row = m0 + wm * 64 + i * 16 + fr;
+        const bool guard = g.row_seq ? (g.row_seq[row] < 0) : false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int d = j * 16 + fq * 4;
+          float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          if (g.bias) {
+            const float4 b = *(const float4 *)(g.bias + c0 + d);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+          }
+          if (guard) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          __half2 p0 = __floats2half2_rn(v.x, v.y), p1 = __floats2half2_rn(v.z, v.w);
+          uint2 u;
+          u.x = *(unsigned *)&p0;
+          u.y = *(unsigned *)&p1;
+          *(uint2 *)(g.outH + (size_t)row * g.ldh + h * 128 + w0 + d) = u;
         }
       }
     }
@@ -249,10 +269,77 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g
     for (int j = 0; j < 4; j++) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fq = lane >> 4;
   char *sa = smem, *sb = smem + 16384;
-  for (int kt = 0; kt < nk; kt++) {
+  // operand order (see gemm_epilogue): natural only for the V columns of a QKV projection (wave-uniform)
+  const bool natural = (MODE == GEMM_OUT_QKV) && (((n0 + wn * 64) % 192) >= 128);
+  // the K loop is instantiated once per operand order so the choice costs nothing inside it
+  auto kloop = [&](auto nat) {
+    constexpr bool NAT = decltype(nat)::value;
+    for (int kt = 0; kt < nk; kt++) {
+      const int seg = kt / tiles_per_seg, kk = (kt - seg * tiles_per_seg) << 6;
+      const __half *abase = g.A[seg] + (size_t)(m0 + g.row_off[seg]) * g.lda + kk;
+      const __half *wbase = g.W + (size_t)n0 * ldw + seg * g.kseg + kk;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int row = (wave * 4 + i) * 8 + prow;
+        const int c = pslot ^ ((row >> 1) & 7);
+        __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)row * g.lda + c * 8), (lptr_t)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (size_t)row * ldw + c * 8), (lptr_t)(sb + (wave * 4 + i) * 1024), 16, 0, 0);
+      }
+      __syncthreads(); // waits vmcnt(0) for the DMA, then barrier
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        half8 af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          af[i] = *(const half8 *)(sa + lds_off(wm * 64 + i * 16 + fr, ks * 4 + fq));
+          bf[i] = *(const half8 *)(sb + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (NAT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+    }
+  };
+  if (MODE == GEMM_OUT_QKV && natural) kloop(std::true_type{});
+  else kloop(std::false_type{});
+  gemm_epilogue<MODE>(g, acc, m0, n0, wm, wn, fr, fq);
+}
+
+// Variant 2/3: NST-deep LDS ring (NST x 32 KB, dynamic LDS). Tile kt+NST-1 is requested while tile kt is
+// multiplied; DMA pieces stay in flight across the (raw) barrier and are retired with a counted vmcnt.
+template <int MODE, int NST>
+static __global__ __launch_bounds__(256) void gemm_f16_ring_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  char *smem = smem_dyn;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = g.N >> 7, ntiles = (g.M >> 7) * ntn;
+  int bid = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (bid / ntn) << 7, n0 = (bid % ntn) << 7;
+  const int tiles_per_seg = g.kseg >> 6, nk = g.nseg * tiles_per_seg;
+  const int ldw = g.nseg * g.kseg;
+  const int prow = lane >> 3, pslot = lane & 7;
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  const bool natural = (MODE == GEMM_OUT_QKV) && (((n0 + wn * 64) % 192) >= 128);
+  auto stage = [&](int kt, int buf) {
     const int seg = kt / tiles_per_seg, kk = (kt - seg * tiles_per_seg) << 6;
     const __half *abase = g.A[seg] + (size_t)(m0 + g.row_off[seg]) * g.lda + kk;
     const __half *wbase = g.W + (size_t)n0 * ldw + seg * g.kseg + kk;
+    char *sa = smem + buf * 32768, *sb = sa + 16384;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int row = (wave * 4 + i) * 8 + prow;
@@ -260,26 +347,152 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g
       __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)row * g.lda + c * 8), (lptr_t)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (size_t)row * ldw + c * 8), (lptr_t)(sb + (wave * 4 + i) * 1024), 16, 0, 0);
     }
-    __syncthreads(); // waits vmcnt(0) for the DMA, then barrier
+  };
+  auto kloop = [&](auto nat) {
+    constexpr bool NAT = decltype(nat)::value;
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
-      half8 af[4], bf[4];
+    for (int p = 0; p < NST - 1; p++)
+      if (p < nk) stage(p, p);
+    for (int kt = 0; kt < nk; kt++) {
+      // tiles kt+1 .. kt+NST-2 may remain in flight (8 DMA pieces each)
+      const int ahead = min(NST - 2, nk - 1 - kt);
+      if (NST == 3 && ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + NST - 1 < nk) stage(kt + NST - 1, (kt + NST - 1) % NST);
+      const char *sa = smem + (kt % NST) * 32768, *sb = sa + 16384;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        af[i] = *(const half8 *)(sa + lds_off(wm * 64 + i * 16 + fr, ks * 4 + fq));
-        bf[i] = *(const half8 *)(sb + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
-      }
+      for (int ks = 0; ks < 2; ks++) {
+        half8 af[4], bf[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          if (MODE == GEMM_OUT_QKV) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-          else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; i++) {
+          af[i] = *(const half8 *)(sa + lds_off(wm * 64 + i * 16 + fr, ks * 4 + fq));
+          bf[i] = *(const half8 *)(sb + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
         }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (NAT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+          }
+      }
     }
-    __syncthreads();
-  }
+  };
+  if (MODE == GEMM_OUT_QKV && natural) kloop(std::true_type{});
+  else kloop(std::false_type{});
   gemm_epilogue<MODE>(g, acc, m0, n0, wm, wn, fr, fq);
+}
+
+template <int NST>
+static inline hipError_t launch_gemm_ring(const GemmArgs &g, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)gemm_f16_ring_kernel<GEMM_OUT_F32, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * 32768);
+    (void)hipFuncSetAttribute((const void *)gemm_f16_ring_kernel<GEMM_OUT_F16, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * 32768);
+    (void)hipFuncSetAttribute((const void *)gemm_f16_ring_kernel<GEMM_OUT_QKV, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, NST * 32768);
+    attr_set = true;
+  }
+  const int ntiles = (g.M >> 7) * (g.N >> 7);
+  if (g.mode == GEMM_OUT_F32) gemm_f16_ring_kernel<GEMM_OUT_F32, NST><<<ntiles, 256, NST * 32768, s>>>(g);
+  else if (g.mode == GEMM_OUT_F16) gemm_f16_ring_kernel<GEMM_OUT_F16, NST><<<ntiles, 256, NST * 32768, s>>>(g);
+  else gemm_f16_ring_kernel<GEMM_OUT_QKV, NST><<<ntiles, 256, NST * 32768, s>>>(g);
+  return hipGetLastError();
+}
+
+// Variant 4: 256(M) x 128(N) x 64 tile, 8 waves (4 x 2, each 64x64), 3-deep LDS ring (3 x 48 KB = 144 KB,
+// one workgroup per CU, two waves per SIMD). Tile kt+2 is requested while tile kt is multiplied; the DMA
+// pieces stay in flight across the single raw barrier per K tile (counted vmcnt).
+template <int MODE>
+static __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  char *smem = smem_dyn;
+  constexpr int STAGE = 49152, NST = 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = g.N >> 7, ntiles = ((g.M + 255) >> 8) * ntn;
+  int bid = blockIdx.x;
+  {
+    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (bid / ntn) << 8, n0 = (bid % ntn) << 7;
+  const int tiles_per_seg = g.kseg >> 6, nk = g.nseg * tiles_per_seg;
+  const int ldw = g.nseg * g.kseg;
+  const int prow = lane >> 3, pslot = lane & 7;
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  const bool natural = (MODE == GEMM_OUT_QKV) && (((n0 + wn * 64) % 192) >= 128);
+  const int mlast = g.M - 1; // rows beyond M (M % 256 == 128) are clamped: their results are never stored
+  auto stage = [&](int kt, int buf) {
+    const int seg = kt / tiles_per_seg, kk = (kt - seg * tiles_per_seg) << 6;
+    const __half *abase = g.A[seg] + (size_t)g.row_off[seg] * g.lda + kk;
+    const __half *wbase = g.W + (size_t)n0 * ldw + seg * g.kseg + kk;
+    char *sa = smem + buf * STAGE, *sb = sa + 32768;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { // A: 32 pieces of 8 rows
+      const int row = (wave * 4 + i) * 8 + prow;
+      const int c = pslot ^ ((row >> 1) & 7);
+      const int grow = min(m0 + row, mlast);
+      __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)grow * g.lda + c * 8), (lptr_t)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) { // B: 16 pieces
+      const int row = (wave * 2 + i) * 8 + prow;
+      const int c = pslot ^ ((row >> 1) & 7);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (size_t)row * ldw + c * 8), (lptr_t)(sb + (wave * 2 + i) * 1024), 16, 0, 0);
+    }
+  };
+  auto kloop = [&](auto nat) {
+    constexpr bool NAT = decltype(nat)::value;
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    for (int kt = 0; kt < nk; kt++) {
+      if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); // tile kt landed; tile kt+1 (6 pieces) may fly
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (kt + 2 < nk) stage(kt + 2, (kt + 2) % NST);
+      const char *sa = smem + (kt % NST) * STAGE, *sb = sa + 32768;
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        half8 af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          af[i] = *(const half8 *)(sa + lds_off(wm * 64 + i * 16 + fr, ks * 4 + fq));
+          bf[i] = *(const half8 *)(sb + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (NAT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+  };
+  if (MODE == GEMM_OUT_QKV && natural) kloop(std::true_type{});
+  else kloop(std::false_type{});
+  if (m0 + wm * 64 < g.M) gemm_epilogue<MODE>(g, acc, m0, n0, wm, wn, fr, fq);
+}
+
+static inline hipError_t launch_gemm_big(const GemmArgs &g, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)gemm_f16_big_kernel<GEMM_OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+    (void)hipFuncSetAttribute((const void *)gemm_f16_big_kernel<GEMM_OUT_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+    (void)hipFuncSetAttribute((const void *)gemm_f16_big_kernel<GEMM_OUT_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+    attr_set = true;
+  }
+  const int ntiles = ((g.M + 255) >> 8) * (g.N >> 7);
+  if (g.mode == GEMM_OUT_F32) gemm_f16_big_kernel<GEMM_OUT_F32><<<ntiles, 512, 147456, s>>>(g);
+  else if (g.mode == GEMM_OUT_F16) gemm_f16_big_kernel<GEMM_OUT_F16><<<ntiles, 512, 147456, s>>>(g);
+  else gemm_f16_big_kernel<GEMM_OUT_QKV><<<ntiles, 512, 147456, s>>>(g);
+  return hipGetLastError();
 }
 
 static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
@@ -293,6 +506,9 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
 #ifndef TTS_GEMM_VARIANT
 #define TTS_GEMM_VARIANT 1
 #endif
+  if (TTS_GEMM_VARIANT == 4) return launch_gemm_big(g, s);
+  if (TTS_GEMM_VARIANT == 2) return launch_gemm_ring<2>(g, s);
+  if (TTS_GEMM_VARIANT == 3) return launch_gemm_ring<3>(g, s);
   if (TTS_GEMM_VARIANT == 0) gemm_f16_kernel<<<ntiles, 256, 65536, s>>>(g);
   else if (g.mode == GEMM_OUT_F32) gemm_f16_glds_kernel<GEMM_OUT_F32><<<ntiles, 256, 0, s>>>(g);
   else if (g.mode == GEMM_OUT_F16) gemm_f16_glds_kernel<GEMM_OUT_F16><<<ntiles, 256, 0, s>>>(g);
