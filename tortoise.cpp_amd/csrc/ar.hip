@@ -12,6 +12,7 @@
 // are run-to-run reproducible). Layouts are fixed once at load time (the reference re-transposes
 // every weight matrix inside every graph execution, main.cpp:2769-2777).
 #include "common.h"
+#include "gemm_f16.h"
 #include <hip/hip_fp16.h>
 #include <algorithm>
 #include <cmath>
@@ -151,6 +152,46 @@ __global__ __launch_bounds__(256) void gemv_kn_kernel(const float *__restrict__ 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Split-precision MFMA path for the multi-row passes (prefill, latent pass): x*W in f32 is evaluated as
+// x_hi*W_hi + x_lo*W_hi + x_hi*W_lo with fp16 hi/lo parts (hi = fp16(v), lo = fp16(v - hi): 22 significant
+// bits) on the fp16 MFMA GEMM with f32 accumulation — ~16x the f32 FMA rate at ~2^-21 relative accuracy
+// (the oracle gate for these passes is 1e-4). Weights are pre-scaled by 64 so the lo parts stay normal.
+// ---------------------------------------------------------------------------------------------
+static constexpr float W16_SCALE = 64.0f;
+// W f32 [K][N] -> out fp16 [N][2K] = [hi(0..K-1) | lo(0..K-1)] of 64*W^T (tile transpose through LDS)
+__global__ __launch_bounds__(256) void split_weight_kernel(const float *__restrict__ W, int K, int N, __half *__restrict__ out) {
+  __shared__ float t[32][33];
+  const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) t[r][tx] = W[(size_t)(k0 + r) * N + n0 + tx] * W16_SCALE;
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const float v = t[tx][r];
+    const __half hi = __float2half_rn(v);
+    const __half lo = __float2half_rn(v - __half2float(hi));
+    out[(size_t)(n0 + r) * 2 * K + k0 + tx] = hi;
+    out[(size_t)(n0 + r) * 2 * K + K + k0 + tx] = lo;
+  }
+}
+// x f32 [rows][K] -> hi, lo fp16 [rows_pad][K] (pad rows zero)
+__global__ __launch_bounds__(256) void split_act_kernel(const float *__restrict__ x, int rows, int K, __half *__restrict__ hi,
+                                                        __half *__restrict__ lo) {
+  const int r = blockIdx.x;
+  for (int c = threadIdx.x * 4; c < K; c += 1024) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) v = *(const float4 *)(x + (size_t)r * K + c);
+    const __half2 h0 = __floats2half2_rn(v.x, v.y), h1 = __floats2half2_rn(v.z, v.w);
+    const float2 f0 = __half22float2(h0), f1 = __half22float2(h1);
+    const __half2 l0 = __floats2half2_rn(v.x - f0.x, v.y - f0.y), l1 = __floats2half2_rn(v.z - f1.x, v.w - f1.y);
+    uint2 uh, ul;
+    uh.x = *(const unsigned *)&h0; uh.y = *(const unsigned *)&h1;
+    ul.x = *(const unsigned *)&l0; ul.y = *(const unsigned *)&l1;
+    *(uint2 *)(hi + (size_t)r * K + c) = uh;
+    *(uint2 *)(lo + (size_t)r * K + c) = ul;
+  }
+}
+
 enum { EPI_BIAS = 0, EPI_QKV = 1, EPI_GELU = 2, EPI_RESID = 3 };
 struct KvDst {          // where EPI_QKV writes K/V as fp16
   __half *k, *v;        // base of this layer's cache: [cand][max_pos][1024]
@@ -162,12 +203,12 @@ struct KvDst {          // where EPI_QKV writes K/V as fp16
 template <int MODE>
 __global__ __launch_bounds__(256) void epilogue_kernel(const float *__restrict__ part, int ks, int rows, int N,
                                                        int n_valid, const float *__restrict__ bias,
-                                                       float *__restrict__ out, int ldo, KvDst kv, int lut) {
+                                                       float *__restrict__ out, int ldo, KvDst kv, int lut, float pscale) {
   const int r = blockIdx.x;
   for (int n = blockIdx.y * 256 + threadIdx.x; n < n_valid; n += 256 * gridDim.y) {
     float v = part[(size_t)r * N + n];
     for (int s = 1; s < ks; s++) v += part[((size_t)s * rows + r) * N + n];
-    v += bias[n];
+    v = v * pscale + bias[n]; // pscale = 1 (f32 path) or 1/64 (split-precision weights are pre-scaled; exact power of 2)
     if (MODE == EPI_QKV) {
       v = f16_round(v);
       out[(size_t)r * ldo + n] = v;
@@ -487,6 +528,7 @@ __global__ __launch_bounds__(256) void gemv_decode_kernel(const float *__restric
 struct ArLayerDev {
   float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
   float *w_attn, *b_attn, *w_proj, *b_proj, *w_fc, *b_fc, *w_fc2, *b_fc2;
+  __half *s_attn = nullptr, *s_proj = nullptr, *s_fc = nullptr, *s_fc2 = nullptr; // [N][2K] hi|lo of 64*W^T
 };
 
 struct ArState {
@@ -500,7 +542,7 @@ struct ArState {
   int B = 0, n_text = 0, P = 0, max_pos = 0;
   std::vector<int> tokens;
   DevBuf voice, kcache, vcache, lat_k, lat_v;
-  DevBuf h, xn, qkv, att, ff, part, desc, logits, hn;
+  DevBuf h, xn, qkv, att, ff, part, desc, logits, hn, a_hi, a_lo;
   // decode-step graph
   DevBuf partA, partB, d_toks;
   int32_t *h_toks = nullptr;   // pinned
@@ -579,6 +621,19 @@ int ar_load(tts_ctx *ctx, const char *path) {
     FETCH(p + ".mlp.c_proj.weight", D, FF, &l.w_fc2); FETCH(p + ".mlp.c_proj.bias", D, 1, &l.b_fc2);
   }
 #undef FETCH
+  for (int i = 0; i < st->n_layers; i++) { // split-precision copies for the multi-row MFMA path
+    ArLayerDev &l = st->L[i];
+    struct { const float *w; int K, N; __half **dst; } jobs[4] = {
+        {l.w_attn, D, 3 * D, &l.s_attn}, {l.w_proj, D, D, &l.s_proj}, {l.w_fc, D, FF, &l.s_fc}, {l.w_fc2, FF, D, &l.s_fc2}};
+    for (auto &j : jobs) {
+      void *p = nullptr;
+      TTS_HIP(ctx, hipMalloc(&p, (size_t)j.N * 2 * j.K * sizeof(__half)));
+      st->owned.push_back(p);
+      split_weight_kernel<<<dim3(j.N / 32, j.K / 32), 256, 0, ctx->stream>>>(j.w, j.K, j.N, (__half *)p);
+      *j.dst = (__half *)p;
+    }
+  }
+  TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   { // lm_head.1: nn.Linear [8194][1024] -> [1024][VPAD] so that it streams like the Conv1D weights
     auto it = wf.t.find("inference_model.lm_head.1.weight");
     auto ib = wf.t.find("inference_model.lm_head.1.bias");
@@ -648,11 +703,31 @@ static int launch_gemv(tts_ctx *ctx, ArState *st, const float *X, int ldx, int r
 
 template <int MODE>
 static int launch_epilogue(tts_ctx *ctx, ArState *st, int ks, int rows, int N, int n_valid, const float *bias, float *out,
-                           int ldo, KvDst kv) {
+                           int ldo, KvDst kv, float pscale = 1.0f) {
   ProfScope ps(ctx, "ar_epilogue");
   epilogue_kernel<MODE><<<dim3(rows, (n_valid + 255) / 256), 256, 0, ctx->stream>>>(st->part.as<float>(), ks, rows, N, n_valid, bias,
-                                                                                    out, ldo, kv, ctx->ggml_lut);
+                                                                                    out, ldo, kv, ctx->ggml_lut, pscale);
   TTS_HIP(ctx, hipGetLastError());
+  return TTS_OK;
+}
+
+
+// part[rows][N] (scaled by 64) <- split-precision MFMA product of X[rows][K] with the layer's hi|lo weights.
+static int launch_mfma_matmul(tts_ctx *ctx, ArState *st, const float *X, int rows, const __half *Wsplit, int N, int K) {
+  const int rpad = (rows + 127) & ~127;
+  TTS_HIP(ctx, st->a_hi.reserve((size_t)rpad * FF * sizeof(__half)));
+  TTS_HIP(ctx, st->a_lo.reserve((size_t)rpad * FF * sizeof(__half)));
+  TTS_HIP(ctx, st->part.reserve((size_t)rpad * N * sizeof(float)));
+  split_act_kernel<<<rpad, 256, 0, ctx->stream>>>(X, rows, K, st->a_hi.as<__half>(), st->a_lo.as<__half>());
+  GemmArgs g{};
+  g.A[0] = st->a_hi.as<__half>(); g.A[1] = st->a_lo.as<__half>(); g.A[2] = st->a_hi.as<__half>();
+  g.row_off[0] = g.row_off[1] = g.row_off[2] = 0;
+  g.nseg = 3; g.kseg = K; g.lda = K; g.W = Wsplit;
+  g.custom_w = 1; g.ldw_ = 2 * K; g.w_off_[0] = 0; g.w_off_[1] = 0; g.w_off_[2] = K; // hi*hi + lo*hi + hi*lo
+  g.M = rpad; g.N = N; g.bias = nullptr; g.row_seq = nullptr;
+  g.mode = GEMM_OUT_F32; g.outF = st->part.as<float>(); g.ldo = N; g.resid = nullptr;
+  ProfScope ps(ctx, "ar_mfma_gemm", 2.0 * rows * (double)N * K);
+  TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream));
   return TTS_OK;
 }
 
@@ -665,24 +740,30 @@ static int run_layers(tts_ctx *ctx, ArState *st, int rows, int S, int n_past, __
   float *h = st->h.as<float>(), *xn = st->xn.as<float>(), *qkv = st->qkv.as<float>();
   float *att = st->att.as<float>(), *ff = st->ff.as<float>();
   KvDst nokv{nullptr, nullptr, 1, 0, 0, 0};
+  const bool mfma = rows >= 32; // multi-row passes: split-precision MFMA GEMM; tiny row counts: exact f32 GEMV
+  const float ps = mfma ? 1.0f / W16_SCALE : 1.0f;
   for (int l = 0; l < st->n_layers; l++) {
     const ArLayerDev &w = st->L[l];
-    int ks;
+    int ks = 1;
     { ProfScope ps(ctx, "ar_layernorm");
       layernorm_kernel<<<rows, 256, 0, ctx->stream>>>(h, w.ln1_g, w.ln1_b, xn); }
-    CHECK(launch_gemv(ctx, st, xn, D, rows, w.w_attn, 3 * D, D, &ks));
+    if (mfma) CHECK(launch_mfma_matmul(ctx, st, xn, rows, w.s_attn, 3 * D, D));
+    else CHECK(launch_gemv(ctx, st, xn, D, rows, w.w_attn, 3 * D, D, &ks));
     KvDst kv{kc + l * layer_stride, vc + l * layer_stride, S, n_past, kv_max_pos, replicate};
-    CHECK(launch_epilogue<EPI_QKV>(ctx, st, ks, rows, 3 * D, 3 * D, w.b_attn, qkv, 3 * D, kv));
+    CHECK(launch_epilogue<EPI_QKV>(ctx, st, ks, rows, 3 * D, 3 * D, w.b_attn, qkv, 3 * D, kv, ps));
     { ProfScope ps(ctx, "ar_attention");
       attention_kernel<<<dim3(rows, NH), 64, 0, ctx->stream>>>(qkv, kv.k, kv.v, att, S, n_past, kv_max_pos, ctx->ggml_lut); }
-    CHECK(launch_gemv(ctx, st, att, D, rows, w.w_proj, D, D, &ks));
-    CHECK(launch_epilogue<EPI_RESID>(ctx, st, ks, rows, D, D, w.b_proj, h, D, nokv));
+    if (mfma) CHECK(launch_mfma_matmul(ctx, st, att, rows, w.s_proj, D, D));
+    else CHECK(launch_gemv(ctx, st, att, D, rows, w.w_proj, D, D, &ks));
+    CHECK(launch_epilogue<EPI_RESID>(ctx, st, ks, rows, D, D, w.b_proj, h, D, nokv, ps));
     { ProfScope ps(ctx, "ar_layernorm");
       layernorm_kernel<<<rows, 256, 0, ctx->stream>>>(h, w.ln2_g, w.ln2_b, xn); }
-    CHECK(launch_gemv(ctx, st, xn, D, rows, w.w_fc, FF, D, &ks));
-    CHECK(launch_epilogue<EPI_GELU>(ctx, st, ks, rows, FF, FF, w.b_fc, ff, FF, nokv));
-    CHECK(launch_gemv(ctx, st, ff, FF, rows, w.w_fc2, D, FF, &ks));
-    CHECK(launch_epilogue<EPI_RESID>(ctx, st, ks, rows, D, D, w.b_fc2, h, D, nokv));
+    if (mfma) CHECK(launch_mfma_matmul(ctx, st, xn, rows, w.s_fc, FF, D));
+    else CHECK(launch_gemv(ctx, st, xn, D, rows, w.w_fc, FF, D, &ks));
+    CHECK(launch_epilogue<EPI_GELU>(ctx, st, ks, rows, FF, FF, w.b_fc, ff, FF, nokv, ps));
+    if (mfma) CHECK(launch_mfma_matmul(ctx, st, ff, rows, w.s_fc2, D, FF));
+    else CHECK(launch_gemv(ctx, st, ff, FF, rows, w.w_fc2, D, FF, &ks));
+    CHECK(launch_epilogue<EPI_RESID>(ctx, st, ks, rows, D, D, w.b_fc2, h, D, nokv, ps));
   }
   TTS_HIP(ctx, hipGetLastError());
   return TTS_OK;
@@ -812,7 +893,7 @@ static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
     ProfScope ps(ctx, "ar_epilogue");
     KvDst nokv{nullptr, nullptr, 1, 0, 0, 0};
     epilogue_kernel<EPI_BIAS><<<dim3(B, (V + 255) / 256), 256, 0, ctx->stream>>>(pA, ks, B, VPAD, V, st->lm_b, st->logits.as<float>(), V,
-                                                                             nokv, 0);
+                                                                             nokv, 0, 1.0f);
   }
   TTS_HIP(ctx, hipMemcpyAsync(st->h_logits, st->logits.p, (size_t)B * V * 4, hipMemcpyDeviceToHost, ctx->stream));
   TTS_HIP(ctx, hipGetLastError());

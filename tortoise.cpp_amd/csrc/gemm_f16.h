@@ -28,7 +28,8 @@ struct GemmArgs {
   int row_off[3];
   int nseg, kseg;      // kseg % 64 == 0
   int lda;             // halves
-  const __half *W;     // [N][nseg*kseg]
+  const __half *W;     // [N][ldw]; segment seg starts at column w_off[seg] (defaults: ldw = nseg*kseg, w_off = seg*kseg)
+  int ldw_, w_off_[3], custom_w; // set custom_w = 1 to use ldw_/w_off_ (e.g. split-precision: hi|lo halves reused)
   int M, N;            // multiples of 128 (buffers are padded)
   const float *bias;   // [N] or nullptr
   const int *row_seq;  // [M]: sequence id, <0 for guard/padding rows (output forced to 0); may be null
@@ -55,14 +56,14 @@ static __global__ __launch_bounds__(256) void gemm_f16_kernel(GemmArgs g) {
   }
   const int m0 = (bid / ntn) << 7, n0 = (bid % ntn) << 7;
   const int tiles_per_seg = g.kseg >> 6, nk = g.nseg * tiles_per_seg;
-  const int ldw = g.nseg * g.kseg;
+  const int ldw = g.custom_w ? g.ldw_ : g.nseg * g.kseg;
 
   const int lc = tid & 7, lr = tid >> 3; // staging: chunk lc of rows lr, lr+32, lr+64, lr+96
   uint4 ra[4], rb[4];
   auto gload = [&](int kt) {
     const int seg = kt / tiles_per_seg, kk = (kt - seg * tiles_per_seg) << 6;
     const __half *ap = g.A[seg] + (size_t)(m0 + g.row_off[seg] + lr) * g.lda + kk + lc * 8;
-    const __half *wp = g.W + (size_t)(n0 + lr) * ldw + seg * g.kseg + kk + lc * 8;
+    const __half *wp = g.W + (size_t)(n0 + lr) * ldw + (g.custom_w ? g.w_off_[seg] : seg * g.kseg) + kk + lc * 8;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       ra[i] = *(const uint4 *)(ap + (size_t)i * 32 * g.lda);
@@ -259,7 +260,7 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g
   }
   const int m0 = (bid / ntn) << 7, n0 = (bid % ntn) << 7;
   const int tiles_per_seg = g.kseg >> 6, nk = g.nseg * tiles_per_seg;
-  const int ldw = g.nseg * g.kseg;
+  const int ldw = g.custom_w ? g.ldw_ : g.nseg * g.kseg;
   // DMA roles: wave w, piece i covers rows (w*4+i)*8 .. +7 of the A tile and of the B tile
   const int prow = lane >> 3, pslot = lane & 7;
   floatx4 acc[4][4];
@@ -277,7 +278,7 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g
     for (int kt = 0; kt < nk; kt++) {
       const int seg = kt / tiles_per_seg, kk = (kt - seg * tiles_per_seg) << 6;
       const __half *abase = g.A[seg] + (size_t)(m0 + g.row_off[seg]) * g.lda + kk;
-      const __half *wbase = g.W + (size_t)n0 * ldw + seg * g.kseg + kk;
+      const __half *wbase = g.W + (size_t)n0 * ldw + (g.custom_w ? g.w_off_[seg] : seg * g.kseg) + kk;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int row = (wave * 4 + i) * 8 + prow;
@@ -326,7 +327,7 @@ static __global__ __launch_bounds__(256) void gemm_f16_ring_kernel(GemmArgs g) {
   }
   const int m0 = (bid / ntn) << 7, n0 = (bid % ntn) << 7;
   const int tiles_per_seg = g.kseg >> 6, nk = g.nseg * tiles_per_seg;
-  const int ldw = g.nseg * g.kseg;
+  const int ldw = g.custom_w ? g.ldw_ : g.nseg * g.kseg;
   const int prow = lane >> 3, pslot = lane & 7;
   floatx4 acc[4][4];
 #pragma unroll
@@ -338,7 +339,7 @@ static __global__ __launch_bounds__(256) void gemm_f16_ring_kernel(GemmArgs g) {
   auto stage = [&](int kt, int buf) {
     const int seg = kt / tiles_per_seg, kk = (kt - seg * tiles_per_seg) << 6;
     const __half *abase = g.A[seg] + (size_t)(m0 + g.row_off[seg]) * g.lda + kk;
-    const __half *wbase = g.W + (size_t)n0 * ldw + seg * g.kseg + kk;
+    const __half *wbase = g.W + (size_t)n0 * ldw + (g.custom_w ? g.w_off_[seg] : seg * g.kseg) + kk;
     char *sa = smem + buf * 32768, *sb = sa + 16384;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -418,7 +419,7 @@ static __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g) {
   }
   const int m0 = (bid / ntn) << 8, n0 = (bid % ntn) << 7;
   const int tiles_per_seg = g.kseg >> 6, nk = g.nseg * tiles_per_seg;
-  const int ldw = g.nseg * g.kseg;
+  const int ldw = g.custom_w ? g.ldw_ : g.nseg * g.kseg;
   const int prow = lane >> 3, pslot = lane & 7;
   floatx4 acc[4][4];
 #pragma unroll
@@ -431,7 +432,7 @@ static __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g) {
   auto stage = [&](int kt, int buf) {
     const int seg = kt / tiles_per_seg, kk = (kt - seg * tiles_per_seg) << 6;
     const __half *abase = g.A[seg] + (size_t)g.row_off[seg] * g.lda + kk;
-    const __half *wbase = g.W + (size_t)n0 * ldw + seg * g.kseg + kk;
+    const __half *wbase = g.W + (size_t)n0 * ldw + (g.custom_w ? g.w_off_[seg] : seg * g.kseg) + kk;
     char *sa = smem + buf * STAGE, *sb = sa + 32768;
 #pragma unroll
     for (int i = 0; i < 4; i++) { // A: 32 pieces of 8 rows

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <fstream>
+#include <functional>
 #include <limits>
 #include <regex>
 
@@ -186,46 +187,88 @@ void sample_candidates(tts_ctx *ctx, const float *logits, const int32_t *ids, in
                        int32_t *out) {
   const int V = TTS_VOCAB_MEL, TOPK = 50;
   const float LOWEST = std::numeric_limits<float>::lowest();
-  std::vector<float> l(V), tmp(V);
+  const float temp = 0.8;
   struct Surv { float v; int idx; float e; };
-  std::vector<Surv> s;
+  std::vector<Surv> s, asc;
+  std::vector<float> l; // only materialised for the (rare) literal fallback
   for (int c = 0; c < B; c++) {
     const float *src = logits + (size_t)c * V;
-    std::copy(src, src + V, l.begin());
-    for (int j = 0; j < ids_per_cand; j++) { // gather -> apply_penalty(2.0) -> scatter
-      int id = ids[(size_t)c * ids_per_cand + j];
-      float g = src[id];
-      l[id] = (g < 0) ? g * 2.0f : g / 2.0f;
-    }
-    const float temp = 0.8;
-    for (int i = 0; i < V; i++) l[i] /= temp;
-    tmp = l;
-    std::nth_element(tmp.begin(), tmp.begin() + (V - TOPK), tmp.end());
-    const float kth = tmp[V - TOPK];
-    s.clear();
-    for (int i = 0; i < V; i++) {
-      if (l[i] < kth) l[i] = LOWEST;
-      else s.push_back({l[i], i, 0.f});
+    // gather -> apply_penalty(2.0) -> scatter touches at most a few distinct ids (the prompt-shaped
+    // [1 ... 1, 8192] at step 0, the previous sample afterwards): keep them as overrides
+    int pid[4]; float pval[4]; int np = 0;
+    bool many = false;
+    for (int j = 0; j < ids_per_cand; j++) {
+      const int id = ids[(size_t)c * ids_per_cand + j];
+      bool seen = false;
+      for (int q = 0; q < np; q++) seen |= (pid[q] == id);
+      if (seen) continue;
+      if (np == 4) { many = true; break; }
+      const float g = src[id];
+      pid[np] = id; pval[np] = (g < 0) ? g * 2.0f : g / 2.0f; np++;
     }
     float sample = ctx->distribution(ctx->generator); // first draw discarded (main.cpp:4708-4709)
     sample = ctx->distribution(ctx->generator);
-    std::vector<Surv> asc(s);
+    auto literal = [&]() {
+      l.assign(src, src + V);
+      for (int j = 0; j < ids_per_cand; j++) {
+        const int id = ids[(size_t)c * ids_per_cand + j];
+        const float g = src[id];
+        l[id] = (g < 0) ? g * 2.0f : g / 2.0f;
+      }
+      for (int i = 0; i < V; i++) l[i] /= temp;
+      std::vector<float> tmp(l);
+      std::nth_element(tmp.begin(), tmp.begin() + (V - TOPK), tmp.end());
+      const float kth = tmp[V - TOPK];
+      for (int i = 0; i < V; i++) if (l[i] < kth) l[i] = LOWEST;
+      return multinomial_literal(l, sample);
+    };
+    if (many) { out[c] = literal(); continue; }
+    auto val = [&](int i) { for (int q = 0; q < np; q++) if (pid[q] == i) return pval[q]; return src[i]; };
+    // k-th largest penalised logit: min-heap of the 50 largest seen so far (almost every element fails
+    // the single compare against the heap minimum)
+    float heap[TOPK];
+    for (int i = 0; i < TOPK; i++) heap[i] = val(i);
+    std::make_heap(heap, heap + TOPK, std::greater<float>());
+    float hmin = heap[0];
+    for (int i = TOPK; i < V; i++) {
+      float x = src[i];
+      if (x <= hmin) continue;              // (penalised values are <= their source unless negative*2, handled by val)
+      x = val(i);
+      if (x <= hmin) continue;
+      std::pop_heap(heap, heap + TOPK, std::greater<float>());
+      heap[TOPK - 1] = x;
+      std::push_heap(heap, heap + TOPK, std::greater<float>());
+      hmin = heap[0];
+    }
+    // a penalised NEGATIVE logit is x*2 < x, a positive one x/2 < x: overrides never exceed src, so the scan
+    // above cannot miss them. Threshold on the tempered values: ties (also those created by the division's
+    // rounding: at most two adjacent floats share a quotient) survive, as in val_where_below_thresh.
+    const float kth = hmin / temp;
+    float cut = hmin;
+    for (int q = 0; q < 4; q++) cut = std::nextafter(cut, LOWEST);
+    s.clear();
+    for (int i = 0; i < V; i++) {
+      if (src[i] < cut) continue;
+      const float v = val(i) / temp;
+      if (v >= kth) s.push_back({v, i, 0.f});
+    }
+    asc = s;
     std::sort(asc.begin(), asc.end(), [](const Surv &a, const Surv &b) { return a.v < b.v; });
     bool tie = false;
     for (size_t i = 1; i < asc.size(); i++) tie |= (asc[i].v == asc[i - 1].v);
-    if (tie) { out[c] = multinomial_literal(l, sample); continue; }
+    if (tie) { out[c] = literal(); continue; } // inherit std::sort's tie order from the literal formulation
     // top-p over the ascending survivors (non-survivors contribute exp(lowest) = +0)
     float sum = 0;
     for (auto &a : asc) { a.e = exp_like_reference(a.v); sum += a.e; }
     float cum = 0;
-    std::vector<char> cut(V, 0);
+    // final softmax + multinomial in index order
     for (size_t i = 0; i < asc.size(); i++) {
       cum += asc[i].e / sum;
-      if (i + 1 < asc.size() && cum <= 0.2) cut[asc[i].idx] = 1;
+      if (i + 1 < asc.size() && cum <= 0.2)
+        for (auto &b : s) if (b.idx == asc[i].idx) b.v = LOWEST; // cut
     }
-    // final softmax + multinomial in index order
     sum = 0;
-    for (auto &a : s) { a.e = cut[a.idx] ? 0.f : exp_like_reference(a.v); sum += a.e; }
+    for (auto &a : s) { a.e = (a.v == LOWEST) ? 0.f : exp_like_reference(a.v); sum += a.e; }
     int pick = V - 1;
     if (!(0.0f < sample)) pick = 0; // cumulative(=0) >= sample already at index 0
     else {
