@@ -87,13 +87,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 // formed while staging (fuses the c_fc epilogue into the c_proj GEMV); X then points at pin, ldx = its N.
 template <int RT, int PRO>
 __global__ __launch_bounds__(256) void gemv_kn_kernel(const float *__restrict__ X, int ldx, int rows,
-                                                      const float *__restrict__ W, int N, int kspan,
+                                                      const float *__restrict__ W, int N, int K, int kspan,
                                                       float *__restrict__ part, int pin_ks, const float *__restrict__ pin_bias,
                                                       int lut) {
   __shared__ float xs[256 * RT];
   __shared__ float red[4 * RT * 64];
   const int tid = threadIdx.x, cx = tid & 15, ky = tid >> 4;
-  const int col0 = blockIdx.x * 64 + cx * 4;
   const int r0 = blockIdx.z * RT;
   float acc[RT][4];
 #pragma unroll
@@ -115,11 +114,11 @@ __global__ __launch_bounds__(256) void gemv_kn_kernel(const float *__restrict__ 
       xs[k * RT + r] = xv;
     }
     __syncthreads();
-    const float *wp = W + (size_t)(k0 + ky) * N + col0;
+    const float *wp = W + ((size_t)blockIdx.x * K + k0 + ky) * 64 + cx * 4; // strip-major [N/64][K][64]
 #pragma unroll 4
     for (int k = ky; k < kchunk; k += 16) {
       const float4 w = *(const float4 *)wp;
-      wp += (size_t)16 * N;
+      wp += 16 * 64;
 #pragma unroll
       for (int r = 0; r < RT; r++) {
         const float xv = xs[k * RT + r];
@@ -160,11 +159,11 @@ __global__ __launch_bounds__(256) void gemv_kn_kernel(const float *__restrict__ 
 // (the oracle gate for these passes is 1e-4). Weights are pre-scaled by 64 so the lo parts stay normal.
 // ---------------------------------------------------------------------------------------------
 static constexpr float W16_SCALE = 64.0f;
-// W f32 [K][N] -> out fp16 [N][2K] = [hi(0..K-1) | lo(0..K-1)] of 64*W^T (tile transpose through LDS)
+// W f32 strip-major [N/64][K][64] -> out fp16 [N][2K] = [hi(0..K-1) | lo(0..K-1)] of 64*W^T (tile transpose through LDS)
 __global__ __launch_bounds__(256) void split_weight_kernel(const float *__restrict__ W, int K, int N, __half *__restrict__ out) {
   __shared__ float t[32][33];
   const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int r = ty; r < 32; r += 8) t[r][tx] = W[(size_t)(k0 + r) * N + n0 + tx] * W16_SCALE;
+  for (int r = ty; r < 32; r += 8) t[r][tx] = W[((size_t)(n0 >> 6) * K + k0 + r) * 64 + (n0 & 63) + tx] * W16_SCALE; // strip-major source
   __syncthreads();
   for (int r = ty; r < 32; r += 8) {
     const float v = t[tx][r];
@@ -436,19 +435,18 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float *__restric
 // is evaluated while staging.
 template <int RT, int NK, int PRO>
 __global__ __launch_bounds__(256) void gemv_decode_kernel(const float *__restrict__ X, int ldx, int rows,
-                                                          const float *__restrict__ W, int N, float *__restrict__ part,
+                                                          const float *__restrict__ W, int N, int K, float *__restrict__ part,
                                                           int pin_ks, const float *__restrict__ pin_bias, int lut) {
   constexpr int KS = NK * 16;
   __shared__ float xs[KS * RT];
   __shared__ float red[4 * RT * 64];
   const int tid = threadIdx.x, cx = tid & 15, ky = tid >> 4;
-  const int col0 = blockIdx.x * 64 + cx * 4;
   const int k0 = blockIdx.y * KS;
   float4 w[NK];
   {
-    const float *wp = W + (size_t)(k0 + ky) * N + col0;
+    const float *wp = W + ((size_t)blockIdx.x * K + k0 + ky) * 64 + cx * 4; // strip-major [N/64][K][64]
 #pragma unroll
-    for (int i = 0; i < NK; i++) w[i] = *(const float4 *)(wp + (size_t)i * 16 * N);
+    for (int i = 0; i < NK; i++) w[i] = *(const float4 *)(wp + i * 16 * 64);
   }
   constexpr int PER = (KS * RT + 255) / 256;
   float xv[PER];
@@ -573,14 +571,26 @@ static int upload(tts_ctx *ctx, ArState *st, const std::vector<float> &src, floa
   return TTS_OK;
 }
 
+// Weight matrices [K][N] (N contiguous) are re-tiled at load into 64-column strips, [N/64][K][64], so that the
+// K-chunk a GEMV workgroup streams is ONE contiguous region and a wave's load instruction covers 1 KB of
+// consecutive bytes (the reference re-transposes every matrix in every graph execution; here the layout
+// is chosen once).
+static std::vector<float> strip_major(const float *w, int K, int N) {
+  std::vector<float> t((size_t)K * N);
+  for (int s0 = 0; s0 < N / 64; s0++)
+    for (int k = 0; k < K; k++) memcpy(&t[((size_t)s0 * K + k) * 64], &w[(size_t)k * N + s0 * 64], 64 * sizeof(float));
+  return t;
+}
+
 static int fetch(tts_ctx *ctx, ArState *st, const WeightFile &wf, const std::string &name, int64_t ne0, int64_t ne1,
-                 float **dst) {
+                 float **dst, bool tile = false) {
   auto it = wf.t.find(name);
   if (it == wf.t.end()) return fail(ctx, TTS_ERR_FORMAT, "tensor '%s' missing from AR model file", name.c_str());
   const HostTensor &t = it->second;
   if (t.ne[0] != ne0 || t.ne[1] != ne1 || t.nelem() != ne0 * ne1)
     return fail(ctx, TTS_ERR_FORMAT, "tensor '%s' has wrong shape in model file: got [%d, %d], expected [%d, %d]",
                 name.c_str(), (int)t.ne[0], (int)t.ne[1], (int)ne0, (int)ne1);
+  if (tile) return upload(ctx, st, strip_major(t.data.data(), (int)ne1, (int)ne0), dst);
   return upload(ctx, st, t.data, dst);
 }
 
@@ -601,6 +611,7 @@ int ar_load(tts_ctx *ctx, const char *path) {
     if (!ok) return fail(ctx, TTS_ERR_FORMAT, "unknown tensor '%s' in model file", n.c_str());
   }
 #define FETCH(name, a, b, dst) do { int _r = fetch(ctx, st.get(), wf, name, a, b, dst); if (_r) return _r; } while (0)
+#define FETCHT(name, a, b, dst) do { int _r = fetch(ctx, st.get(), wf, name, a, b, dst, true); if (_r) return _r; } while (0)
   FETCH("text_embedding.weight", D, 256, &st->text_emb);
   FETCH("text_pos_embedding.emb.weight", D, 404, &st->text_pos);
   FETCH("mel_embedding.weight", D, V, &st->mel_emb);
@@ -615,12 +626,13 @@ int ar_load(tts_ctx *ctx, const char *path) {
     ArLayerDev &l = st->L[i];
     FETCH(p + ".ln_1.weight", D, 1, &l.ln1_g); FETCH(p + ".ln_1.bias", D, 1, &l.ln1_b);
     FETCH(p + ".ln_2.weight", D, 1, &l.ln2_g); FETCH(p + ".ln_2.bias", D, 1, &l.ln2_b);
-    FETCH(p + ".attn.c_attn.weight", 3 * D, D, &l.w_attn); FETCH(p + ".attn.c_attn.bias", 3 * D, 1, &l.b_attn);
-    FETCH(p + ".attn.c_proj.weight", D, D, &l.w_proj); FETCH(p + ".attn.c_proj.bias", D, 1, &l.b_proj);
-    FETCH(p + ".mlp.c_fc.weight", FF, D, &l.w_fc); FETCH(p + ".mlp.c_fc.bias", FF, 1, &l.b_fc);
-    FETCH(p + ".mlp.c_proj.weight", D, FF, &l.w_fc2); FETCH(p + ".mlp.c_proj.bias", D, 1, &l.b_fc2);
+    FETCHT(p + ".attn.c_attn.weight", 3 * D, D, &l.w_attn); FETCH(p + ".attn.c_attn.bias", 3 * D, 1, &l.b_attn);
+    FETCHT(p + ".attn.c_proj.weight", D, D, &l.w_proj); FETCH(p + ".attn.c_proj.bias", D, 1, &l.b_proj);
+    FETCHT(p + ".mlp.c_fc.weight", FF, D, &l.w_fc); FETCH(p + ".mlp.c_fc.bias", FF, 1, &l.b_fc);
+    FETCHT(p + ".mlp.c_proj.weight", D, FF, &l.w_fc2); FETCH(p + ".mlp.c_proj.bias", D, 1, &l.b_fc2);
   }
 #undef FETCH
+#undef FETCHT
   for (int i = 0; i < st->n_layers; i++) { // split-precision copies for the multi-row MFMA path
     ArLayerDev &l = st->L[i];
     struct { const float *w; int K, N; __half **dst; } jobs[4] = {
@@ -645,7 +657,7 @@ int ar_load(tts_ctx *ctx, const char *path) {
     for (int n = 0; n < V; n++)
       for (int k = 0; k < D; k++) wt[(size_t)k * VPAD + n] = w[(size_t)n * D + k];
     std::copy(ib->second.data.begin(), ib->second.data.end(), bt.begin());
-    int r = upload(ctx, st.get(), wt, &st->lm_w); if (r) return r;
+    int r = upload(ctx, st.get(), strip_major(wt.data(), D, VPAD), &st->lm_w); if (r) return r;
     r = upload(ctx, st.get(), bt, &st->lm_b); if (r) return r;
   }
   if (ctx->ar) ar_free(ctx->ar);
@@ -672,8 +684,8 @@ static int launch_gemv(tts_ctx *ctx, ArState *st, const float *X, int ldx, int r
   ProfScope ps(ctx, "ar_gemv", (double)K * N * 4.0 * ztiles); // weight bytes streamed
   if (ztiles == 1 && rows <= 16 && kchunk <= 256 && (kchunk == 32 || kchunk == 64 || kchunk == 128 || kchunk == 256)) {
 #define DEC_LAUNCH(NK_)                                                                                                      \
-  if (pin_ks > 0) gemv_decode_kernel<16, NK_, 1><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, part, pin_ks, pin_bias, ctx->ggml_lut); \
-  else gemv_decode_kernel<16, NK_, 0><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, part, 0, nullptr, 0)
+  if (pin_ks > 0) gemv_decode_kernel<16, NK_, 1><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, K, part, pin_ks, pin_bias, ctx->ggml_lut); \
+  else gemv_decode_kernel<16, NK_, 0><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, K, part, 0, nullptr, 0)
     switch (kchunk) {
       case 32: DEC_LAUNCH(2); break;
       case 64: DEC_LAUNCH(4); break;
@@ -686,8 +698,8 @@ static int launch_gemv(tts_ctx *ctx, ArState *st, const float *X, int ldx, int r
     return TTS_OK;
   }
 #define GEMV_LAUNCH(RT_)                                                                                                   \
-  if (pin_ks > 0) gemv_kn_kernel<RT_, 1><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, kchunk, part, pin_ks, pin_bias, ctx->ggml_lut); \
-  else gemv_kn_kernel<RT_, 0><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, kchunk, part, 0, nullptr, 0)
+  if (pin_ks > 0) gemv_kn_kernel<RT_, 1><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, K, kchunk, part, pin_ks, pin_bias, ctx->ggml_lut); \
+  else gemv_kn_kernel<RT_, 0><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, K, kchunk, part, 0, nullptr, 0)
   switch (rt) {
     case 1: GEMV_LAUNCH(1); break;
     case 2: GEMV_LAUNCH(2); break;
