@@ -16,6 +16,7 @@
 #include <hip/hip_fp16.h>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace tts {
 
@@ -923,7 +924,8 @@ int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out
   }
   st->h_toks[st->B] = st->P + step_i; // n_past
   st->h_toks[st->B + 1] = step_i + 2; // mel position id (main.cpp:5244)
-  if (ctx->prof_on) { // event records are not captured: run eagerly when profiling
+  static const bool no_graph = getenv("TTS_NO_GRAPH") != nullptr; // e.g. under rocprofv3, which crashes on graph replays here
+  if (ctx->prof_on || no_graph) { // event records are not captured: run eagerly when profiling
     CHECK(enqueue_decode_step(ctx, st));
   } else {
     if (!st->graph_exec) {

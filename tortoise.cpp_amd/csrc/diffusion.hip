@@ -751,15 +751,6 @@ static int gn_stats(tts_ctx *ctx, const Layout &lay, Work &wk, const float *x) {
   TTS_HIP(ctx, hipGetLastError());
   return TTS_OK;
 }
-static int gn_apply(tts_ctx *ctx, const Layout &lay, Work &wk, const float *x, const float *g, const float *b, const float *ss,
-                    int do_silu, __half *y) {
-  ProfScope ps(ctx, "diff_gn_apply");
-  gn_apply_kernel<<<lay.rows, 256, 0, ctx->stream>>>(x, lay.d_row_seq.as<int>(), wk.use_raw ? wk.raw.as<float2>() : wk.stats.as<float2>(), g, b,
-                                                     ss, do_silu, ctx->ggml_lut, y, wk.use_raw ? lay.d_len.as<int>() : nullptr, ctx->gn_eps);
-  TTS_HIP(ctx, hipGetLastError());
-  return TTS_OK;
-}
-
 // stats + apply in one launch (see gn_fused_kernel)
 static int gn_fused(tts_ctx *ctx, const Layout &lay, const float *x, const float *g, const float *b, const float *ss, int do_silu,
                     __half *y) {

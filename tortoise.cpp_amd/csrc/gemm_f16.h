@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <type_traits>
 
 namespace tts {
@@ -31,6 +32,7 @@ struct GemmArgs {
   const __half *W;     // [N][ldw]; segment seg starts at column w_off[seg] (defaults: ldw = nseg*kseg, w_off = seg*kseg)
   int ldw_, w_off_[3], custom_w; // set custom_w = 1 to use ldw_/w_off_ (e.g. split-precision: hi|lo halves reused)
   int M, N;            // multiples of 128 (buffers are padded)
+  int cn;              // n-tiles per L2 chunk (0 = all; chosen by launch_gemm_f16)
   const float *bias;   // [N] or nullptr
   const int *row_seq;  // [M]: sequence id, <0 for guard/padding rows (output forced to 0); may be null
   // GEMM_OUT_F32
@@ -252,13 +254,18 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g
   __shared__ __attribute__((aligned(16))) char smem[32768];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int ntn = g.N >> 7, ntiles = (g.M >> 7) * ntn;
-  int bid = blockIdx.x;
-  {
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int m0 = (bid / ntn) << 7, n0 = (bid % ntn) << 7;
+  // L2-aware tile order. Workgroup b runs on XCD b % 8 (each XCD has its own 4 MB L2). An XCD owns a
+  // contiguous range of m-tiles and walks them once per chunk of `cn` n-tiles, chunk outermost: the chunk's
+  // weight rows (cn * 128 * K * 2 B <= ~2.5 MB) stay L2-resident while the activations stream through.
+  // (With plain m-major order the 6 MB QKV weight thrashed L2: 417 MB fetched per launch for 64 MB of operands.)
+  const int MT = g.M >> 7, NT = g.N >> 7;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int mq = MT >> 3, mr = MT & 7;
+  const int mcount = mq + (xcd < mr ? 1 : 0), mfirst = xcd * mq + (xcd < mr ? xcd : mr);
+  if (idx >= mcount * NT) return; // grid is padded to 8 * max tiles per XCD
+  const int cn = g.cn > 0 ? g.cn : NT, per_chunk = mcount * cn;
+  const int chunk = idx / per_chunk, rem = idx - chunk * per_chunk;
+  const int m0 = (mfirst + rem / cn) << 7, n0 = (chunk * cn + rem % cn) << 7;
   const int tiles_per_seg = g.kseg >> 6, nk = g.nseg * tiles_per_seg;
   const int ldw = g.custom_w ? g.ldw_ : g.nseg * g.kseg;
   // DMA roles: wave w, piece i covers rows (w*4+i)*8 .. +7 of the A tile and of the B tile
@@ -504,6 +511,17 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
     attr_set = true;
   }
   const int ntiles = (g.M >> 7) * (g.N >> 7);
+  GemmArgs gg = g;
+  {
+    const int NT = g.N >> 7, ktot = g.nseg * g.kseg;
+    int cn = NT;
+    static const bool no_chunk = getenv("TTS_GEMM_NOCHUNK") != nullptr; // A/B switch for tools/gemm_bench
+    // measured (tools/gemm_bench): chunking pays for wide outputs (N=3072: 248-268 vs 275-279 us) and costs ~3% when
+    // the activations would have to stream twice for a narrow one (N=1024, K=3072) -> only chunk when NT > 8
+    while (!no_chunk && NT > 8 && cn > 1 && (cn % 2 == 0) && (size_t)cn * 128 * ktot * 2 > (size_t)2560 * 1024) cn /= 2;
+    gg.cn = cn;
+  }
+  const int MTt = g.M >> 7, grid1 = 8 * ((MTt >> 3) + ((MTt & 7) ? 1 : 0)) * (g.N >> 7);
 #ifndef TTS_GEMM_VARIANT
 #define TTS_GEMM_VARIANT 1
 #endif
@@ -511,9 +529,9 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
   if (TTS_GEMM_VARIANT == 2) return launch_gemm_ring<2>(g, s);
   if (TTS_GEMM_VARIANT == 3) return launch_gemm_ring<3>(g, s);
   if (TTS_GEMM_VARIANT == 0) gemm_f16_kernel<<<ntiles, 256, 65536, s>>>(g);
-  else if (g.mode == GEMM_OUT_F32) gemm_f16_glds_kernel<GEMM_OUT_F32><<<ntiles, 256, 0, s>>>(g);
-  else if (g.mode == GEMM_OUT_F16) gemm_f16_glds_kernel<GEMM_OUT_F16><<<ntiles, 256, 0, s>>>(g);
-  else gemm_f16_glds_kernel<GEMM_OUT_QKV><<<ntiles, 256, 0, s>>>(g);
+  else if (g.mode == GEMM_OUT_F32) gemm_f16_glds_kernel<GEMM_OUT_F32><<<grid1, 256, 0, s>>>(gg);
+  else if (g.mode == GEMM_OUT_F16) gemm_f16_glds_kernel<GEMM_OUT_F16><<<grid1, 256, 0, s>>>(gg);
+  else gemm_f16_glds_kernel<GEMM_OUT_QKV><<<grid1, 256, 0, s>>>(gg);
   return hipGetLastError();
 }
 
