@@ -194,6 +194,15 @@ def main():
             dist.destroy_process_group()
         return
     achieved = g_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+    # HBM bytes per GEMM launch from the committed PMC profile (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes,
+    # calibration in the file's note); null when the profile is absent. bench.py does not run rocprofv3 itself.
+    traffic = None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")))["kernels"]
+        gk = [v for k, v in prof.items() if "gemm_f16" in k]
+        traffic = int(sum(v["dispatches"] * v["hbm_bytes_per_launch"] for v in gk) / max(1, sum(v["dispatches"] for v in gk)))
+    except Exception:
+        pass
     out = {
         "metric": "audio-seconds/sec end-to-end (AR+diffusion+vocoder), 16 cands x 80 steps",
         "value": round(audio_s / dt, 3), "unit": "audio-seconds/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -208,7 +217,7 @@ def main():
         "stage_ms_per_step": {k: round(v / a.steps, 1) for k, v in stage_ms.items()},
         "roofline": {"kernel": "gemm_f16_kernel (diffusion convs/projections)", "bound": "mfma", "achieved": round(achieved, 1),
                      "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
-                     "traffic": None, "launches": int(g_n), "avg_launch_us": round(1000.0 * g_ms / max(g_n, 1), 2),
+                     "traffic": traffic, "launches": int(g_n), "avg_launch_us": round(1000.0 * g_ms / max(g_n, 1), 2),
                      "algorithmic_gflop_per_launch": round(g_flops / max(g_n, 1) / 1e9, 2)},
     }
     if world == 1 and not a.no_cpu_baseline:
