@@ -242,8 +242,11 @@ __device__ __forceinline__ float rows4_sum(float x) {
 __global__ __launch_bounds__(256) void diff_attn_kernel(const __half *__restrict__ qk, const __half *__restrict__ vt, int ldvt,
                                                         const int *__restrict__ seq_start, const int *__restrict__ seq_len,
                                                         const float *__restrict__ bias_tab, __half *__restrict__ out, int nq) {
-  __shared__ __attribute__((aligned(16))) char smem[3 * 16384]; // 3-deep ring of (K tile 8 KB | V^T tile 8 KB)
-  __shared__ float tab[128];
+  // ONE LDS object: with a second __shared__ variable hipcc puts an s_waitcnt vmcnt(0) in front of the first
+  // ds_read of every tile, which drains the DMA prefetch (seen in the ISA; cdna_hip_programming.md §5 trap (a)).
+  // (dynamic LDS: with a static array the DMA writes and the fragment reads alias for the waitcnt pass as well)
+  extern __shared__ __attribute__((aligned(16))) char smem[]; // 3-deep ring of (K tile 8 KB | V^T tile 8 KB) + bias table
+  float *tab = (float *)(smem + 3 * 16384);
   // XCD-aware block order: workgroup id b runs on XCD b % 8, so all q-blocks of one (sequence, head) pair
   // get ids congruent mod 8 and reuse that pair's K/V tiles from one L2 (16 heads => pairs % 8 == 0).
   const int xcd = blockIdx.x & 7, tt = blockIdx.x >> 3;
@@ -260,6 +263,10 @@ __global__ __launch_bounds__(256) void diff_attn_kernel(const __half *__restrict
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
       qf[i][ks] = *(const half8 *)(qk + (size_t)(r0 + qw + i * 16 + fr) * 2048 + h * 128 + ks * 32 + fq * 8);
+  // Retire the Q loads HERE (a use makes hipcc place its vmcnt(0) now): vmcnt is an in-order counter, so a Q
+  // load still pending at the loop would force vmcnt(0) in front of the first MFMA of every tile and drain the
+  // K/V prefetch (seen in the ISA as `s_waitcnt vmcnt(0) lgkmcnt(0)` after the ds_reads).
+  asm volatile("" ::"v"(qf[0][0]), "v"(qf[0][1]), "v"(qf[1][0]), "v"(qf[1][1]));
   floatx4 o[2][4]; // O^T[d = dt*16 + fq*4 + r][query = qw + i*16 + fr]
   float mrow[2], lrow[2];
 #pragma unroll
@@ -782,7 +789,7 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
     for (int l : lay.len) aw += 4.0 * l * (double)l * 64 * NHEAD; // QK^T + PV
     ProfScope ps(ctx, "diff_attn", aw);
     const int nq = (lay.max_len() + 127) / 128;
-    diff_attn_kernel<<<nq * NHEAD * lay.ns, 256, 0, ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128,
+    diff_attn_kernel<<<nq * NHEAD * lay.ns, 256, 3 * 16384 + 512, ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128,
                                                                    lay.d_start.as<int>(), lay.d_len.as<int>(), w.bias_tab, wk.ATT16(), nq);
     TTS_HIP(ctx, hipGetLastError());
   }

@@ -503,6 +503,120 @@ static inline hipError_t launch_gemm_big(const GemmArgs &g, hipStream_t s) {
   return hipGetLastError();
 }
 
+// Variant 5: 256 x 256 x 64 tile (128 FLOP per operand byte: half the L2->LDS traffic of the 128^2 tile),
+// 8 waves as 2(M) x 4(N), each 128 x 64 = 8 x 4 MFMA tiles; two 64 KB LDS stages (A 32 KB | B 32 KB), one raw
+// barrier per K tile, tile kt+1 requested right after the barrier and retired (vmcnt 0) before the next one.
+// Fragments are loaded per 64-row half of the wave's rows to stay inside 256 VGPRs.
+template <int MODE>
+static __global__ __launch_bounds__(512) void gemm_f16_256_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  char *smem = smem_dyn;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int MT = (g.M + 255) >> 8, NT = g.N >> 8;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int mq = MT >> 3, mr = MT & 7;
+  const int mcount = mq + (xcd < mr ? 1 : 0), mfirst = xcd * mq + (xcd < mr ? xcd : mr);
+  if (idx >= mcount * NT) return;
+  const int m0 = (mfirst + idx / NT) << 8, n0 = (idx % NT) << 8;
+  const int tiles_per_seg = g.kseg >> 6, nk = g.nseg * tiles_per_seg;
+  const int ldw = g.custom_w ? g.ldw_ : g.nseg * g.kseg;
+  const int prow = lane >> 3, pslot = lane & 7;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int mlast = g.M - 1;
+  floatx4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  auto stage = [&](int kt, int buf) {
+    const int seg = kt / tiles_per_seg, kk = (kt - seg * tiles_per_seg) << 6;
+    const __half *abase = g.A[seg] + (size_t)g.row_off[seg] * g.lda + kk;
+    const __half *wbase = g.W + (size_t)n0 * ldw + (g.custom_w ? g.w_off_[seg] : seg * g.kseg) + kk;
+    char *sa = smem + buf * 65536, *sb = sa + 32768;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { // 32 pieces of 8 rows for A and for B; wave w moves pieces 4w .. 4w+3
+      const int row = (wave * 4 + i) * 8 + prow;
+      const int c = pslot ^ ((row >> 1) & 7);
+      const int grow = min(m0 + row, mlast);
+      __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)grow * g.lda + c * 8), (lptr_t)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (size_t)row * ldw + c * 8), (lptr_t)(sb + (wave * 4 + i) * 1024), 16, 0, 0);
+    }
+  };
+  stage(0, 0);
+  for (int kt = 0; kt < nk; kt++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    const char *sa = smem + (kt & 1) * 65536, *sb = sa + 32768;
+    half8 bf[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) bf[j][ks] = *(const half8 *)(sb + lds_off(wn * 64 + j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+    for (int mh = 0; mh < 2; mh++) {
+      half8 af[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) af[i][ks] = *(const half8 *)(sa + lds_off(wm * 128 + mh * 64 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j][ks], af[i][ks], acc[mh * 4 + i][j], 0, 0, 0);
+    }
+  }
+  // epilogue (F32 / F16 outputs; swapped operand order: lane = 4 consecutive columns of one row)
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int row = m0 + wm * 128 + i * 16 + fr;
+    if (row >= g.M) continue;
+    const bool guard = g.row_seq ? (g.row_seq[row] < 0) : false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int col = n0 + wn * 64 + j * 16 + fq * 4;
+      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      if (g.bias) {
+        const float4 b = *(const float4 *)(g.bias + col);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      if (MODE == GEMM_OUT_F32) {
+        if (g.resid) {
+          const float4 rr = *(const float4 *)(g.resid + (size_t)row * g.ldo + col);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        if (guard) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *(float4 *)(g.outF + (size_t)row * g.ldo + col) = v;
+      } else {
+        if (guard) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        __half2 p0 = __floats2half2_rn(v.x, v.y), p1 = __floats2half2_rn(v.z, v.w);
+        uint2 u;
+        u.x = *(unsigned *)&p0;
+        u.y = *(unsigned *)&p1;
+        *(uint2 *)(g.outH + (size_t)row * g.ldh + col) = u;
+      }
+    }
+  }
+}
+
+static inline hipError_t launch_gemm_256(const GemmArgs &g, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void *)gemm_f16_256_kernel<GEMM_OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    (void)hipFuncSetAttribute((const void *)gemm_f16_256_kernel<GEMM_OUT_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    attr_set = true;
+  }
+  const int MT = (g.M + 255) >> 8, NT = g.N >> 8;
+  const int grid = 8 * ((MT >> 3) + ((MT & 7) ? 1 : 0)) * NT;
+  if (g.mode == GEMM_OUT_F32) gemm_f16_256_kernel<GEMM_OUT_F32><<<grid, 512, 131072, s>>>(g);
+  else gemm_f16_256_kernel<GEMM_OUT_F16><<<grid, 512, 131072, s>>>(g);
+  return hipGetLastError();
+}
+
 static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -525,6 +639,7 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
 #ifndef TTS_GEMM_VARIANT
 #define TTS_GEMM_VARIANT 1
 #endif
+  if (TTS_GEMM_VARIANT == 5) return launch_gemm_256(g, s);
   if (TTS_GEMM_VARIANT == 4) return launch_gemm_big(g, s);
   if (TTS_GEMM_VARIANT == 2) return launch_gemm_ring<2>(g, s);
   if (TTS_GEMM_VARIANT == 3) return launch_gemm_ring<3>(g, s);
