@@ -300,69 +300,271 @@ __global__ __launch_bounds__(256) void embed_step_kernel(const float *__restrict
   ((float4 *)(h + (size_t)r * D))[threadIdx.x] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 
-// h += sum_s part[s] + bias (when part != null), then xn = LayerNorm(h)*g + b. One block per row.
-__global__ __launch_bounds__(256) void reduce_ln_kernel(const float *__restrict__ part, int ks, int rows, const float *__restrict__ bias,
-                                                        float *__restrict__ h, const float *__restrict__ g, const float *__restrict__ b,
-                                                        float *__restrict__ xn) {
-  __shared__ float sh[4];
-  const size_t row = blockIdx.x;
-  float4 v = ((const float4 *)(h + row * D))[threadIdx.x];
-  if (part) {
-    // all partial loads are independent: issue them 8 at a time, add in s order (deterministic)
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s0 = 0; s0 < ks; s0 += 8) {
-      float4 p[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++)
-        p[u] = (s0 + u < ks) ? ((const float4 *)(part + ((size_t)(s0 + u) * rows + row) * D))[threadIdx.x] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int u = 0; u < 8; u++) { a.x += p[u].x; a.y += p[u].y; a.z += p[u].z; a.w += p[u].w; }
-    }
-    const float4 bi = ((const float4 *)bias)[threadIdx.x];
-    v.x += a.x + bi.x; v.y += a.y + bi.y; v.z += a.z + bi.z; v.w += a.w + bi.w;
-    ((float4 *)(h + row * D))[threadIdx.x] = v;
-  }
-  const float mean = block_sum_256(v.x + v.y + v.z + v.w, sh) * (1.0f / D);
-  v.x -= mean; v.y -= mean; v.z -= mean; v.w -= mean;
-  const float var = block_sum_256(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w, sh) * (1.0f / D);
-  const float sc = 1.0f / sqrtf(var + 1e-5f);
-  const float4 gg = ((const float4 *)g)[threadIdx.x], bb = ((const float4 *)b)[threadIdx.x];
-  v.x = v.x * sc * gg.x + bb.x; v.y = v.y * sc * gg.y + bb.y;
-  v.z = v.z * sc * gg.z + bb.z; v.w = v.w * sc * gg.w + bb.w;
-  ((float4 *)(xn + row * D))[threadIdx.x] = v;
+// ---- decode step: five launches per layer, no split-K partials ---------------------------------------
+// Every weight matrix is packed at load for the workgroup that streams it (one contiguous slab per
+// workgroup, every wave-level load instruction 1 KB of consecutive bytes) and every launch writes COMPLETE
+// outputs, so LayerNorm, bias, GELU, the fp16 rounding of QKV, the KV-cache append and the residual add all
+// live in the prologue/epilogue of the kernel that streams the weights:
+//   dec_ln_gemv<QKV>  : LN1(h) . c_attn -> q (fp32 of the fp16-rounded value), K/V appended to the fp16 cache
+//   attn_decode       : softmax(q.K/8).V over n_past+1 keys
+//   dec_gemv_resid<4> : h += att . c_proj + b
+//   dec_ln_gemv<GELU> : gelu(LN2(h) . c_fc + b) -> ff
+//   dec_gemv_resid<16>: h += ff . c_proj2 + b
+// and the head is dec_ln_gemv<LOGITS> (ln_f, lm_head LayerNorm, lm_head linear) straight to the logits.
+
+// K = 1024 GEMV with LayerNorm prologue for 16 candidates x 16 output columns per workgroup, on the fp32 MFMA
+// (v_mfma_f32_16x16x4_f32). Wave w covers k in [256w, 256w+256). Operands are fed swapped (A = weights,
+// B = activations) so that a lane ends with 4 consecutive output columns of one candidate. The 4 k values of
+// one MFMA are k0 + 4q + j for lane quarter q — a lane's activations are then one float4 of the natural
+// [row][k] layout; the weights are packed to match (pack_mfma16 below). LayerNorm is evaluated on the
+// register-resident operands: a row's 1024 values live in 4 lanes x 4 waves.
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+enum { DEC_QKV = 0, DEC_GELU = 1, DEC_LOGITS = 2 };
+#ifdef TTS_DEC_TRACE // developer build (tools/dec_bench.hip): phase timestamps of every workgroup
+__device__ long long tts_dec_trace[8 * 4096];
+#define DEC_T(i) do { if (threadIdx.x == 0) tts_dec_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define DEC_T(i)
+#endif
+struct DecLnArgs {
+  const float *h;            // [rows][1024]
+  const float *g1, *b1;      // DEC_LOGITS: ln_f (the LayerNorm feeding W is folded into W/bias at load)
+  const float *W;            // pack_mfma16 of diag(gamma) W
+  const float *bias;         // bias + beta . W
+  int rows, n_valid, ldo;
+  float *out;                // q [rows][1024] | ff [rows][4096] | logits [rows][ldo]
+  __half *kc, *vc;           // layer's caches [cand][max_pos][1024]
+  const StepState *ss;
+  int max_pos, lut;
+};
+
+// sum over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48): gfx950 half/row swap instructions
+__device__ __forceinline__ float rows4_sum(float x) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-// Decode attention for one (candidate, head): reduces the QKV split-K partials (+bias, fp16 round, as
-// main.cpp:2789-2790), appends K/V to the fp16 cache at position n_past, then softmax(q.K/8) V over
-// n_past+1 keys. 4 waves: keys are spread over all 256 threads for the scores and over 4 groups for PV.
-__global__ __launch_bounds__(256) void attn_decode_kernel(const float *__restrict__ part, int ks, int B, const float *__restrict__ bias,
-                                                          __half *__restrict__ kc, __half *__restrict__ vc,
-                                                          const StepState *__restrict__ ss, int max_pos, float *__restrict__ out, int lut) {
+// sred: two [4][16] arrays (one per pass, so each pass costs one barrier). g == nullptr: the affine part has
+// been folded into the weights/bias at load (fold_layernorm).
+__device__ __forceinline__ void dec_layernorm(float4 (&x)[16], const float *__restrict__ g, const float *__restrict__ b,
+                                              int koff, float (*sred)[4][16], int wave, int m) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; i++) s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+  sred[0][wave][m] = rows4_sum(s); // the 4 lanes of a row write the same value
+  __syncthreads();
+  const float mean = (((sred[0][0][m] + sred[0][1][m]) + sred[0][2][m]) + sred[0][3][m]) * (1.0f / D);
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    x[i].x -= mean; x[i].y -= mean; x[i].z -= mean; x[i].w -= mean;
+    ss += (x[i].x * x[i].x + x[i].y * x[i].y) + (x[i].z * x[i].z + x[i].w * x[i].w);
+  }
+  sred[1][wave][m] = rows4_sum(ss);
+  __syncthreads();
+  const float var = (((sred[1][0][m] + sred[1][1][m]) + sred[1][2][m]) + sred[1][3][m]) * (1.0f / D);
+  const float sc = 1.0f / sqrtf(var + 1e-5f);
+  if (g) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const float4 gg = *(const float4 *)(g + koff + i * 16), bb = *(const float4 *)(b + koff + i * 16);
+      x[i].x = x[i].x * sc * gg.x + bb.x; x[i].y = x[i].y * sc * gg.y + bb.y;
+      x[i].z = x[i].z * sc * gg.z + bb.z; x[i].w = x[i].w * sc * gg.w + bb.w;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; i++) { x[i].x *= sc; x[i].y *= sc; x[i].z *= sc; x[i].w *= sc; }
+  }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
+  __shared__ float sred[4][4][16];
+  __shared__ float4 accs[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, q = lane >> 4;
+  const int cb = blockIdx.x, row = blockIdx.y * 16 + m;
+  DEC_T(0);
+  // activations first (L2 hits), then the weight slab (HBM): vmcnt retires in order, so the LayerNorm runs on
+  // the activations while the 16 x 1 KB-per-wave weight loads are still streaming in
+  const int koff = wave * 256 + 4 * q;
+  float4 x[16];
+  {
+    // rows past the batch re-read the last candidate (branch-free); their results are never stored
+    const float *hp = a.h + (size_t)min(row, a.rows - 1) * D + koff;
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = *(const float4 *)(hp + i * 16);
+  }
+  float4 w[16];
+  {
+    const float4 *wp = (const float4 *)a.W + ((size_t)(cb * 4 + wave) * 16) * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i] = wp[i * 64];
+  }
+  DEC_T(1);
+  // the (last) LayerNorm's gamma/beta are folded into W/bias; the head's ln_f keeps its own
+  if (EPI == DEC_LOGITS) dec_layernorm(x, a.g1, a.b1, koff, sred, wave, m);
+  dec_layernorm(x, nullptr, nullptr, koff, sred + (EPI == DEC_LOGITS ? 2 : 0), wave, m);
+  DEC_T(2);
+  // four independent accumulator chains keep the fp32 MFMA pipe issue-bound instead of latency-bound
+  floatx4 ac0 = {0.f, 0.f, 0.f, 0.f}, ac1 = ac0, ac2 = ac0, ac3 = ac0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    ac0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, x[i].x, ac0, 0, 0, 0);
+    ac1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].y, x[i].y, ac1, 0, 0, 0);
+    ac2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, x[i].z, ac2, 0, 0, 0);
+    ac3 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, x[i].w, ac3, 0, 0, 0);
+  }
+  const floatx4 acc = (ac0 + ac1) + (ac2 + ac3);
+  DEC_T(3);
+  accs[wave][lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  __syncthreads();
+  DEC_T(4);
+  if (wave != 0 || row >= a.rows) return;
+  const float4 p0 = accs[0][lane], p1 = accs[1][lane], p2 = accs[2][lane], p3 = accs[3][lane];
+  const int col = cb * 16 + 4 * q; // lane: candidate `row`, columns col .. col+3
+  const float4 bi = *(const float4 *)(a.bias + col);
+  float4 v;
+  v.x = (((p0.x + p1.x) + p2.x) + p3.x) + bi.x; v.y = (((p0.y + p1.y) + p2.y) + p3.y) + bi.y;
+  v.z = (((p0.z + p1.z) + p2.z) + p3.z) + bi.z; v.w = (((p0.w + p1.w) + p2.w) + p3.w) + bi.w;
+  if (EPI == DEC_QKV) {
+    // QKV activations are rounded to fp16 (main.cpp:2789-2790)
+    const __half2 h01 = __floats2half2_rn(v.x, v.y), h23 = __floats2half2_rn(v.z, v.w);
+    const int sec = col >> 10, cc = col & (D - 1);
+    if (sec == 0) {
+      const float2 f01 = __half22float2(h01), f23 = __half22float2(h23);
+      *(float4 *)(a.out + (size_t)row * D + cc) = make_float4(f01.x, f01.y, f23.x, f23.y);
+    } else {
+      __half *dst = (sec == 1 ? a.kc : a.vc) + ((size_t)row * a.max_pos + a.ss->n_past) * D + cc;
+      uint2 u;
+      u.x = *(const unsigned *)&h01;
+      u.y = *(const unsigned *)&h23;
+      *(uint2 *)dst = u;
+    }
+  } else if (EPI == DEC_GELU) {
+    v.x = gelu_tanh(v.x, a.lut); v.y = gelu_tanh(v.y, a.lut); v.z = gelu_tanh(v.z, a.lut); v.w = gelu_tanh(v.w, a.lut);
+    *(float4 *)(a.out + (size_t)row * FF + col) = v;
+  } else {
+    float *o = a.out + (size_t)row * a.ldo + col;
+    if (col + 0 < a.n_valid) o[0] = v.x;
+    if (col + 1 < a.n_valid) o[1] = v.y;
+    if (col + 2 < a.n_valid) o[2] = v.z;
+    if (col + 3 < a.n_valid) o[3] = v.w;
+  }
+}
+
+// h[rows][1024] += X[rows][K] . W[K][1024] + bias, K = 1024 * KG. One workgroup owns 4 output columns over the
+// whole K (W packed by pack_cols4: 16 KB x KG contiguous per workgroup); thread t holds k = 1024 i + 4 t + kk.
+// The 64 per-thread sums (16 candidates x 4 columns) are reduced with a 6-step exchange butterfly that
+// leaves output t on lane t, then across the 4 waves through LDS — a fixed summation tree.
+template <int KG>
+__global__ __launch_bounds__(256) void dec_gemv_resid_kernel(const float *__restrict__ X, int rows, const float *__restrict__ W,
+                                                             const float *__restrict__ bias, float *__restrict__ h) {
+  constexpr int K = 1024 * KG;
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cb = blockIdx.x, row0 = blockIdx.y * 16;
+  DEC_T(0);
+  float4 xa0[8]; // candidates 0-7 of K group 0: requested before the weight stream
+#pragma unroll
+  for (int r = 0; r < 8; r++) xa0[r] = *(const float4 *)(X + (size_t)min(row0 + r, rows - 1) * K + 4 * tid);
+  float4 w[KG][4];
+  {
+    const float4 *wp = (const float4 *)W + (size_t)cb * KG * 1024 + tid;
+#pragma unroll
+    for (int i = 0; i < KG; i++)
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) w[i][kk] = wp[(i * 4 + kk) * 256];
+  }
+  // Activations (L2 hits) are fetched 8 candidates at a time, double-buffered against the FMAs; K group i of the
+  // weight slab is consumed for all 16 candidates as soon as it has arrived (vmcnt retires in order), so the
+  // FMAs of groups 0..KG-2 overlap the rest of the weight stream. Two columns per v_pk_fma_f32.
+  floatx2 acc[32];
+#pragma unroll
+  for (int j = 0; j < 32; j++) acc[j] = (floatx2){0.f, 0.f};
+  const float *xbase = X + 4 * tid;
+  int rowoff[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) rowoff[r] = min(row0 + r, rows - 1) * K; // rows past the batch re-read the last candidate
+  float4 xa[8], xb[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) { xa[r] = xa0[r]; xb[r] = *(const float4 *)(xbase + rowoff[8 + r]); }
+#pragma unroll
+  for (int i = 0; i < KG; i++) {
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      // half 0 consumes xa (candidates 0-7), half 1 consumes xb (8-15); the other buffer is refilled meanwhile
+      float4 (&cur)[8] = half ? xb : xa;
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const float xs[4] = {cur[r].x, cur[r].y, cur[r].z, cur[r].w};
+        floatx2 a01 = acc[(half * 8 + r) * 2], a23 = acc[(half * 8 + r) * 2 + 1];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          const floatx2 xx = {xs[kk], xs[kk]};
+          a01 = __builtin_elementwise_fma(xx, (floatx2){w[i][kk].x, w[i][kk].y}, a01);
+          a23 = __builtin_elementwise_fma(xx, (floatx2){w[i][kk].z, w[i][kk].w}, a23);
+        }
+        acc[(half * 8 + r) * 2] = a01; acc[(half * 8 + r) * 2 + 1] = a23;
+      }
+      if (i + 1 < KG) { // refill the buffer just consumed with the next K group
+#pragma unroll
+        for (int r = 0; r < 8; r++) cur[r] = *(const float4 *)(xbase + rowoff[half * 8 + r] + (i + 1) * 1024);
+      }
+    }
+  }
+  float v[64];
+#pragma unroll
+  for (int j = 0; j < 32; j++) { v[2 * j] = acc[j][0]; v[2 * j + 1] = acc[j][1]; }
+  DEC_T(1);
+  // exchange butterfly: after the step with lane mask M a lane keeps the half of its values selected by its
+  // bit M, summed with the partner lane's copy; 64 values -> 1, output index = lane.
+#pragma unroll
+  for (int i = 0; i < 32; i++) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 32]), false, false);
+    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
+    v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+#pragma unroll
+  for (int step = 2; step < 6; step++) {
+    const int mask = 32 >> step, n = 32 >> step;
+    const bool up = (lane & mask) != 0;
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+      const float send = up ? v[i] : v[i + n], keep = up ? v[i + n] : v[i];
+      v[i] = keep + __shfl_xor(send, mask);
+    }
+  }
+  DEC_T(2);
+  red[wave][lane] = v[0]; // output index = lane = 4 * candidate + column
+  __syncthreads();
+  DEC_T(3);
+  if (tid < 64) {
+    const int r = row0 + (tid >> 2), col = cb * 4 + (tid & 3);
+    if (r < rows) h[(size_t)r * D + col] += (((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid]) + bias[col];
+  }
+}
+
+// Decode attention for one (candidate, head): q is this step's (fp16-rounded) query, K/V of the new position
+// are already in the fp16 cache; softmax(q.K/8) V over n_past+1 keys. 4 waves: keys are spread over all 256
+// threads for the scores and over 16 groups for PV.
+__global__ __launch_bounds__(256) void attn_decode_kernel(const float *__restrict__ qbuf, const __half *__restrict__ kc,
+                                                          const __half *__restrict__ vc, const StepState *__restrict__ ss,
+                                                          int max_pos, float *__restrict__ out, int lut) {
   __shared__ float sc[1024];
   __shared__ float qs[HD];
   __shared__ float red[16 * HD];
   __shared__ float wred[8];
   const int c = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n_past = ss->n_past, nk = n_past + 1;
-  __half *kb = kc + (size_t)c * max_pos * D + h * HD;
-  __half *vb = vc + (size_t)c * max_pos * D + h * HD;
-  if (tid < 3 * HD) {
-    const int which = tid >> 6, d = tid & 63, n = which * D + h * HD + d;
-    float v = 0.f;
-    for (int s0 = 0; s0 < ks; s0 += 8) {
-      float p[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) p[u] = (s0 + u < ks) ? part[((size_t)(s0 + u) * B + c) * 3 * D + n] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; u++) v += p[u];
-    }
-    v += bias[n];
-    const __half hv = __float2half_rn(v);
-    if (which == 0) qs[d] = __half2float(hv);
-    else if (which == 1) kb[(size_t)n_past * D + d] = hv;
-    else vb[(size_t)n_past * D + d] = hv;
-  }
-  __threadfence_block();
+  const int nk = ss->n_past + 1;
+  const __half *kb = kc + (size_t)c * max_pos * D + h * HD;
+  const __half *vb = vc + (size_t)c * max_pos * D + h * HD;
+  if (tid < HD) qs[tid] = qbuf[(size_t)c * D + h * HD + tid];
   __syncthreads();
   float mx = -INFINITY;
   for (int j = tid; j < nk; j += 256) {
@@ -430,97 +632,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float *__restric
   }
 }
 
-// Decode GEMV (rows <= 16, one K span of NK*16 <= 256 per block): same split-K layout and summation order
-// as gemv_kn_kernel, but latency-oriented — every W load of the thread is issued before anything else,
-// the X staging loads are fully unrolled, and with PRO the c_fc epilogue (partial reduce + bias + GELU)
-// is evaluated while staging.
-template <int RT, int NK, int PRO>
-__global__ __launch_bounds__(256) void gemv_decode_kernel(const float *__restrict__ X, int ldx, int rows,
-                                                          const float *__restrict__ W, int N, int K, float *__restrict__ part,
-                                                          int pin_ks, const float *__restrict__ pin_bias, int lut) {
-  constexpr int KS = NK * 16;
-  __shared__ float xs[KS * RT];
-  __shared__ float red[4 * RT * 64];
-  const int tid = threadIdx.x, cx = tid & 15, ky = tid >> 4;
-  const int k0 = blockIdx.y * KS;
-  float4 w[NK];
-  {
-    const float *wp = W + ((size_t)blockIdx.x * K + k0 + ky) * 64 + cx * 4; // strip-major [N/64][K][64]
-#pragma unroll
-    for (int i = 0; i < NK; i++) w[i] = *(const float4 *)(wp + i * 16 * 64);
-  }
-  constexpr int PER = (KS * RT + 255) / 256;
-  float xv[PER];
-#pragma unroll
-  for (int it = 0; it < PER; it++) {
-    const int idx = tid + it * 256, r = idx / KS, k = idx % KS;
-    xv[it] = (idx < KS * RT && r < rows) ? X[(size_t)r * ldx + k0 + k] : 0.f;
-  }
-  if (PRO) {
-    // c_fc partials: all pin_ks x PER loads are independent -> issue them in groups of 8 splits
-    for (int sp0 = 1; sp0 < pin_ks; sp0 += 8) {
-      float pv[8][PER];
-#pragma unroll
-      for (int u = 0; u < 8; u++)
-#pragma unroll
-        for (int it = 0; it < PER; it++) {
-          const int idx = tid + it * 256, r = idx / KS, k = idx % KS, sp = sp0 + u;
-          pv[u][it] = (sp < pin_ks && idx < KS * RT && r < rows) ? X[((size_t)sp * rows + r) * ldx + k0 + k] : 0.f;
-        }
-#pragma unroll
-      for (int u = 0; u < 8; u++)
-#pragma unroll
-        for (int it = 0; it < PER; it++) xv[it] += pv[u][it];
-    }
-#pragma unroll
-    for (int it = 0; it < PER; it++) {
-      const int idx = tid + it * 256, k = idx % KS;
-      if (idx < KS * RT) xv[it] = gelu_tanh(xv[it] + pin_bias[k0 + k], lut);
-    }
-  }
-#pragma unroll
-  for (int it = 0; it < PER; it++) {
-    const int idx = tid + it * 256, r = idx / KS, k = idx % KS;
-    if (idx < KS * RT) xs[k * RT + r] = xv[it];
-  }
-  __syncthreads();
-  float acc[RT][4];
-#pragma unroll
-  for (int r = 0; r < RT; r++) { acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.f; }
-#pragma unroll
-  for (int i = 0; i < NK; i++) {
-    const int k = ky + i * 16;
-#pragma unroll
-    for (int r = 0; r < RT; r++) {
-      const float x = xs[k * RT + r];
-      acc[r][0] = fmaf(x, w[i].x, acc[r][0]); acc[r][1] = fmaf(x, w[i].y, acc[r][1]);
-      acc[r][2] = fmaf(x, w[i].z, acc[r][2]); acc[r][3] = fmaf(x, w[i].w, acc[r][3]);
-    }
-  }
-  const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int r = 0; r < RT; r++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      float v = acc[r][j];
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
-      if (lane < 16) red[(wave * RT + r) * 64 + cx * 4 + j] = v;
-    }
-  __syncthreads();
-  for (int idx = tid; idx < RT * 16; idx += 256) {
-    const int r = idx >> 4, c4 = idx & 15;
-    if (r < rows) {
-      float4 sres;
-      const float *p0 = &red[(0 * RT + r) * 64 + c4 * 4], *p1 = &red[(1 * RT + r) * 64 + c4 * 4];
-      const float *p2 = &red[(2 * RT + r) * 64 + c4 * 4], *p3 = &red[(3 * RT + r) * 64 + c4 * 4];
-      sres.x = ((p0[0] + p1[0]) + p2[0]) + p3[0]; sres.y = ((p0[1] + p1[1]) + p2[1]) + p3[1];
-      sres.z = ((p0[2] + p1[2]) + p2[2]) + p3[2]; sres.w = ((p0[3] + p1[3]) + p2[3]) + p3[3];
-      *(float4 *)&part[((size_t)blockIdx.y * rows + r) * N + blockIdx.x * 64 + c4 * 4] = sres;
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -528,6 +639,9 @@ struct ArLayerDev {
   float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
   float *w_attn, *b_attn, *w_proj, *b_proj, *w_fc, *b_fc, *w_fc2, *b_fc2;
   __half *s_attn = nullptr, *s_proj = nullptr, *s_fc = nullptr, *s_fc2 = nullptr; // [N][2K] hi|lo of 64*W^T
+  float *d_attn = nullptr, *d_fc = nullptr;   // pack_mfma16 of diag(ln gamma) W (decode step)
+  float *db_attn = nullptr, *db_fc = nullptr; // bias + ln beta . W
+  float *d_proj = nullptr, *d_fc2 = nullptr;  // pack_cols4  (decode step)
 };
 
 struct ArState {
@@ -535,7 +649,7 @@ struct ArState {
   std::vector<ArLayerDev> L;
   float *text_emb = nullptr, *text_pos = nullptr, *mel_emb = nullptr, *mel_pos = nullptr;
   float *lnf_g = nullptr, *lnf_b = nullptr, *lmh_g = nullptr, *lmh_b = nullptr;
-  float *lm_w = nullptr /*[1024][VPAD]*/, *lm_b = nullptr /*[VPAD]*/;
+  float *lm_w = nullptr /*[1024][VPAD] strip-major*/, *lm_b = nullptr /*[VPAD]*/, *d_lm = nullptr /*pack_mfma16, lm_head.0 folded*/, *d_lmb = nullptr;
   std::vector<void *> owned;
   // run state
   int B = 0, n_text = 0, P = 0, max_pos = 0;
@@ -543,7 +657,7 @@ struct ArState {
   DevBuf voice, kcache, vcache, lat_k, lat_v;
   DevBuf h, xn, qkv, att, ff, part, desc, logits, hn, a_hi, a_lo;
   // decode-step graph
-  DevBuf partA, partB, d_toks;
+  DevBuf d_toks;
   int32_t *h_toks = nullptr;   // pinned
   float *h_logits = nullptr;   // pinned [B][8194]
   hipGraph_t graph = nullptr;
@@ -581,6 +695,47 @@ static std::vector<float> strip_major(const float *w, int K, int N) {
   for (int s0 = 0; s0 < N / 64; s0++)
     for (int k = 0; k < K; k++) memcpy(&t[((size_t)s0 * K + k) * 64], &w[(size_t)k * N + s0 * 64], 64 * sizeof(float));
   return t;
+}
+
+// Decode-step layouts (w is [K][N], N contiguous).
+// pack_mfma16 (K = 1024): slab of workgroup cb (16 columns) = 4 waves x 16 groups x 64 lanes x float4, where lane
+// (m = lane & 15, q = lane >> 4) of wave wv holds W[256 wv + 16 g + 4 q + j][16 cb + m], j = 0..3, for group g.
+static std::vector<float> pack_mfma16(const float *w, int K, int N) {
+  std::vector<float> t((size_t)K * N);
+  for (int cb = 0; cb < N / 16; cb++)
+    for (int wv = 0; wv < 4; wv++)
+      for (int g = 0; g < 16; g++)
+        for (int lane = 0; lane < 64; lane++)
+          for (int j = 0; j < 4; j++)
+            t[((((size_t)cb * 4 + wv) * 16 + g) * 64 + lane) * 4 + j] =
+                w[(size_t)(wv * 256 + g * 16 + 4 * (lane >> 4) + j) * N + cb * 16 + (lane & 15)];
+  return t;
+}
+// pack_cols4 (K = 1024 KG): slab of workgroup cb (4 columns) = KG x 4 x 256 threads x float4 (the 4 columns),
+// thread t holding k = 1024 i + 4 t + kk.
+static std::vector<float> pack_cols4(const float *w, int K, int N) {
+  std::vector<float> t((size_t)K * N);
+  const int KG = K / 1024;
+  for (int cb = 0; cb < N / 4; cb++)
+    for (int i = 0; i < KG; i++)
+      for (int kk = 0; kk < 4; kk++)
+        for (int tid = 0; tid < 256; tid++)
+          memcpy(&t[((((size_t)cb * KG + i) * 4 + kk) * 256 + tid) * 4], &w[(size_t)(i * 1024 + 4 * tid + kk) * N + cb * 4], 16);
+  return t;
+}
+
+// LayerNorm affine folded into the matrix it feeds: (xhat*g + b) W + c = xhat (diag(g) W) + (b W + c).
+static void fold_layernorm(const float *w, int K, int N, const float *g, const float *b, const float *c,
+                           std::vector<float> &wf, std::vector<float> &cf) {
+  wf.resize((size_t)K * N);
+  std::vector<double> acc(N, 0.0);
+  for (int k = 0; k < K; k++)
+    for (int n = 0; n < N; n++) {
+      wf[(size_t)k * N + n] = g[k] * w[(size_t)k * N + n];
+      acc[n] += (double)b[k] * (double)w[(size_t)k * N + n];
+    }
+  cf.resize(N);
+  for (int n = 0; n < N; n++) cf[n] = (float)((double)c[n] + acc[n]);
 }
 
 static int fetch(tts_ctx *ctx, ArState *st, const WeightFile &wf, const std::string &name, int64_t ne0, int64_t ne1,
@@ -631,6 +786,18 @@ int ar_load(tts_ctx *ctx, const char *path) {
     FETCHT(p + ".attn.c_proj.weight", D, D, &l.w_proj); FETCH(p + ".attn.c_proj.bias", D, 1, &l.b_proj);
     FETCHT(p + ".mlp.c_fc.weight", FF, D, &l.w_fc); FETCH(p + ".mlp.c_fc.bias", FF, 1, &l.b_fc);
     FETCHT(p + ".mlp.c_proj.weight", D, FF, &l.w_fc2); FETCH(p + ".mlp.c_proj.bias", D, 1, &l.b_fc2);
+    int r;
+    std::vector<float> wfold, cfold;
+    fold_layernorm(wf.t.at(p + ".attn.c_attn.weight").data.data(), D, 3 * D, wf.t.at(p + ".ln_1.weight").data.data(),
+                   wf.t.at(p + ".ln_1.bias").data.data(), wf.t.at(p + ".attn.c_attn.bias").data.data(), wfold, cfold);
+    if ((r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, 3 * D), &l.d_attn))) return r;
+    if ((r = upload(ctx, st.get(), cfold, &l.db_attn))) return r;
+    fold_layernorm(wf.t.at(p + ".mlp.c_fc.weight").data.data(), D, FF, wf.t.at(p + ".ln_2.weight").data.data(),
+                   wf.t.at(p + ".ln_2.bias").data.data(), wf.t.at(p + ".mlp.c_fc.bias").data.data(), wfold, cfold);
+    if ((r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, FF), &l.d_fc))) return r;
+    if ((r = upload(ctx, st.get(), cfold, &l.db_fc))) return r;
+    if ((r = upload(ctx, st.get(), pack_cols4(wf.t.at(p + ".attn.c_proj.weight").data.data(), D, D), &l.d_proj))) return r;
+    if ((r = upload(ctx, st.get(), pack_cols4(wf.t.at(p + ".mlp.c_proj.weight").data.data(), FF, D), &l.d_fc2))) return r;
   }
 #undef FETCH
 #undef FETCHT
@@ -659,6 +826,13 @@ int ar_load(tts_ctx *ctx, const char *path) {
       for (int k = 0; k < D; k++) wt[(size_t)k * VPAD + n] = w[(size_t)n * D + k];
     std::copy(ib->second.data.begin(), ib->second.data.end(), bt.begin());
     int r = upload(ctx, st.get(), strip_major(wt.data(), D, VPAD), &st->lm_w); if (r) return r;
+    { // decode head: lm_head.0 LayerNorm folded into lm_head.1
+      std::vector<float> wfold, cfold;
+      fold_layernorm(wt.data(), D, VPAD, wf.t.at("inference_model.lm_head.0.weight").data.data(),
+                     wf.t.at("inference_model.lm_head.0.bias").data.data(), bt.data(), wfold, cfold);
+      r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, VPAD), &st->d_lm); if (r) return r;
+      r = upload(ctx, st.get(), cfold, &st->d_lmb); if (r) return r;
+    }
     r = upload(ctx, st.get(), bt, &st->lm_b); if (r) return r;
   }
   if (ctx->ar) ar_free(ctx->ar);
@@ -683,21 +857,6 @@ static int launch_gemv(tts_ctx *ctx, ArState *st, const float *X, int ldx, int r
   }
   dim3 grid(strips, ks, ztiles);
   ProfScope ps(ctx, "ar_gemv", (double)K * N * 4.0 * ztiles); // weight bytes streamed
-  if (ztiles == 1 && rows <= 16 && kchunk <= 256 && (kchunk == 32 || kchunk == 64 || kchunk == 128 || kchunk == 256)) {
-#define DEC_LAUNCH(NK_)                                                                                                      \
-  if (pin_ks > 0) gemv_decode_kernel<16, NK_, 1><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, K, part, pin_ks, pin_bias, ctx->ggml_lut); \
-  else gemv_decode_kernel<16, NK_, 0><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, K, part, 0, nullptr, 0)
-    switch (kchunk) {
-      case 32: DEC_LAUNCH(2); break;
-      case 64: DEC_LAUNCH(4); break;
-      case 128: DEC_LAUNCH(8); break;
-      default: DEC_LAUNCH(16); break;
-    }
-#undef DEC_LAUNCH
-    TTS_HIP(ctx, hipGetLastError());
-    *ks_out = ks;
-    return TTS_OK;
-  }
 #define GEMV_LAUNCH(RT_)                                                                                                   \
   if (pin_ks > 0) gemv_kn_kernel<RT_, 1><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, K, kchunk, part, pin_ks, pin_bias, ctx->ggml_lut); \
   else gemv_kn_kernel<RT_, 0><<<grid, 256, 0, ctx->stream>>>(X, ldx, rows, W, N, K, kchunk, part, 0, nullptr, 0)
@@ -839,9 +998,6 @@ int ar_begin(tts_ctx *ctx, const int32_t *text_ids, int n_text, const float *voi
   TTS_HIP(ctx, st->kcache.reserve(cache));
   TTS_HIP(ctx, st->vcache.reserve(cache));
   st->drop_graph(); // buffers may have moved
-  // split-K partials: ks * N <= 768 * 64 columns per row by construction of launch_gemv
-  TTS_HIP(ctx, st->partA.reserve((size_t)65536 * B * 4));
-  TTS_HIP(ctx, st->partB.reserve((size_t)65536 * B * 4));
   TTS_HIP(ctx, st->d_toks.reserve((size_t)(B + 2) * 4)); // [tokens | n_past, pos_id]
   TTS_HIP(ctx, st->logits.reserve((size_t)B * V * 4));
   if (st->h_toks) (void)hipHostFree(st->h_toks);
@@ -867,47 +1023,36 @@ int ar_prefill(tts_ctx *ctx, float *logits_out) {
   return head_logits(ctx, st, st->h.as<float>() + (size_t)(P - 1) * D, 1, logits_out, st->B);
 }
 
-// One decode step for all candidates, enqueued on the ctx stream (captured once into a hipGraph).
-// Per layer: reduce+LN1 | c_attn GEMV | attention (QKV reduce + KV append + softmax.V) | c_proj GEMV |
-// reduce+LN2 | c_fc GEMV | c_proj GEMV with fused bias+GELU prologue  -> 7 launches.
+// One decode step for all candidates, enqueued on the ctx stream (captured once into a hipGraph): five
+// launches per layer (see the kernels above) + embed + head; every launch streams its weights exactly once
+// per tile of 16 candidates.
 static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
-  const int B = st->B;
-  float *h = st->h.as<float>(), *xn = st->xn.as<float>(), *hn = st->hn.as<float>(), *att = st->att.as<float>();
-  float *pA = st->partA.as<float>(), *pB = st->partB.as<float>();
+  const int B = st->B, tiles = (B + 15) / 16;
+  float *h = st->h.as<float>(), *q = st->qkv.as<float>(), *att = st->att.as<float>(), *ff = st->ff.as<float>();
   const StepState *ss = (const StepState *)(st->d_toks.as<int>() + B);
   const size_t layer_stride = (size_t)B * st->max_pos * D;
   TTS_HIP(ctx, hipMemcpyAsync(st->d_toks.p, st->h_toks, (size_t)(B + 2) * 4, hipMemcpyHostToDevice, ctx->stream));
   embed_step_kernel<<<B, 256, 0, ctx->stream>>>(st->mel_emb, st->mel_pos, st->d_toks.as<int>(), ss, h);
-  int ks_prev = 0, ks;
-  const float *bias_prev = nullptr;
   for (int l = 0; l < st->n_layers; l++) {
     const ArLayerDev &w = st->L[l];
-    { ProfScope ps(ctx, "ar_reduce_ln");
-      reduce_ln_kernel<<<B, 256, 0, ctx->stream>>>(l ? pB : nullptr, ks_prev, B, bias_prev, h, w.ln1_g, w.ln1_b, xn); }
-    CHECK(launch_gemv(ctx, st, xn, D, B, w.w_attn, 3 * D, D, &ks, pA));
+    __half *kc = st->kcache.as<__half>() + l * layer_stride, *vc = st->vcache.as<__half>() + l * layer_stride;
+    { ProfScope ps(ctx, "ar_gemv", 3.0 * D * D * 4.0 * tiles);
+      DecLnArgs a{h, nullptr, nullptr, w.d_attn, w.db_attn, B, 3 * D, 0, q, kc, vc, ss, st->max_pos, ctx->ggml_lut};
+      dec_ln_gemv_kernel<DEC_QKV><<<dim3(3 * D / 16, tiles), 256, 0, ctx->stream>>>(a); }
     { ProfScope ps(ctx, "ar_attention");
-      attn_decode_kernel<<<dim3(B, NH), 256, 0, ctx->stream>>>(pA, ks, B, w.b_attn, st->kcache.as<__half>() + l * layer_stride,
-                                                               st->vcache.as<__half>() + l * layer_stride, ss, st->max_pos, att,
-                                                               ctx->ggml_lut); }
-    CHECK(launch_gemv(ctx, st, att, D, B, w.w_proj, D, D, &ks, pB));
-    { ProfScope ps(ctx, "ar_reduce_ln");
-      reduce_ln_kernel<<<B, 256, 0, ctx->stream>>>(pB, ks, B, w.b_proj, h, w.ln2_g, w.ln2_b, xn); }
-    CHECK(launch_gemv(ctx, st, xn, D, B, w.w_fc, FF, D, &ks, pA));
-    const int ks_fc = ks;
-    CHECK(launch_gemv(ctx, st, pA, FF, B, w.w_fc2, D, FF, &ks, pB, ks_fc, w.b_fc));
-    ks_prev = ks;
-    bias_prev = w.b_fc2;
+      attn_decode_kernel<<<dim3(B, NH), 256, 0, ctx->stream>>>(q, kc, vc, ss, st->max_pos, att, ctx->ggml_lut); }
+    { ProfScope ps(ctx, "ar_gemv", 1.0 * D * D * 4.0 * tiles);
+      dec_gemv_resid_kernel<1><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, w.d_proj, w.b_proj, h); }
+    { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * 4.0 * tiles);
+      DecLnArgs a{h, nullptr, nullptr, w.d_fc, w.db_fc, B, FF, 0, ff, nullptr, nullptr, ss, 0, ctx->ggml_lut};
+      dec_ln_gemv_kernel<DEC_GELU><<<dim3(FF / 16, tiles), 256, 0, ctx->stream>>>(a); }
+    { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * 4.0 * tiles);
+      dec_gemv_resid_kernel<4><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(ff, B, w.d_fc2, w.b_fc2, h); }
   }
-  { ProfScope ps(ctx, "ar_reduce_ln");
-    reduce_ln_kernel<<<B, 256, 0, ctx->stream>>>(pB, ks_prev, B, bias_prev, h, st->lnf_g, st->lnf_b, xn);
-    layernorm_kernel<<<B, 256, 0, ctx->stream>>>(xn, st->lmh_g, st->lmh_b, hn); }
-  CHECK(launch_gemv(ctx, st, hn, D, B, st->lm_w, VPAD, D, &ks, pA));
-  {
-    ProfScope ps(ctx, "ar_epilogue");
-    KvDst nokv{nullptr, nullptr, 1, 0, 0, 0};
-    epilogue_kernel<EPI_BIAS><<<dim3(B, (V + 255) / 256), 256, 0, ctx->stream>>>(pA, ks, B, VPAD, V, st->lm_b, st->logits.as<float>(), V,
-                                                                             nokv, 0, 1.0f);
-  }
+  { ProfScope ps(ctx, "ar_gemv", (double)D * VPAD * 4.0 * tiles);
+    DecLnArgs a{h, st->lnf_g, st->lnf_b, st->d_lm, st->d_lmb, B, V, V, st->logits.as<float>(),
+                nullptr, nullptr, ss, 0, ctx->ggml_lut};
+    dec_ln_gemv_kernel<DEC_LOGITS><<<dim3(VPAD / 16, tiles), 256, 0, ctx->stream>>>(a); }
   TTS_HIP(ctx, hipMemcpyAsync(st->h_logits, st->logits.p, (size_t)B * V * 4, hipMemcpyDeviceToHost, ctx->stream));
   TTS_HIP(ctx, hipGetLastError());
   return TTS_OK;
