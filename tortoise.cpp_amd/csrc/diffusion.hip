@@ -758,22 +758,96 @@ static int gn_stats(tts_ctx *ctx, const Layout &lay, Work &wk, const float *x) {
   TTS_HIP(ctx, hipGetLastError());
   return TTS_OK;
 }
+// Register-resident variant: one workgroup of NT threads = one (sequence, 32-channel group); the [T][32] slab
+// (T <= NJ * NT / 8 rows) is read from HBM exactly once into NJ float4 per thread, mean and centred variance are
+// reduced across the workgroup (two-pass on registers), and the normalised fp16 rows are written straight out.
+template <int NT, int NJ>
+__global__ __launch_bounds__(NT) void gn_reg_kernel(const float *__restrict__ x, const int *__restrict__ seq_start,
+                                                    const int *__restrict__ seq_len, int rows_total, int ns, float eps,
+                                                    const float *__restrict__ g, const float *__restrict__ b,
+                                                    const float *__restrict__ ss, int do_silu, int lut, __half *__restrict__ y) {
+  constexpr int NW = NT / 64, SWEEP = NT / 8;
+  __shared__ float sh[2][NW];
+  const int grp = blockIdx.x, s = blockIdx.y, T = seq_len[s], r0 = seq_start[s];
+  const int q = threadIdx.x & 7, c = grp * 32 + q * 4, t0 = threadIdx.x >> 3;
+  const float *base = x + (size_t)r0 * C + c;
+  float4 v[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const int t = t0 + j * SWEEP;
+    v[j] = *(const float4 *)(base + (size_t)min(t, T - 1) * C); // clamped rows are masked out of the sums below
+  }
+  const float4 gg = *(const float4 *)(g + c), bb = *(const float4 *)(b + c);
+  float sc4[4] = {1.f, 1.f, 1.f, 1.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ss) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) { sc4[i] = ss[c + i] + 1.0f; sh4[i] = ss[C + c + i]; }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+    if (t0 + j * SWEEP < T) sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  if ((threadIdx.x & 63) == 0) sh[0][threadIdx.x >> 6] = sum;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; w++) tot += sh[0][w];
+  const float n = (float)T * 32.f, mean = tot / n;
+  float sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+    if (t0 + j * SWEEP < T) sq += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  if ((threadIdx.x & 63) == 0) sh[1][threadIdx.x >> 6] = sq;
+  __syncthreads();
+  float tsq = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; w++) tsq += sh[1][w];
+  const float rstd = 1.0f / sqrtf(tsq / n + eps);
+  const float ge[4] = {gg.x, gg.y, gg.z, gg.w}, be[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const int t = t0 + j * SWEEP;
+    if (t < T) {
+      float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float u = e[i] * rstd;
+        u = u * ge[i];
+        u = u + be[i];
+        if (ss) { u = u * sc4[i]; u = u + sh4[i]; }
+        if (do_silu) u = silu_dev(u, lut);
+        e[i] = u;
+      }
+      const __half2 p0 = __floats2half2_rn(e[0], e[1]), p1 = __floats2half2_rn(e[2], e[3]);
+      uint2 o;
+      o.x = *(const unsigned *)&p0;
+      o.y = *(const unsigned *)&p1;
+      *(uint2 *)(y + (size_t)(r0 + t) * C + c) = o;
+    }
+  }
+  // zero the guard/padding rows that follow this sequence (and those before the first one)
+  const int gend = (s + 1 < ns) ? seq_start[s + 1] : rows_total;
+  for (int r = r0 + T + t0; r < gend; r += SWEEP) *(uint2 *)(y + (size_t)r * C + c) = make_uint2(0u, 0u);
+  if (s == 0)
+    for (int r = t0; r < r0; r += SWEEP) *(uint2 *)(y + (size_t)r * C + c) = make_uint2(0u, 0u);
+}
+
 // stats + apply in one launch (see gn_fused_kernel)
 static int gn_fused(tts_ctx *ctx, const Layout &lay, const float *x, const float *g, const float *b, const float *ss, int do_silu,
                     __half *y) {
   ProfScope ps(ctx, "diff_gn_fused");
-  const size_t slab = (size_t)lay.max_len() * 128;
-  static bool attr = false;
-  if (!attr) {
-    TTS_HIP(ctx, hipFuncSetAttribute((const void *)gn_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456));
-    attr = true;
-  }
-  if (slab <= 0) // LDS-resident slab measured slower (one workgroup per CU): 74.9 vs 58.6 us
-    gn_fused_kernel<1><<<dim3(32, lay.ns), 256, slab, ctx->stream>>>(x, lay.d_start.as<int>(), lay.d_len.as<int>(), lay.rows, lay.ns,
-                                                                     ctx->gn_eps, g, b, ss, do_silu, ctx->ggml_lut, y);
-  else
-    gn_fused_kernel<0><<<dim3(32, lay.ns), 256, 0, ctx->stream>>>(x, lay.d_start.as<int>(), lay.d_len.as<int>(), lay.rows, lay.ns,
-                                                                  ctx->gn_eps, g, b, ss, do_silu, ctx->ggml_lut, y);
+  const int tmax = lay.max_len();
+#define GN_ARGS x, lay.d_start.as<int>(), lay.d_len.as<int>(), lay.rows, lay.ns, ctx->gn_eps, g, b, ss, do_silu, ctx->ggml_lut, y
+  if (tmax <= 14 * 64) gn_reg_kernel<512, 14><<<dim3(32, lay.ns), 512, 0, ctx->stream>>>(GN_ARGS);
+  else if (tmax <= 18 * 128) gn_reg_kernel<1024, 18><<<dim3(32, lay.ns), 1024, 0, ctx->stream>>>(GN_ARGS);
+  else gn_fused_kernel<0><<<dim3(32, lay.ns), 256, 0, ctx->stream>>>(GN_ARGS); // two sweeps over global memory
+#undef GN_ARGS
   TTS_HIP(ctx, hipGetLastError());
   return TTS_OK;
 }
