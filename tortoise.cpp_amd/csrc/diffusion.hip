@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256) void to_f16_kernel(const float *__restrict__ x
 //  * the output is 4 consecutive channels per lane (8-byte stores).
 // bias = tab[(q<k)*64 + min(|k-q|,63)] (32-bucket table x8, expanded per distance at load time); blocks
 // of keys at least 63 away from every query of the wave use the saturated constant.
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int attn_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
 // all-reduce over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the gfx950 half/row swap
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256) void diff_attn_kernel(const __half *__restrict
   // ONE LDS object: with a second __shared__ variable hipcc puts an s_waitcnt vmcnt(0) in front of the first
   // ds_read of every tile, which drains the DMA prefetch (seen in the ISA; cdna_hip_programming.md §5 trap (a)).
   // (dynamic LDS: with a static array the DMA writes and the fragment reads alias for the waitcnt pass as well)
-  extern __shared__ __attribute__((aligned(16))) char smem[]; // 3-deep ring of (K tile 8 KB | V^T tile 8 KB) + bias table
+  extern __shared__ __attribute__((aligned(16))) char smem[]; // K ring 3 x 8 KB | V^T ring 3 x 8 KB | bias table
   float *tab = (float *)(smem + 3 * 16384);
   // XCD-aware block order: workgroup id b runs on XCD b % 8, so all q-blocks of one (sequence, head) pair
   // get ids congruent mod 8 and reuse that pair's K/V tiles from one L2 (16 heads => pairs % 8 == 0).
@@ -280,29 +281,30 @@ __global__ __launch_bounds__(256) void diff_attn_kernel(const __half *__restrict
   const int prow = lane >> 3, pslot = lane & 7;
   const __half *kbase = qk + (size_t)r0 * 2048 + h * 128 + 64;
   const __half *vbase = vt + (size_t)(h * 64) * ldvt + r0;
-  auto stage = [&](int kb, int buf) { // wave w moves rows w*16 .. w*16+15 of both tiles; swizzle on the source chunk
-    char *ks_ = smem + buf * 16384, *vs_ = ks_ + 8192;
+  // K and V^T tiles live in two separate 3-deep rings (K at smem + slot*8 KB, V^T at smem + 24 KB + slot*8 KB): the
+  // scores of tile kb+1 are issued to the matrix pipe BEFORE the softmax of tile kb (they overlap its VALU work),
+  // so K runs one tile ahead of V. Wave w moves rows w*16 .. w*16+15 of a tile; swizzle on the source chunk.
+  // Tile indices past the end are clamped (harmless re-stage) so that the vmcnt arithmetic stays uniform.
+  auto stageK = [&](int kb, int slot) {
+    kb = min(kb, nkb - 1);
+    char *ks_ = smem + slot * 8192;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int row = wave * 16 + i * 8 + prow, c = pslot ^ (row & 7);
       __builtin_amdgcn_global_load_lds((gptr_t)(kbase + (size_t)(kb * 64 + row) * 2048 + c * 8), (lptr_t)(ks_ + (wave * 2 + i) * 1024), 16, 0, 0);
+    }
+  };
+  auto stageV = [&](int kb, int slot) {
+    kb = min(kb, nkb - 1);
+    char *vs_ = smem + 24576 + slot * 8192;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int row = wave * 16 + i * 8 + prow, c = pslot ^ (row & 7);
       __builtin_amdgcn_global_load_lds((gptr_t)(vbase + (size_t)row * ldvt + kb * 64 + c * 8), (lptr_t)(vs_ + (wave * 2 + i) * 1024), 16, 0, 0);
     }
   };
-  stage(0, 0);
-  if (nkb > 1) stage(1, 1);
-  const float SC = 0.125f * L2E; // 1/sqrt(64) in log2 units
-  for (int kb = 0; kb < nkb; kb++) {
-    // Tile kb must have landed; the 4 DMA pieces of tile kb+1 may stay in flight across the barrier
-    // (counted vmcnt + raw s_barrier: __syncthreads() would drain the prefetch).
-    if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // every wave has passed the barrier => nobody still reads tile kb-1, whose slot receives tile kb+2
-    if (kb + 2 < nkb) stage(kb + 2, (kb + 2) % 3);
-    const char *Ks = smem + (kb % 3) * 16384, *Vs = Ks + 8192;
-    // S^T: sc[i][jt][r] = S[query i*16+fr][key kb*64 + jt*16 + fq*4 + r]
-    floatx4 sc[2][4];
+  // S^T of one key tile: sc[i][jt][r] = S[query i*16+fr][key jt*16 + fq*4 + r]
+  auto scores = [&](const char *Ks, floatx4 (&sc)[2][4]) {
 #pragma unroll
     for (int jt = 0; jt < 4; jt++) {
       const half8 kf0 = *(const half8 *)(Ks + attn_off(jt * 16 + fr, fq));
@@ -315,6 +317,27 @@ __global__ __launch_bounds__(256) void diff_attn_kernel(const __half *__restrict
         sc[i][jt] = a;
       }
     }
+  };
+  // issue order (2 DMA pieces per call): K0 | K1 V0 | K2 V1, then per tile kb: K(kb+3) V(kb+2)
+  stageK(0, 0);
+  stageK(1, 1); stageV(0, 0);
+  stageK(2, 2); stageV(1, 1);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); // K0 (this wave's pieces)
+  __builtin_amdgcn_s_barrier();
+  floatx4 sc[2][4], scn[2][4];
+  scores(smem, sc);
+  const float SC = 0.125f * L2E; // 1/sqrt(64) in log2 units
+  for (int kb = 0; kb < nkb; kb++) {
+    // K(kb+1) and V(kb) must have landed; the 4 pieces issued one tile ago (K(kb+2), V(kb+1)) may stay in flight
+    // across the barrier (counted vmcnt + raw s_barrier: __syncthreads() would drain the prefetch).
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // every wave has passed the barrier => nobody still reads K(kb) / V(kb-1): their slots take K(kb+3) / V(kb+2)
+    stageK(kb + 3, kb % 3);
+    stageV(kb + 2, (kb + 2) % 3);
+    const char *Vs = smem + 24576 + (kb % 3) * 8192;
+    // scores of the NEXT tile go to the matrix pipe now and are consumed one iteration later
+    if (kb + 1 < nkb) scores(smem + ((kb + 1) % 3) * 8192, scn);
     const int kmin = kb * 64;
     const bool far_hi = kmin - (qw + 31) >= 63, far_lo = qw - (kmin + 63) >= 63, tail = kmin + 64 > T;
     half8 pf[2][2]; // P^T in B-operand layout: slot e<4 -> key (2*ks2)*16+fq*4+e ; e>=4 -> key (2*ks2+1)*16+fq*4+e-4
@@ -374,15 +397,21 @@ __global__ __launch_bounds__(256) void diff_attn_kernel(const __half *__restrict
 #pragma unroll
       for (int dt = 0; dt < 4; dt++) {
         const int row = dt * 16 + fr;
-        const uint2 lo = *(const uint2 *)(Vs + attn_off(row, 4 * ks2 + (fq >> 1)) + (fq & 1) * 8);
-        const uint2 hi = *(const uint2 *)(Vs + attn_off(row, 4 * ks2 + 2 + (fq >> 1)) + (fq & 1) * 8);
-        uint4 both = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        const half8 vf = *(const half8 *)&both;
+        // _Float16-typed loads like the K fragments: with integer-typed (uint2) loads hipcc's waitcnt pass assumes
+        // they may alias the in-flight LDS-DMA and puts s_waitcnt vmcnt(0) in front of them (seen in the ISA)
+        const half4 lo = *(const half4 *)(Vs + attn_off(row, 4 * ks2 + (fq >> 1)) + (fq & 1) * 8);
+        const half4 hi = *(const half4 *)(Vs + attn_off(row, 4 * ks2 + 2 + (fq >> 1)) + (fq & 1) * 8);
+        const half8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
         for (int i = 0; i < 2; i++) o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[i][ks2], o[i][dt], 0, 0, 0);
       }
     }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int jt = 0; jt < 4; jt++) sc[i][jt] = scn[i][jt];
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // trailing (clamped) DMA pieces must land before the LDS is released
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     const int qi = qw + i * 16 + fr;
