@@ -223,6 +223,15 @@ __global__ __launch_bounds__(256) void to_f16_kernel(const float *__restrict__ x
 // bias = tab[(q<k)*64 + min(|k-q|,63)] (32-bucket table x8, expanded per distance at load time); blocks
 // of keys at least 63 away from every query of the wave use the saturated constant.
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+static constexpr int ATT_TAB = 320, ATT_LDS = 3 * 16384 + ATT_TAB * 4;
+#ifdef TTS_ATT_TRACE // developer build (tools/attn_bench.hip): per-tile phase timestamps of wave 0 of workgroup 0
+__device__ long long tts_att_trace[64 * 8];
+#define ATT_CLK(j) do { if (blockIdx.x == TTS_ATT_TRACE && threadIdx.x == 0) { tts_att_trace[63 * 8 + 2 * (j)] = __builtin_readcyclecounter(); tts_att_trace[63 * 8 + 2 * (j) + 1] = wall_clock64(); } } while (0)
+#define ATT_T(i) do { if (blockIdx.x == TTS_ATT_TRACE && threadIdx.x == 0 && kb < 64) tts_att_trace[kb * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ATT_T(i)
+#define ATT_CLK(j)
+#endif
 __device__ __forceinline__ int attn_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 7)) << 4); }
 
 // all-reduce over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48) with the gfx950 half/row swap
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(256) void diff_attn_kernel(const __half *__restrict
   // ONE LDS object: with a second __shared__ variable hipcc puts an s_waitcnt vmcnt(0) in front of the first
   // ds_read of every tile, which drains the DMA prefetch (seen in the ISA; cdna_hip_programming.md §5 trap (a)).
   // (dynamic LDS: with a static array the DMA writes and the fragment reads alias for the waitcnt pass as well)
-  extern __shared__ __attribute__((aligned(16))) char smem[]; // K ring 3 x 8 KB | V^T ring 3 x 8 KB | bias table
+  extern __shared__ __attribute__((aligned(16))) char smem[]; // 3 x (K tile 8 KB | V^T tile 8 KB) + bias table
   float *tab = (float *)(smem + 3 * 16384);
   // XCD-aware block order: workgroup id b runs on XCD b % 8, so all q-blocks of one (sequence, head) pair
   // get ids congruent mod 8 and reuse that pair's K/V tiles from one L2 (16 heads => pairs % 8 == 0).
@@ -256,7 +265,14 @@ __global__ __launch_bounds__(256) void diff_attn_kernel(const __half *__restrict
   if (q0 >= T) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
   const float L2E = 1.44269504088896f;
-  if (tid < 128) tab[tid] = bias_tab[h * 128 + tid] * L2E; // bias in log2 units (softmax via exp2)
+  // Bias by SIGNED key-query distance d in [-160, 160), saturated outside +-63, in raw-score units (added to q.k
+  // before the 1/8 * log2e scaling): a lane's 16 keys of a tile sit at compile-time offsets from one base distance,
+  // so the near-diagonal path is one LDS read at an immediate offset + one add per score.
+  const float SC = 0.125f * L2E; // 1/sqrt(64) in log2 units (softmax via exp2)
+  for (int j = tid; j < ATT_TAB; j += 256) {
+    const int d = j - ATT_TAB / 2, ad = d < 0 ? -d : d;
+    tab[j] = bias_tab[h * 128 + (d > 0 ? 64 : 0) + (ad < 63 ? ad : 63)] * (L2E / SC);
+  }
   const int qw = q0 + wave * 32;
   half8 qf[2][2]; // Q[query = qw + i*16 + fr][d = ks*32 + fq*8 ..+7]
 #pragma unroll
@@ -269,41 +285,45 @@ __global__ __launch_bounds__(256) void diff_attn_kernel(const __half *__restrict
   // K/V prefetch (seen in the ISA as `s_waitcnt vmcnt(0) lgkmcnt(0)` after the ds_reads).
   asm volatile("" ::"v"(qf[0][0]), "v"(qf[0][1]), "v"(qf[1][0]), "v"(qf[1][1]));
   floatx4 o[2][4]; // O^T[d = dt*16 + fq*4 + r][query = qw + i*16 + fr]
-  float mrow[2], lrow[2];
+  floatx4 lacc[2]; // row sums of P from the matrix pipe: (all-ones A tile) . P^T, every register = l[query fr]
+  float mrow[2];
 #pragma unroll
   for (int i = 0; i < 2; i++) {
 #pragma unroll
     for (int j = 0; j < 4; j++) o[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    lacc[i] = (floatx4){0.f, 0.f, 0.f, 0.f};
     mrow[i] = -INFINITY;
-    lrow[i] = 0.f;
   }
   const int nkb = (T + 63) >> 6;
   const int prow = lane >> 3, pslot = lane & 7;
   const __half *kbase = qk + (size_t)r0 * 2048 + h * 128 + 64;
   const __half *vbase = vt + (size_t)(h * 64) * ldvt + r0;
-  // K and V^T tiles live in two separate 3-deep rings (K at smem + slot*8 KB, V^T at smem + 24 KB + slot*8 KB): the
-  // scores of tile kb+1 are issued to the matrix pipe BEFORE the softmax of tile kb (they overlap its VALU work),
-  // so K runs one tile ahead of V. Wave w moves rows w*16 .. w*16+15 of a tile; swizzle on the source chunk.
+  // K and V^T tiles live in a 3-deep ring of (K 8 KB | V^T 8 KB) slots filled by LDS-DMA two tiles ahead.
+  // Wave w moves rows w*16 .. w*16+15 of both tiles; swizzle on the source chunk.
+  // The K tile is stored with its key rows permuted: LDS row jt*16 + x holds key SIG(jt, x) =
+  // (jt>>1)*32 + (x>>2)*8 + (jt&1)*4 + (x&3). The score accumulator (jt, fq, r) then belongs to key
+  // (jt>>1)*32 + fq*8 + (jt&1)*4 + r, so the 8 P values a lane feeds to PV step ks2 are the 8 CONSECUTIVE keys
+  // 32 ks2 + 8 fq .. +7 and its V^T fragment is one 16-byte LDS read (no half-fragment shuffles).
   // Tile indices past the end are clamped (harmless re-stage) so that the vmcnt arithmetic stays uniform.
-  auto stageK = [&](int kb, int slot) {
-    kb = min(kb, nkb - 1);
-    char *ks_ = smem + slot * 8192;
+  int koff[2], voff[2]; // per-lane source offsets (halves) inside a tile, fixed for the whole kernel
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int row = wave * 16 + i * 8 + prow, c = pslot ^ (row & 7);
-      __builtin_amdgcn_global_load_lds((gptr_t)(kbase + (size_t)(kb * 64 + row) * 2048 + c * 8), (lptr_t)(ks_ + (wave * 2 + i) * 1024), 16, 0, 0);
-    }
-  };
-  auto stageV = [&](int kb, int slot) {
+  for (int i = 0; i < 2; i++) {
+    const int row = wave * 16 + i * 8 + prow, c = pslot ^ (row & 7);
+    const int jt = row >> 4, x = row & 15;
+    const int key = (jt >> 1) * 32 + (x >> 2) * 8 + (jt & 1) * 4 + (x & 3);
+    koff[i] = key * 2048 + c * 8;
+    voff[i] = row * ldvt + c * 8;
+  }
+  auto stage = [&](int kb, int slot) {
     kb = min(kb, nkb - 1);
-    char *vs_ = smem + 24576 + slot * 8192;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int row = wave * 16 + i * 8 + prow, c = pslot ^ (row & 7);
-      __builtin_amdgcn_global_load_lds((gptr_t)(vbase + (size_t)row * ldvt + kb * 64 + c * 8), (lptr_t)(vs_ + (wave * 2 + i) * 1024), 16, 0, 0);
-    }
+    const __half *ksrc = kbase + (size_t)kb * (64 * 2048), *vsrc = vbase + kb * 64; // wave-uniform
+    char *ks_ = smem + slot * 16384 + wave * 2048, *vs_ = ks_ + 8192;
+    __builtin_amdgcn_global_load_lds((gptr_t)(ksrc + koff[0]), (lptr_t)ks_, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(ksrc + koff[1]), (lptr_t)(ks_ + 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(vsrc + voff[0]), (lptr_t)vs_, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(vsrc + voff[1]), (lptr_t)(vs_ + 1024), 16, 0, 0);
   };
-  // S^T of one key tile: sc[i][jt][r] = S[query i*16+fr][key jt*16 + fq*4 + r]
+  // S^T of one key tile: sc[i][jt][r] = S[query i*16+fr][key SIG(jt, fq*4 + r)]
   auto scores = [&](const char *Ks, floatx4 (&sc)[2][4]) {
 #pragma unroll
     for (int jt = 0; jt < 4; jt++) {
@@ -318,47 +338,70 @@ __global__ __launch_bounds__(256) void diff_attn_kernel(const __half *__restrict
       }
     }
   };
-  // issue order (2 DMA pieces per call): K0 | K1 V0 | K2 V1, then per tile kb: K(kb+3) V(kb+2)
-  stageK(0, 0);
-  stageK(1, 1); stageV(0, 0);
-  stageK(2, 2); stageV(1, 1);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); // K0 (this wave's pieces)
-  __builtin_amdgcn_s_barrier();
-  floatx4 sc[2][4], scn[2][4];
-  scores(smem, sc);
-  const float SC = 0.125f * L2E; // 1/sqrt(64) in log2 units
+  ATT_CLK(0);
+  stage(0, 0);
+  stage(1, 1);
+  half8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; e++) ones[e] = (_Float16)1.0f;
   for (int kb = 0; kb < nkb; kb++) {
-    // K(kb+1) and V(kb) must have landed; the 4 pieces issued one tile ago (K(kb+2), V(kb+1)) may stay in flight
-    // across the barrier (counted vmcnt + raw s_barrier: __syncthreads() would drain the prefetch).
+    // Tile kb must have landed; the 4 DMA pieces of tile kb+1 may stay in flight across the barrier
+    // (counted vmcnt + raw s_barrier: __syncthreads() would drain the prefetch).
+    ATT_T(0);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    ATT_T(1);
     __builtin_amdgcn_s_barrier();
-    // every wave has passed the barrier => nobody still reads K(kb) / V(kb-1): their slots take K(kb+3) / V(kb+2)
-    stageK(kb + 3, kb % 3);
-    stageV(kb + 2, (kb + 2) % 3);
-    const char *Vs = smem + 24576 + (kb % 3) * 8192;
-    // scores of the NEXT tile go to the matrix pipe now and are consumed one iteration later
-    if (kb + 1 < nkb) scores(smem + ((kb + 1) % 3) * 8192, scn);
+    ATT_T(2);
+    // every wave has passed the barrier => nobody still reads tile kb-1, whose slot receives tile kb+2
+    stage(kb + 2, (kb + 2) % 3);
+    const char *Ks = smem + (kb % 3) * 16384, *Vs = Ks + 8192;
+    ATT_T(3);
+    floatx4 sc[2][4];
+    scores(Ks, sc);
+    ATT_T(4);
     const int kmin = kb * 64;
     const bool far_hi = kmin - (qw + 31) >= 63, far_lo = qw - (kmin + 63) >= 63, tail = kmin + 64 > T;
-    half8 pf[2][2]; // P^T in B-operand layout: slot e<4 -> key (2*ks2)*16+fq*4+e ; e>=4 -> key (2*ks2+1)*16+fq*4+e-4
+    half8 pf[2][2]; // P^T in B-operand layout: slot e of step ks2 = key 32 ks2 + 8 fq + e
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int qi = qw + i * 16 + fr;
       float mx = -INFINITY, boff = 0.f; // v = sc*SC + bias; far tiles: bias is one constant (folded below)
       if ((far_hi || far_lo) && !tail) {
-        boff = far_hi ? tab[64 + 63] : tab[63];
+        boff = (far_hi ? tab[ATT_TAB / 2 + 63] : tab[ATT_TAB / 2 - 63]) * SC;
 #pragma unroll
-        for (int jt = 0; jt < 4; jt++) mx = fmaxf(mx, fmaxf(fmaxf(sc[i][jt][0], sc[i][jt][1]), fmaxf(sc[i][jt][2], sc[i][jt][3])));
+        for (int jt = 0; jt < 4; jt++) { // two v_max3 per accumulator register quad
+          mx = fmaxf(fmaxf(mx, sc[i][jt][0]), sc[i][jt][1]);
+          mx = fmaxf(fmaxf(mx, sc[i][jt][2]), sc[i][jt][3]);
+        }
         mx = fmaf(mx, SC, boff);
-      } else {
+      } else if (!tail) {
+        // key of (jt, r) = kmin + fq*8 + off, off = (jt>>1)*32 + (jt&1)*4 + r  =>  d = (kmin + fq*8 - qi) + off
+        const float *tp = tab + (kmin + fq * 8 - qi + ATT_TAB / 2); // in range: |d| < 160 on near-diagonal tiles
 #pragma unroll
         for (int jt = 0; jt < 4; jt++)
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            const int ki = kmin + jt * 16 + fq * 4 + r;
-            const int d = ki - qi, ad = d < 0 ? -d : d;
-            float v = sc[i][jt][r] + tab[(d > 0 ? 64 : 0) + (ad < 63 ? ad : 63)] * (1.0f / SC); // keep sc in raw units
-            v = (ki < T) ? v : -INFINITY;
+            const float v = sc[i][jt][r] + tp[(jt >> 1) * 32 + (jt & 1) * 4 + r];
+            sc[i][jt][r] = v;
+            mx = fmaxf(mx, v);
+          }
+        mx *= SC;
+      } else { // last tile of the sequence: keys >= T are masked
+        const int left = T - kmin - fq * 8; // keys of this lane with off < left exist
+        const bool far = far_hi || far_lo;  // then the bias is one constant (and the table base would be out of range)
+        const float cb = far_hi ? tab[ATT_TAB / 2 + 63] : tab[ATT_TAB / 2 - 63];
+        const float *tp = tab + (far ? 0 : kmin + fq * 8 - qi + ATT_TAB / 2);
+        float bv[4][4]; // all table reads first, unconditionally (a load under a per-element select is branched around)
+#pragma unroll
+        for (int jt = 0; jt < 4; jt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) bv[jt][r] = tp[(jt >> 1) * 32 + (jt & 1) * 4 + r];
+#pragma unroll
+        for (int jt = 0; jt < 4; jt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int off = (jt >> 1) * 32 + (jt & 1) * 4 + r;
+            const float v = off < left ? sc[i][jt][r] + (far ? cb : bv[jt][r]) : -INFINITY;
             sc[i][jt][r] = v;
             mx = fmaxf(mx, v);
           }
@@ -368,50 +411,39 @@ __global__ __launch_bounds__(256) void diff_attn_kernel(const __half *__restrict
       const float mnew = fmaxf(mrow[i], mx);
       const float alpha = __builtin_amdgcn_exp2f(mrow[i] - mnew);
       const float sub = boff - mnew; // p = 2^(sc*SC + bias - mnew)
-      float sum = 0.f;
-#pragma unroll
-      for (int jt = 0; jt < 4; jt++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(sc[i][jt][r], SC, sub));
-          sc[i][jt][r] = pv;
-          sum += pv;
-        }
-      sum = rows4_sum(sum);
-      lrow[i] = lrow[i] * alpha + sum;
       mrow[i] = mnew;
       if (!__all(alpha == 1.0f)) { // the running max settles after the first tiles: usually nothing to rescale
 #pragma unroll
         for (int dt = 0; dt < 4; dt++)
 #pragma unroll
           for (int r = 0; r < 4; r++) o[i][dt][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 4; r++) lacc[i][r] *= alpha;
       }
 #pragma unroll
       for (int ks2 = 0; ks2 < 2; ks2++)
 #pragma unroll
-        for (int e = 0; e < 8; e++) pf[i][ks2][e] = (_Float16)sc[i][2 * ks2 + (e >> 2)][e & 3];
+        for (int e = 0; e < 8; e++)
+          pf[i][ks2][e] = (_Float16)__builtin_amdgcn_exp2f(fmaf(sc[i][2 * ks2 + (e >> 2)][e & 3], SC, sub));
     }
-    // O^T += V^T P^T : A = V^T[d = dt*16 + fr][key slots of this lane group], B = P^T
+    ATT_T(5);
+    // O^T += V^T P^T : A = V^T[d = dt*16 + fr][keys 32 ks2 + 8 fq ..+7], B = P^T; row sums: A = ones
 #pragma unroll
     for (int ks2 = 0; ks2 < 2; ks2++) {
 #pragma unroll
       for (int dt = 0; dt < 4; dt++) {
-        const int row = dt * 16 + fr;
-        // _Float16-typed loads like the K fragments: with integer-typed (uint2) loads hipcc's waitcnt pass assumes
-        // they may alias the in-flight LDS-DMA and puts s_waitcnt vmcnt(0) in front of them (seen in the ISA)
-        const half4 lo = *(const half4 *)(Vs + attn_off(row, 4 * ks2 + (fq >> 1)) + (fq & 1) * 8);
-        const half4 hi = *(const half4 *)(Vs + attn_off(row, 4 * ks2 + 2 + (fq >> 1)) + (fq & 1) * 8);
-        const half8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        const half8 vf = *(const half8 *)(Vs + attn_off(dt * 16 + fr, 4 * ks2 + fq));
 #pragma unroll
         for (int i = 0; i < 2; i++) o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[i][ks2], o[i][dt], 0, 0, 0);
       }
+#pragma unroll
+      for (int i = 0; i < 2; i++) lacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[i][ks2], lacc[i], 0, 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int jt = 0; jt < 4; jt++) sc[i][jt] = scn[i][jt];
+    ATT_T(6);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // trailing (clamped) DMA pieces must land before the LDS is released
+  ATT_CLK(1);
+  float lrow[2] = {lacc[0][0], lacc[1][0]};
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     const int qi = qw + i * 16 + fr;
@@ -892,7 +924,7 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
     for (int l : lay.len) aw += 4.0 * l * (double)l * 64 * NHEAD; // QK^T + PV
     ProfScope ps(ctx, "diff_attn", aw);
     const int nq = (lay.max_len() + 127) / 128;
-    diff_attn_kernel<<<nq * NHEAD * lay.ns, 256, 3 * 16384 + 512, ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128,
+    diff_attn_kernel<<<nq * NHEAD * lay.ns, 256, ATT_LDS, ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128,
                                                                    lay.d_start.as<int>(), lay.d_len.as<int>(), w.bias_tab, wk.ATT16(), nq);
     TTS_HIP(ctx, hipGetLastError());
   }
