@@ -318,6 +318,99 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g
   gemm_epilogue<MODE>(g, acc, m0, n0, wm, wn, fr, fq);
 }
 
+// k = 3 convolution as ONE GEMM with a shared activation slab. The three taps are three row-shifted GEMM
+// segments over the SAME activation rows (row_off = -1, 0, +1), so per 64-channel chunk the kernel stages the
+// 130 (136) activation rows m0-1 .. once and multiplies them three times, each time against that tap's weight
+// tile and read from LDS one row further down. Operand traffic through the CU's load path per chunk:
+// 17 + 3 x 16 = 65 DMA pieces instead of 3 x 32 = 96 — the 128^2 tile is bound by exactly that path
+// (64 B/clk/CU feeds at most one 32 KB K tile per 512 MFMA cycles).
+// The weight tiles alternate between two LDS buffers: tap p+1's tile is requested before tap p's is waited for
+// (counted vmcnt + raw barrier), so only the slab load at the start of a chunk is exposed.
+static constexpr int CONV3_LDS = 17408 + 2 * 16384;
+template <int MODE>
+static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[]; // A slab 136 rows | B tile x 2
+  char *smem = smem_dyn;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int MT = g.M >> 7, NT = g.N >> 7;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int mq = MT >> 3, mr = MT & 7;
+  const int mcount = mq + (xcd < mr ? 1 : 0), mfirst = xcd * mq + (xcd < mr ? xcd : mr);
+  if (idx >= mcount * NT) return;
+  const int cn = g.cn > 0 ? g.cn : NT, per_chunk = mcount * cn;
+  const int chunk = idx / per_chunk, rem = idx - chunk * per_chunk;
+  const int m0 = (mfirst + rem / cn) << 7, n0 = (chunk * cn + rem % cn) << 7;
+  const int nchunks = g.kseg >> 6, ldw = 3 * g.kseg, nph = 3 * nchunks;
+  const int prow = lane >> 3, pslot = lane & 7;
+  floatx4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  const int fr = lane & 15, fq = lane >> 4;
+  char *sa = smem, *sb = smem + 17408;
+  // slab row s = activation row m0 - 1 + s (the buffer has its guard rows, as for the plain segments)
+  const __half *abase = g.A[0] + (ptrdiff_t)(m0 - 1) * g.lda;
+  const __half *wbase = g.W + (size_t)n0 * ldw;
+  int aoff[5], boff[4];
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    const int row = (i < 4 ? wave * 4 + i : 16) * 8 + prow;
+    const int c = pslot ^ ((row >> 1) & 7);
+    aoff[i] = min(row, g.M - m0 + 1) * g.lda + c * 8; // rows past the buffer end are never multiplied: clamp
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = (wave * 4 + i) * 8 + prow;
+    const int c = pslot ^ ((row >> 1) & 7);
+    boff[i] = row * ldw + c * 8;
+  }
+  auto stageA = [&](int kc) {
+    const __half *src = abase + (min(kc, nchunks - 1) << 6);
+#pragma unroll
+    for (int i = 0; i < 4; i++) __builtin_amdgcn_global_load_lds((gptr_t)(src + aoff[i]), (lptr_t)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
+    if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(src + aoff[4]), (lptr_t)(sa + 16 * 1024), 16, 0, 0);
+  };
+  auto stageB = [&](int p) { // phase p = chunk p / 3, tap p % 3 (clamped past the end: uniform vmcnt arithmetic)
+    p = min(p, nph - 1);
+    const int kc = p / 3, tap = p - kc * 3;
+    const __half *src = wbase + tap * g.kseg + (kc << 6);
+    char *dst = sb + (p & 1) * 16384;
+#pragma unroll
+    for (int i = 0; i < 4; i++) __builtin_amdgcn_global_load_lds((gptr_t)(src + boff[i]), (lptr_t)(dst + (wave * 4 + i) * 1024), 16, 0, 0);
+  };
+  stageA(0);
+  stageB(0);
+  for (int kc = 0, p = 0; kc < nchunks; kc++) {
+#pragma unroll
+    for (int tap = 0; tap < 3; tap++, p++) {
+      stageB(p + 1); // its buffer was last read in phase p-1, which every wave has left (trailing barrier)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // all but the 4 pieces just issued: B(p) and the slab have landed
+      __builtin_amdgcn_s_barrier();
+      const char *sbp = sb + (p & 1) * 16384;
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        half8 af[4], bf[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          af[i] = *(const half8 *)(sa + lds_off(wm * 64 + i * 16 + fr + tap, ks * 4 + fq));
+          bf[i] = *(const half8 *)(sbp + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier(); // every wave is done reading the slab and B(p)
+      if (tap == 2) stageA(kc + 1);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // trailing (clamped) pieces must land before the LDS is released
+  gemm_epilogue<MODE>(g, acc, m0, n0, wm, wn, fr, fq);
+}
+
 // Variant 2/3: NST-deep LDS ring (NST x 32 KB, dynamic LDS). Tile kt+NST-1 is requested while tile kt is
 // multiplied; DMA pieces stay in flight across the (raw) barrier and are retired with a counted vmcnt.
 template <int MODE, int NST>
@@ -867,7 +960,13 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
   if (TTS_GEMM_VARIANT == 4) return launch_gemm_big(g, s);
   if (TTS_GEMM_VARIANT == 2) return launch_gemm_ring<2>(g, s);
   if (TTS_GEMM_VARIANT == 3) return launch_gemm_ring<3>(g, s);
+  // k = 3 convolution (three row-shifted segments of one activation buffer, tap-major weights): shared-slab kernel
+  static const bool no_conv3 = getenv("TTS_GEMM_NOCONV3") != nullptr; // A/B switch for tools/gemm_bench
+  const bool conv3 = !no_conv3 && g.nseg == 3 && !g.custom_w && g.A[0] == g.A[1] && g.A[1] == g.A[2] && g.row_off[0] == -1 &&
+                     g.row_off[1] == 0 && g.row_off[2] == 1 && g.mode != GEMM_OUT_QKV;
   if (TTS_GEMM_VARIANT == 0) gemm_f16_kernel<<<ntiles, 256, 65536, s>>>(g);
+  else if (conv3 && g.mode == GEMM_OUT_F32) gemm_f16_conv3_kernel<GEMM_OUT_F32><<<grid1, 256, CONV3_LDS, s>>>(gg);
+  else if (conv3) gemm_f16_conv3_kernel<GEMM_OUT_F16><<<grid1, 256, CONV3_LDS, s>>>(gg);
   else if (g.mode == GEMM_OUT_F32) gemm_f16_glds_kernel<GEMM_OUT_F32><<<grid1, 256, 0, s>>>(gg);
   else if (g.mode == GEMM_OUT_F16) gemm_f16_glds_kernel<GEMM_OUT_F16><<<grid1, 256, 0, s>>>(gg);
   else gemm_f16_glds_kernel<GEMM_OUT_QKV><<<grid1, 256, 0, s>>>(gg);
