@@ -1,0 +1,62 @@
+"""Turn raw rocprofv3 output (under gpurun_out/) into the small summaries committed under profiles/.
+
+    python tools/summarize_profiles.py stats  <kernel_stats.csv> <out.csv> "<command line that was profiled>"
+    python tools/summarize_profiles.py pmc    <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> "<note>"
+
+The commands that produce the inputs (on the GPU box):
+    cd /tmp && export TMPDIR=/tmp
+    TTS_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_e2e -o e2e -- python $R/tools/e2e_once.py 80
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o f -- python $R/tools/diff_prof.py 2
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o w -- python $R/tools/diff_prof.py 2
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    return name if len(name) <= 90 else name[:90]
+
+
+def stats(src, dst, cmd):
+    rows = list(csv.DictReader(open(src)))
+    total = sum(float(r["TotalDurationNs"]) for r in rows)
+    rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
+    with open(dst, "w") as f:
+        f.write("# %s\n# total kernel time %.1f ms\nkernel,calls,total_ms,avg_us,pct\n" % (cmd, total / 1e6))
+        for r in rows[:40]:
+            t = float(r["TotalDurationNs"])
+            f.write('"%s",%s,%.2f,%.2f,%.2f\n' % (short(r["Name"]), r["Calls"], t / 1e6, float(r["AverageNs"]) / 1e3, 100 * t / total))
+
+
+def counter_avg(path, counter):
+    acc = defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        a = acc[r["Kernel_Name"]]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    return {k: (n, s / n) for k, (n, s) in acc.items()}
+
+
+def pmc(fetch_csv, write_csv, dst, note):
+    fe, wr = counter_avg(fetch_csv, "FETCH_SIZE"), counter_avg(write_csv, "WRITE_SIZE")
+    out = {"_note": note, "kernels": {}}
+    for k, (n, f) in sorted(fe.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+        if not k.startswith(("void tts::", "tts::")):
+            continue
+        w = wr.get(k, (0, 0.0))[1]
+        out["kernels"][short(k)] = {"dispatches": n, "fetch_KiB": round(f, 1), "write_KiB": round(w, 1),
+                                    "hbm_bytes_per_launch": int((f + w) * 1024)}
+    json.dump(out, open(dst, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(*sys.argv[2:5])
+    elif sys.argv[1] == "pmc":
+        pmc(*sys.argv[2:6])
+    else:
+        sys.exit(__doc__)
