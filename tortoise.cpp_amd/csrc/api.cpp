@@ -55,6 +55,7 @@ tts_ctx *tts_create(int device) {
 
 void tts_destroy(tts_ctx *c) {
   if (!c) return;
+  if (c->sampler_pool) sampler_pool_free(c->sampler_pool);
   if (c->device < 0) { delete c->tok; delete c; return; }
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);

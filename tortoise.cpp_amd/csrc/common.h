@@ -53,6 +53,8 @@ struct ArState;
 struct DiffState;
 struct VocState;
 struct Tokenizer;
+struct SamplerPool;
+void sampler_pool_free(SamplerPool *p);
 
 } // namespace tts
 
@@ -73,6 +75,7 @@ struct tts_ctx {
   tts::DiffState *diff = nullptr;
   tts::VocState *voc = nullptr;
   tts::Tokenizer *tok = nullptr;
+  tts::SamplerPool *sampler_pool = nullptr; // worker threads for the per-candidate sampler scans (host_logic.cpp)
   // profiling: per kernel family, HIP event pairs recorded on the ctx stream around every launch and
   // resolved lazily (no host sync inside the timed region)
   bool prof_on = false;

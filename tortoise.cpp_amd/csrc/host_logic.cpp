@@ -2,6 +2,12 @@
 // sequence bookkeeping, WAV writer. Reference behaviour is cited per function (file:line in
 // /root/reference); tests/test_host_parity.py checks each against the real reference code.
 #include "common.h"
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <algorithm>
 #include <cmath>
 #include <fstream>
@@ -183,103 +189,170 @@ static int multinomial_literal(std::vector<float> &l, float sample) {
   return V - 1;
 }
 
-void sample_candidates(tts_ctx *ctx, const float *logits, const int32_t *ids, int ids_per_cand, int B,
-                       int32_t *out) {
+// One candidate, given its uniform draw: pure function of its arguments (runs on the sampler pool's threads).
+static int sample_one(const float *src, const int32_t *ids, int ids_per_cand, float sample) {
   const int V = TTS_VOCAB_MEL, TOPK = 50;
   const float LOWEST = std::numeric_limits<float>::lowest();
   const float temp = 0.8;
   struct Surv { float v; int idx; float e; };
-  std::vector<Surv> s, asc;
-  std::vector<float> l; // only materialised for the (rare) literal fallback
-  for (int c = 0; c < B; c++) {
-    const float *src = logits + (size_t)c * V;
-    // gather -> apply_penalty(2.0) -> scatter touches at most a few distinct ids (the prompt-shaped
-    // [1 ... 1, 8192] at step 0, the previous sample afterwards): keep them as overrides
-    int pid[4]; float pval[4]; int np = 0;
-    bool many = false;
+  thread_local std::vector<Surv> s, asc;
+  thread_local std::vector<float> l; // only materialised for the (rare) literal fallback
+  // gather -> apply_penalty(2.0) -> scatter touches at most a few distinct ids (the prompt-shaped
+  // [1 ... 1, 8192] at step 0, the previous sample afterwards): keep them as overrides
+  int pid[4]; float pval[4]; int np = 0;
+  bool many = false;
+  for (int j = 0; j < ids_per_cand; j++) {
+    const int id = ids[j];
+    bool seen = false;
+    for (int q = 0; q < np; q++) seen |= (pid[q] == id);
+    if (seen) continue;
+    if (np == 4) { many = true; break; }
+    const float g = src[id];
+    pid[np] = id; pval[np] = (g < 0) ? g * 2.0f : g / 2.0f; np++;
+  }
+  auto literal = [&]() {
+    l.assign(src, src + V);
     for (int j = 0; j < ids_per_cand; j++) {
-      const int id = ids[(size_t)c * ids_per_cand + j];
-      bool seen = false;
-      for (int q = 0; q < np; q++) seen |= (pid[q] == id);
-      if (seen) continue;
-      if (np == 4) { many = true; break; }
+      const int id = ids[j];
       const float g = src[id];
-      pid[np] = id; pval[np] = (g < 0) ? g * 2.0f : g / 2.0f; np++;
+      l[id] = (g < 0) ? g * 2.0f : g / 2.0f;
     }
+    for (int i = 0; i < V; i++) l[i] /= temp;
+    std::vector<float> tmp(l);
+    std::nth_element(tmp.begin(), tmp.begin() + (V - TOPK), tmp.end());
+    const float kth = tmp[V - TOPK];
+    for (int i = 0; i < V; i++) if (l[i] < kth) l[i] = LOWEST;
+    return multinomial_literal(l, sample);
+  };
+  if (many) return literal();
+  auto val = [&](int i) { for (int q = 0; q < np; q++) if (pid[q] == i) return pval[q]; return src[i]; };
+  // k-th largest penalised logit: min-heap of the 50 largest seen so far (almost every element fails
+  // the single compare against the heap minimum)
+  float heap[TOPK];
+  for (int i = 0; i < TOPK; i++) heap[i] = val(i);
+  std::make_heap(heap, heap + TOPK, std::greater<float>());
+  float hmin = heap[0];
+  for (int i = TOPK; i < V; i++) {
+    float x = src[i];
+    if (x <= hmin) continue;              // (penalised values are <= their source unless negative*2, handled by val)
+    x = val(i);
+    if (x <= hmin) continue;
+    std::pop_heap(heap, heap + TOPK, std::greater<float>());
+    heap[TOPK - 1] = x;
+    std::push_heap(heap, heap + TOPK, std::greater<float>());
+    hmin = heap[0];
+  }
+  // a penalised NEGATIVE logit is x*2 < x, a positive one x/2 < x: overrides never exceed src, so the scan
+  // above cannot miss them. Threshold on the tempered values: ties (also those created by the division's
+  // rounding: at most two adjacent floats share a quotient) survive, as in val_where_below_thresh.
+  const float kth = hmin / temp;
+  float cut = hmin;
+  for (int q = 0; q < 4; q++) cut = std::nextafter(cut, LOWEST);
+  s.clear();
+  for (int i = 0; i < V; i++) {
+    if (src[i] < cut) continue;
+    const float v = val(i) / temp;
+    if (v >= kth) s.push_back({v, i, 0.f});
+  }
+  asc = s;
+  std::sort(asc.begin(), asc.end(), [](const Surv &a, const Surv &b) { return a.v < b.v; });
+  bool tie = false;
+  for (size_t i = 1; i < asc.size(); i++) tie |= (asc[i].v == asc[i - 1].v);
+  if (tie) return literal(); // inherit std::sort's tie order from the literal formulation
+  // top-p over the ascending survivors (non-survivors contribute exp(lowest) = +0)
+  float sum = 0;
+  for (auto &a : asc) { a.e = exp_like_reference(a.v); sum += a.e; }
+  float cum = 0;
+  // final softmax + multinomial in index order
+  for (size_t i = 0; i < asc.size(); i++) {
+    cum += asc[i].e / sum;
+    if (i + 1 < asc.size() && cum <= 0.2)
+      for (auto &b : s) if (b.idx == asc[i].idx) b.v = LOWEST; // cut
+  }
+  sum = 0;
+  for (auto &a : s) { a.e = (a.v == LOWEST) ? 0.f : exp_like_reference(a.v); sum += a.e; }
+  int pick = V - 1;
+  if (!(0.0f < sample)) pick = 0; // cumulative(=0) >= sample already at index 0
+  else {
+    cum = 0;
+    for (auto &a : s) {
+      cum += a.e / sum;
+      if (cum >= sample) { pick = a.idx; break; }
+    }
+  }
+  return pick;
+}
+
+// Small persistent pool for the per-candidate sampler work (16 independent scans of 8194 logits between two
+// decode steps). Workers spin for a short while after each job — the decode loop calls back within ~1 ms — and
+// sleep on a condition variable otherwise.
+struct SamplerPool {
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::atomic<uint64_t> gen{0};
+  std::atomic<int> next{0}, remaining{0}, n_items{0}; // a straggler's last fetch_add may land in the next job: all atomics
+  std::function<void(int)> fn;
+  bool stop = false;
+  explicit SamplerPool(int n) {
+    for (int i = 0; i < n; i++) th.emplace_back([this] { loop(); });
+  }
+  ~SamplerPool() {
+    { std::lock_guard<std::mutex> lk(m); stop = true; gen++; }
+    cv.notify_all();
+    for (auto &t : th) t.join();
+  }
+  void drain() {
+    int i;
+    while ((i = next.fetch_add(1)) < n_items) { fn(i); remaining.fetch_sub(1); }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      // spin up to 2 ms for the next job, then block
+      auto t0 = std::chrono::steady_clock::now();
+      while (gen.load(std::memory_order_acquire) == seen) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2000)) {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait(lk, [&] { return gen.load() != seen; });
+          break;
+        }
+      }
+      seen = gen.load(std::memory_order_acquire);
+      if (stop) return;
+      drain();
+    }
+  }
+  void run(int n, std::function<void(int)> f) {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      fn = std::move(f); n_items = n; next = 0; remaining = n;
+      gen.fetch_add(1, std::memory_order_release);
+    }
+    cv.notify_all();
+    drain();
+    while (remaining.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+  }
+};
+void sampler_pool_free(SamplerPool *p) { delete p; }
+
+void sample_candidates(tts_ctx *ctx, const float *logits, const int32_t *ids, int ids_per_cand, int B,
+                       int32_t *out) {
+  const int V = TTS_VOCAB_MEL;
+  // the RNG is consumed in candidate order exactly as the reference does; the scans then run in parallel
+  std::vector<float> samples(B);
+  for (int c = 0; c < B; c++) {
     float sample = ctx->distribution(ctx->generator); // first draw discarded (main.cpp:4708-4709)
     sample = ctx->distribution(ctx->generator);
-    auto literal = [&]() {
-      l.assign(src, src + V);
-      for (int j = 0; j < ids_per_cand; j++) {
-        const int id = ids[(size_t)c * ids_per_cand + j];
-        const float g = src[id];
-        l[id] = (g < 0) ? g * 2.0f : g / 2.0f;
-      }
-      for (int i = 0; i < V; i++) l[i] /= temp;
-      std::vector<float> tmp(l);
-      std::nth_element(tmp.begin(), tmp.begin() + (V - TOPK), tmp.end());
-      const float kth = tmp[V - TOPK];
-      for (int i = 0; i < V; i++) if (l[i] < kth) l[i] = LOWEST;
-      return multinomial_literal(l, sample);
-    };
-    if (many) { out[c] = literal(); continue; }
-    auto val = [&](int i) { for (int q = 0; q < np; q++) if (pid[q] == i) return pval[q]; return src[i]; };
-    // k-th largest penalised logit: min-heap of the 50 largest seen so far (almost every element fails
-    // the single compare against the heap minimum)
-    float heap[TOPK];
-    for (int i = 0; i < TOPK; i++) heap[i] = val(i);
-    std::make_heap(heap, heap + TOPK, std::greater<float>());
-    float hmin = heap[0];
-    for (int i = TOPK; i < V; i++) {
-      float x = src[i];
-      if (x <= hmin) continue;              // (penalised values are <= their source unless negative*2, handled by val)
-      x = val(i);
-      if (x <= hmin) continue;
-      std::pop_heap(heap, heap + TOPK, std::greater<float>());
-      heap[TOPK - 1] = x;
-      std::push_heap(heap, heap + TOPK, std::greater<float>());
-      hmin = heap[0];
-    }
-    // a penalised NEGATIVE logit is x*2 < x, a positive one x/2 < x: overrides never exceed src, so the scan
-    // above cannot miss them. Threshold on the tempered values: ties (also those created by the division's
-    // rounding: at most two adjacent floats share a quotient) survive, as in val_where_below_thresh.
-    const float kth = hmin / temp;
-    float cut = hmin;
-    for (int q = 0; q < 4; q++) cut = std::nextafter(cut, LOWEST);
-    s.clear();
-    for (int i = 0; i < V; i++) {
-      if (src[i] < cut) continue;
-      const float v = val(i) / temp;
-      if (v >= kth) s.push_back({v, i, 0.f});
-    }
-    asc = s;
-    std::sort(asc.begin(), asc.end(), [](const Surv &a, const Surv &b) { return a.v < b.v; });
-    bool tie = false;
-    for (size_t i = 1; i < asc.size(); i++) tie |= (asc[i].v == asc[i - 1].v);
-    if (tie) { out[c] = literal(); continue; } // inherit std::sort's tie order from the literal formulation
-    // top-p over the ascending survivors (non-survivors contribute exp(lowest) = +0)
-    float sum = 0;
-    for (auto &a : asc) { a.e = exp_like_reference(a.v); sum += a.e; }
-    float cum = 0;
-    // final softmax + multinomial in index order
-    for (size_t i = 0; i < asc.size(); i++) {
-      cum += asc[i].e / sum;
-      if (i + 1 < asc.size() && cum <= 0.2)
-        for (auto &b : s) if (b.idx == asc[i].idx) b.v = LOWEST; // cut
-    }
-    sum = 0;
-    for (auto &a : s) { a.e = (a.v == LOWEST) ? 0.f : exp_like_reference(a.v); sum += a.e; }
-    int pick = V - 1;
-    if (!(0.0f < sample)) pick = 0; // cumulative(=0) >= sample already at index 0
-    else {
-      cum = 0;
-      for (auto &a : s) {
-        cum += a.e / sum;
-        if (cum >= sample) { pick = a.idx; break; }
-      }
-    }
-    out[c] = pick;
+    samples[c] = sample;
   }
+  auto one = [&](int c) { out[c] = sample_one(logits + (size_t)c * V, ids + (size_t)c * ids_per_cand, ids_per_cand, samples[c]); };
+  if (B < 4) { for (int c = 0; c < B; c++) one(c); return; }
+  if (!ctx->sampler_pool) {
+    const int hw = (int)std::thread::hardware_concurrency();
+    ctx->sampler_pool = new SamplerPool(std::max(1, std::min(7, hw - 1)));
+  }
+  ctx->sampler_pool->run(B, one);
 }
 
 // apply_padding, main.cpp:4510-4532 (the 8139 is the reference's literal, not 8193)
