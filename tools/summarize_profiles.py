@@ -48,8 +48,10 @@ def pmc(fetch_csv, write_csv, dst, note):
         if not k.startswith(("void tts::", "tts::")):
             continue
         w = wr.get(k, (0, 0.0))[1]
-        out["kernels"][short(k)] = {"dispatches": n, "fetch_KiB": round(f, 1), "write_KiB": round(w, 1),
-                                    "hbm_bytes_per_launch": int((f + w) * 1024)}
+        # MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports exactly half the bytes of wide (16 B/lane) coalesced
+        # reads, global_load and LDS-DMA alike -> doubled; WRITE_SIZE calibrated x1 (see the note in the output file)
+        out["kernels"][short(k)] = {"dispatches": n, "fetch_KiB_raw": round(f, 1), "write_KiB_raw": round(w, 1),
+                                    "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
     json.dump(out, open(dst, "w"), indent=1)
 
 
