@@ -167,15 +167,16 @@ typedef void __attribute__((address_space(3))) *lptr_t;
 // activation rows), so a lane's 4 accumulator registers are 4 CONSECUTIVE output columns of one row:
 // residual loads and stores are 16 bytes per lane instead of 4. The QKV mode keeps the natural order
 // (a lane holds 4 consecutive rows of one column) because V is stored transposed.
-template <int MODE>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, floatx4 (&acc)[4][4], int m0, int n0, int wm, int wn, int fr, int fq) {
+template <int MODE, int MI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, floatx4 (&acc)[MI][4], int m0, int n0, int wm, int wn, int fr, int fq) {
   if (MODE == GEMM_OUT_QKV) {
     // col = h*192 + {q 0..63 | k 64..127 | v 128..191}; a wave's 64-column span is entirely q, k or v.
     const int c0 = n0 + wn * 64, h = c0 / 192, w0 = c0 - h * 192;
     if (w0 >= 128) { // V, natural operand order: lane = 4 consecutive rows of one column -> 8-byte transposed store
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int rbase = m0 + wm * 64 + i * 16 + fq * 4;
+      for (int i = 0; i < MI; i++) {
+        const int rbase = m0 + wm * (16 * MI) + i * 16 + fq * 4;
+        if (rbase >= g.M) continue; // M % 4 == 0: a lane's 4 rows are in or out together
         bool guard[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) guard[r] = g.row_seq ? (g.row_seq[rbase + r] < 0) : false;
@@ -195,8 +196,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, floatx4 (&acc)[
       }
     } else { // Q or K, swapped operand order: lane = 4 consecutive columns of one row -> 8-byte store
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int row = m0 + wm * 64 + i * 16 + fr;
+      for (int i = 0; i < MI; i++) {
+        const int row = m0 + wm * (16 * MI) + i * 16 + fr;
+        if (row >= g.M) continue;
         const bool guard = g.row_seq ? (g.row_seq[row] < 0) : false;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -216,10 +218,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, floatx4 (&acc)[
       }
     }
   } else {
-    // acc[i][j][r] = C[m0 + wm*64 + i*16 + fr][n0 + wn*64 + j*16 + fq*4 + r]
+    // acc[i][j][r] = C[m0 + wm*16*MI + i*16 + fr][n0 + wn*64 + j*16 + fq*4 + r]
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int row = m0 + wm * 64 + i * 16 + fr;
+    for (int i = 0; i < MI; i++) {
+      const int row = m0 + wm * (16 * MI) + i * 16 + fr;
+      if (row >= g.M) continue;
       const bool guard = g.row_seq ? (g.row_seq[row] < 0) : false;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
@@ -249,34 +252,48 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, floatx4 (&acc)[
   }
 }
 
-template <int MODE>
+// MI = 16-row MFMA tiles per wave along M: the workgroup tile is (32 MI) x 128. MI = 4 (128 rows) is the default;
+// MI = 5 (160 rows) is chosen by launch_gemm_f16 when it turns a 2.3-round grid into fewer, fuller rounds.
+template <int MODE, int MI>
 static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) char smem[32768];
+  constexpr int BM = 32 * MI;
+  __shared__ __attribute__((aligned(16))) char smem[BM * 128 + 16384];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // L2-aware tile order. Workgroup b runs on XCD b % 8 (each XCD has its own 4 MB L2). An XCD owns a
   // contiguous range of m-tiles and walks them once per chunk of `cn` n-tiles, chunk outermost: the chunk's
   // weight rows (cn * 128 * K * 2 B <= ~2.5 MB) stay L2-resident while the activations stream through.
   // (With plain m-major order the 6 MB QKV weight thrashed L2: 417 MB fetched per launch for 64 MB of operands.)
-  const int MT = g.M >> 7, NT = g.N >> 7;
+  const int MT = (g.M + BM - 1) / BM, NT = g.N >> 7;
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int mq = MT >> 3, mr = MT & 7;
   const int mcount = mq + (xcd < mr ? 1 : 0), mfirst = xcd * mq + (xcd < mr ? xcd : mr);
   if (idx >= mcount * NT) return; // grid is padded to 8 * max tiles per XCD
   const int cn = g.cn > 0 ? g.cn : NT, per_chunk = mcount * cn;
   const int chunk = idx / per_chunk, rem = idx - chunk * per_chunk;
-  const int m0 = (mfirst + rem / cn) << 7, n0 = (chunk * cn + rem % cn) << 7;
+  const int m0 = (mfirst + rem / cn) * BM, n0 = (chunk * cn + rem % cn) << 7;
   const int tiles_per_seg = g.kseg >> 6, nk = g.nseg * tiles_per_seg;
   const int ldw = g.custom_w ? g.ldw_ : g.nseg * g.kseg;
-  // DMA roles: wave w, piece i covers rows (w*4+i)*8 .. +7 of the A tile and of the B tile
+  // DMA roles: wave w, piece i covers rows (w*MI+i)*8 .. +7 of the A tile; (w*4+i)*8 .. +7 of the B tile
   const int prow = lane >> 3, pslot = lane & 7;
-  floatx4 acc[4][4];
+  int aoff[MI], boff[4];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < MI; i++) {
+    const int row = (wave * MI + i) * 8 + prow;
+    aoff[i] = min(m0 + row, g.M - 1) * g.lda + (pslot ^ ((row >> 1) & 7)) * 8; // rows past M re-read the last row (never stored)
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = (wave * 4 + i) * 8 + prow;
+    boff[i] = (n0 + row) * ldw + (pslot ^ ((row >> 1) & 7)) * 8;
+  }
+  floatx4 acc[MI][4];
+#pragma unroll
+  for (int i = 0; i < MI; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fq = lane >> 4;
-  char *sa = smem, *sb = smem + 16384;
+  char *sa = smem, *sb = smem + BM * 128;
   // operand order (see gemm_epilogue): natural only for the V columns of a QKV projection (wave-uniform)
   const bool natural = (MODE == GEMM_OUT_QKV) && (((n0 + wn * 64) % 192) >= 128);
   // the K loop is instantiated once per operand order so the choice costs nothing inside it
@@ -284,26 +301,24 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g
     constexpr bool NAT = decltype(nat)::value;
     for (int kt = 0; kt < nk; kt++) {
       const int seg = kt / tiles_per_seg, kk = (kt - seg * tiles_per_seg) << 6;
-      const __half *abase = g.A[seg] + (size_t)(m0 + g.row_off[seg]) * g.lda + kk;
-      const __half *wbase = g.W + (size_t)n0 * ldw + (g.custom_w ? g.w_off_[seg] : seg * g.kseg) + kk;
+      const __half *abase = g.A[seg] + (ptrdiff_t)g.row_off[seg] * g.lda + kk;
+      const __half *wbase = g.W + (g.custom_w ? g.w_off_[seg] : seg * g.kseg) + kk;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int row = (wave * 4 + i) * 8 + prow;
-        const int c = pslot ^ ((row >> 1) & 7);
-        __builtin_amdgcn_global_load_lds((gptr_t)(abase + (size_t)row * g.lda + c * 8), (lptr_t)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (size_t)row * ldw + c * 8), (lptr_t)(sb + (wave * 4 + i) * 1024), 16, 0, 0);
-      }
+      for (int i = 0; i < MI; i++)
+        __builtin_amdgcn_global_load_lds((gptr_t)(abase + aoff[i]), (lptr_t)(sa + (wave * MI + i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        __builtin_amdgcn_global_load_lds((gptr_t)(wbase + boff[i]), (lptr_t)(sb + (wave * 4 + i) * 1024), 16, 0, 0);
       __syncthreads(); // waits vmcnt(0) for the DMA, then barrier
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
-        half8 af[4], bf[4];
+        half8 af[MI], bf[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          af[i] = *(const half8 *)(sa + lds_off(wm * 64 + i * 16 + fr, ks * 4 + fq));
-          bf[i] = *(const half8 *)(sb + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
-        }
+        for (int i = 0; i < MI; i++) af[i] = *(const half8 *)(sa + lds_off(wm * (16 * MI) + i * 16 + fr, ks * 4 + fq));
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 4; i++) bf[i] = *(const half8 *)(sb + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < MI; i++)
 #pragma unroll
           for (int j = 0; j < 4; j++) {
             if (NAT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
@@ -315,7 +330,7 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g
   };
   if (MODE == GEMM_OUT_QKV && natural) kloop(std::true_type{});
   else kloop(std::false_type{});
-  gemm_epilogue<MODE>(g, acc, m0, n0, wm, wn, fr, fq);
+  gemm_epilogue<MODE, MI>(g, acc, m0, n0, wm, wn, fr, fq);
 }
 
 // k = 3 convolution as ONE GEMM with a shared activation slab. The three taps are three row-shifted GEMM
@@ -326,37 +341,38 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g
 // (64 B/clk/CU feeds at most one 32 KB K tile per 512 MFMA cycles).
 // The weight tiles alternate between two LDS buffers: tap p+1's tile is requested before tap p's is waited for
 // (counted vmcnt + raw barrier), so only the slab load at the start of a chunk is exposed.
-static constexpr int CONV3_LDS = 17408 + 2 * 16384;
-template <int MODE>
+template <int MI> constexpr int conv3_lds() { return (32 * MI + 8) * 128 + 2 * 16384; }
+template <int MODE, int MI>
 static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem_dyn[]; // A slab 136 rows | B tile x 2
+  constexpr int BM = 32 * MI, SLAB = (BM + 8) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[]; // A slab BM+8 rows | B tile x 2
   char *smem = smem_dyn;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int MT = g.M >> 7, NT = g.N >> 7;
+  const int MT = (g.M + BM - 1) / BM, NT = g.N >> 7;
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
   const int mq = MT >> 3, mr = MT & 7;
   const int mcount = mq + (xcd < mr ? 1 : 0), mfirst = xcd * mq + (xcd < mr ? xcd : mr);
   if (idx >= mcount * NT) return;
   const int cn = g.cn > 0 ? g.cn : NT, per_chunk = mcount * cn;
   const int chunk = idx / per_chunk, rem = idx - chunk * per_chunk;
-  const int m0 = (mfirst + rem / cn) << 7, n0 = (chunk * cn + rem % cn) << 7;
+  const int m0 = (mfirst + rem / cn) * BM, n0 = (chunk * cn + rem % cn) << 7;
   const int nchunks = g.kseg >> 6, ldw = 3 * g.kseg, nph = 3 * nchunks;
   const int prow = lane >> 3, pslot = lane & 7;
-  floatx4 acc[4][4];
+  floatx4 acc[MI][4];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < MI; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fq = lane >> 4;
-  char *sa = smem, *sb = smem + 17408;
+  char *sa = smem, *sb = smem + SLAB;
   // slab row s = activation row m0 - 1 + s (the buffer has its guard rows, as for the plain segments)
   const __half *abase = g.A[0] + (ptrdiff_t)(m0 - 1) * g.lda;
   const __half *wbase = g.W + (size_t)n0 * ldw;
-  int aoff[5], boff[4];
+  int aoff[MI + 1], boff[4];
 #pragma unroll
-  for (int i = 0; i < 5; i++) {
-    const int row = (i < 4 ? wave * 4 + i : 16) * 8 + prow;
+  for (int i = 0; i <= MI; i++) {
+    const int row = (i < MI ? wave * MI + i : 4 * MI) * 8 + prow;
     const int c = pslot ^ ((row >> 1) & 7);
     aoff[i] = min(row, g.M - m0 + 1) * g.lda + c * 8; // rows past the buffer end are never multiplied: clamp
   }
@@ -369,8 +385,8 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_kernel(GemmArgs 
   auto stageA = [&](int kc) {
     const __half *src = abase + (min(kc, nchunks - 1) << 6);
 #pragma unroll
-    for (int i = 0; i < 4; i++) __builtin_amdgcn_global_load_lds((gptr_t)(src + aoff[i]), (lptr_t)(sa + (wave * 4 + i) * 1024), 16, 0, 0);
-    if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(src + aoff[4]), (lptr_t)(sa + 16 * 1024), 16, 0, 0);
+    for (int i = 0; i < MI; i++) __builtin_amdgcn_global_load_lds((gptr_t)(src + aoff[i]), (lptr_t)(sa + (wave * MI + i) * 1024), 16, 0, 0);
+    if (wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(src + aoff[MI]), (lptr_t)(sa + 4 * MI * 1024), 16, 0, 0);
   };
   auto stageB = [&](int p) { // phase p = chunk p / 3, tap p % 3 (clamped past the end: uniform vmcnt arithmetic)
     p = min(p, nph - 1);
@@ -391,14 +407,13 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_kernel(GemmArgs 
       const char *sbp = sb + (p & 1) * 16384;
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
-        half8 af[4], bf[4];
+        half8 af[MI], bf[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          af[i] = *(const half8 *)(sa + lds_off(wm * 64 + i * 16 + fr + tap, ks * 4 + fq));
-          bf[i] = *(const half8 *)(sbp + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
-        }
+        for (int i = 0; i < MI; i++) af[i] = *(const half8 *)(sa + lds_off(wm * (16 * MI) + i * 16 + fr + tap, ks * 4 + fq));
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 4; i++) bf[i] = *(const half8 *)(sbp + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < MI; i++)
 #pragma unroll
           for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
       }
@@ -408,7 +423,7 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_kernel(GemmArgs 
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // trailing (clamped) pieces must land before the LDS is released
-  gemm_epilogue<MODE>(g, acc, m0, n0, wm, wn, fr, fq);
+  gemm_epilogue<MODE, MI>(g, acc, m0, n0, wm, wn, fr, fq);
 }
 
 // Variant 2/3: NST-deep LDS ring (NST x 32 KB, dynamic LDS). Tile kt+NST-1 is requested while tile kt is
@@ -482,7 +497,7 @@ static __global__ __launch_bounds__(256) void gemm_f16_ring_kernel(GemmArgs g) {
   };
   if (MODE == GEMM_OUT_QKV && natural) kloop(std::true_type{});
   else kloop(std::false_type{});
-  gemm_epilogue<MODE>(g, acc, m0, n0, wm, wn, fr, fq);
+  gemm_epilogue<MODE, 4>(g, acc, m0, n0, wm, wn, fr, fq);
 }
 
 template <int NST>
@@ -578,7 +593,7 @@ static __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g) {
   };
   if (MODE == GEMM_OUT_QKV && natural) kloop(std::true_type{});
   else kloop(std::false_type{});
-  if (m0 + wm * 64 < g.M) gemm_epilogue<MODE>(g, acc, m0, n0, wm, wn, fr, fq);
+  if (m0 + wm * 64 < g.M) gemm_epilogue<MODE, 4>(g, acc, m0, n0, wm, wn, fr, fq);
 }
 
 static inline hipError_t launch_gemm_big(const GemmArgs &g, hipStream_t s) {
@@ -951,7 +966,6 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
     while (!no_chunk && NT > 8 && cn > 1 && (cn % 2 == 0) && (size_t)cn * 128 * ktot * 2 > (size_t)2560 * 1024) cn /= 2;
     gg.cn = cn;
   }
-  const int MTt = g.M >> 7, grid1 = 8 * ((MTt >> 3) + ((MTt & 7) ? 1 : 0)) * (g.N >> 7);
 #ifndef TTS_GEMM_VARIANT
 #define TTS_GEMM_VARIANT 1
 #endif
@@ -960,16 +974,36 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
   if (TTS_GEMM_VARIANT == 4) return launch_gemm_big(g, s);
   if (TTS_GEMM_VARIANT == 2) return launch_gemm_ring<2>(g, s);
   if (TTS_GEMM_VARIANT == 3) return launch_gemm_ring<3>(g, s);
+  if (TTS_GEMM_VARIANT == 0) { gemm_f16_kernel<<<ntiles, 256, 65536, s>>>(g); return hipGetLastError(); }
+  // Tile height: 128 rows. 160-row tiles (MI = 5: 1416 instead of 1768 workgroups on 768 slots) were measured 4-6 %
+  // SLOWER on all three shapes (tools/gemm_bench, TTS_GEMM_MI=5): workgroups are dispatched continuously, not in
+  // rounds, so there is no 2.3 -> 3 round quantisation to win back. The instantiation is kept for the A/B switch.
+  static const char *force_mi = getenv("TTS_GEMM_MI");
+  const int NTt = g.N >> 7;
+  const int mi = (force_mi && atoi(force_mi) == 5) ? 5 : 4;
+  const int bm = 32 * mi, MTt = (g.M + bm - 1) / bm, grid1 = 8 * ((MTt >> 3) + ((MTt & 7) ? 1 : 0)) * NTt;
   // k = 3 convolution (three row-shifted segments of one activation buffer, tap-major weights): shared-slab kernel
   static const bool no_conv3 = getenv("TTS_GEMM_NOCONV3") != nullptr; // A/B switch for tools/gemm_bench
   const bool conv3 = !no_conv3 && g.nseg == 3 && !g.custom_w && g.A[0] == g.A[1] && g.A[1] == g.A[2] && g.row_off[0] == -1 &&
                      g.row_off[1] == 0 && g.row_off[2] == 1 && g.mode != GEMM_OUT_QKV;
-  if (TTS_GEMM_VARIANT == 0) gemm_f16_kernel<<<ntiles, 256, 65536, s>>>(g);
-  else if (conv3 && g.mode == GEMM_OUT_F32) gemm_f16_conv3_kernel<GEMM_OUT_F32><<<grid1, 256, CONV3_LDS, s>>>(gg);
-  else if (conv3) gemm_f16_conv3_kernel<GEMM_OUT_F16><<<grid1, 256, CONV3_LDS, s>>>(gg);
-  else if (g.mode == GEMM_OUT_F32) gemm_f16_glds_kernel<GEMM_OUT_F32><<<grid1, 256, 0, s>>>(gg);
-  else if (g.mode == GEMM_OUT_F16) gemm_f16_glds_kernel<GEMM_OUT_F16><<<grid1, 256, 0, s>>>(gg);
-  else gemm_f16_glds_kernel<GEMM_OUT_QKV><<<grid1, 256, 0, s>>>(gg);
+#define TTS_LAUNCH_MI(MI_)                                                                                              \
+  do {                                                                                                                  \
+    if (conv3) {                                                                                                        \
+      static bool attr = false;                                                                                         \
+      if (!attr) {                                                                                                      \
+        (void)hipFuncSetAttribute((const void *)gemm_f16_conv3_kernel<GEMM_OUT_F32, MI_>, hipFuncAttributeMaxDynamicSharedMemorySize, conv3_lds<MI_>()); \
+        (void)hipFuncSetAttribute((const void *)gemm_f16_conv3_kernel<GEMM_OUT_F16, MI_>, hipFuncAttributeMaxDynamicSharedMemorySize, conv3_lds<MI_>()); \
+        attr = true;                                                                                                    \
+      }                                                                                                                 \
+      if (g.mode == GEMM_OUT_F32) gemm_f16_conv3_kernel<GEMM_OUT_F32, MI_><<<grid1, 256, conv3_lds<MI_>(), s>>>(gg);     \
+      else gemm_f16_conv3_kernel<GEMM_OUT_F16, MI_><<<grid1, 256, conv3_lds<MI_>(), s>>>(gg);                            \
+    } else if (g.mode == GEMM_OUT_F32) gemm_f16_glds_kernel<GEMM_OUT_F32, MI_><<<grid1, 256, 0, s>>>(gg);                \
+    else if (g.mode == GEMM_OUT_F16) gemm_f16_glds_kernel<GEMM_OUT_F16, MI_><<<grid1, 256, 0, s>>>(gg);                  \
+    else gemm_f16_glds_kernel<GEMM_OUT_QKV, MI_><<<grid1, 256, 0, s>>>(gg);                                              \
+  } while (0)
+  if (mi == 5) TTS_LAUNCH_MI(5);
+  else TTS_LAUNCH_MI(4);
+#undef TTS_LAUNCH_MI
   return hipGetLastError();
 }
 
