@@ -795,6 +795,8 @@ static int gemm(tts_ctx *ctx, const char *fam, GemmArgs &g, const Layout &lay, i
   // (GroupNorm statistics fused into this epilogue were tried and measured slower: +2.7 ms/step of GEMM
   //  time for 1.0 ms/step of gn_stats saved — register pressure costs a resident workgroup per CU.)
   (void)stats_wk;
+  static const bool log_shapes = getenv("TTS_GEMM_LOG") != nullptr; // developer aid: one line per launch
+  if (log_shapes) fprintf(stderr, "gemm M=%d N=%d K=%dx%d mode=%d resid=%d\n", g.M, g.N, g.nseg, g.kseg, g.mode, g.resid != nullptr);
   ProfScope ps(ctx, fam, 2.0 * mv * (n_valid ? n_valid : g.N) * (k_valid ? k_valid : g.nseg * g.kseg));
   TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream));
   return TTS_OK;
@@ -823,13 +825,21 @@ static int gn_stats(tts_ctx *ctx, const Layout &lay, Work &wk, const float *x) {
 // (T <= NJ * NT / 8 rows) is read from HBM exactly once into NJ float4 per thread, mean and centred variance are
 // reduced across the workgroup (two-pass on registers), and the normalised fp16 rows are written straight out.
 template <int NT, int NJ>
-__global__ __launch_bounds__(NT) void gn_reg_kernel(const float *__restrict__ x, const int *__restrict__ seq_start,
+__global__ __launch_bounds__(NT) void gn_reg_kernel(int getenv_gn_xcd, const float *__restrict__ x, const int *__restrict__ seq_start,
                                                     const int *__restrict__ seq_len, int rows_total, int ns, float eps,
                                                     const float *__restrict__ g, const float *__restrict__ b,
                                                     const float *__restrict__ ss, int do_silu, int lut, __half *__restrict__ y) {
   constexpr int NW = NT / 64, SWEEP = NT / 8;
   __shared__ float sh[2][NW];
-  const int grp = blockIdx.x, s = blockIdx.y, T = seq_len[s], r0 = seq_start[s];
+  // workgroup b runs on XCD b % 8: give each XCD whole sequences (all 32 groups of a row = the full 4 KB row go
+  // through one L2) instead of 128-byte slices of every row
+  int grp = blockIdx.x, s = blockIdx.y;
+  if (getenv_gn_xcd) {
+    const int b = blockIdx.y * 32 + blockIdx.x, nb = ns * 32, xcd = b & 7, j = b >> 3;
+    const int q = nb >> 3, item = xcd * q + j; // nb % 8 == 0 (32 groups)
+    s = item >> 5; grp = item & 31;
+  }
+  const int T = seq_len[s], r0 = seq_start[s];
   const int q = threadIdx.x & 7, c = grp * 32 + q * 4, t0 = threadIdx.x >> 3;
   const float *base = x + (size_t)r0 * C + c;
   float4 v[NJ];
@@ -904,10 +914,12 @@ static int gn_fused(tts_ctx *ctx, const Layout &lay, const float *x, const float
                     __half *y) {
   ProfScope ps(ctx, "diff_gn_fused");
   const int tmax = lay.max_len();
-#define GN_ARGS x, lay.d_start.as<int>(), lay.d_len.as<int>(), lay.rows, lay.ns, ctx->gn_eps, g, b, ss, do_silu, ctx->ggml_lut, y
+  static const int gn_xcd = getenv("TTS_GN_NOXCD") ? 0 : 1; // A/B switch
+#define GN_ARGS gn_xcd, x, lay.d_start.as<int>(), lay.d_len.as<int>(), lay.rows, lay.ns, ctx->gn_eps, g, b, ss, do_silu, ctx->ggml_lut, y
   if (tmax <= 14 * 64) gn_reg_kernel<512, 14><<<dim3(32, lay.ns), 512, 0, ctx->stream>>>(GN_ARGS);
   else if (tmax <= 18 * 128) gn_reg_kernel<1024, 18><<<dim3(32, lay.ns), 1024, 0, ctx->stream>>>(GN_ARGS);
-  else gn_fused_kernel<0><<<dim3(32, lay.ns), 256, 0, ctx->stream>>>(GN_ARGS); // two sweeps over global memory
+  else gn_fused_kernel<0><<<dim3(32, lay.ns), 256, 0, ctx->stream>>>(x, lay.d_start.as<int>(), lay.d_len.as<int>(), lay.rows, lay.ns, ctx->gn_eps, g, b, ss,
+                                                                    do_silu, ctx->ggml_lut, y); // two sweeps over global memory
 #undef GN_ARGS
   TTS_HIP(ctx, hipGetLastError());
   return TTS_OK;
