@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void convt_kernel(const float *__restrict__ x,
 // Fused location-variable convolution + gate + residual (main.cpp:4365-4455):
 //   o[ch][pos] = b_l[ch] + sum_{i<32} sum_{k<3} ypad[i][pos+k-1] * W_l[i][ch][k],  ch < 64
 //   x[pos][c] += sigmoid(o[c]) * tanh(o[32+c])
-// kern: [rows][24576] f32 with channel ((layer*32 + i)*64 + ch)*3 + k ; kb: [rows][256], channel layer*64+ch.
+// kern: [rows][24576] f32, layer l at l*6144, inside a layer in lvc_col order (below); kb: [rows][256], channel layer*64+ch.
 // One block per (frame, chunk of 64 samples); W_l staged in LDS as [i*3+k][64].
 __global__ __launch_bounds__(256) void lvc_gate_kernel(const float *__restrict__ y, const float *__restrict__ kern,
                                                        const float *__restrict__ kb, const int *__restrict__ row_seq, int hop,
@@ -138,8 +138,9 @@ __global__ __launch_bounds__(256) void lvc_gate_kernel(const float *__restrict__
   if (s < 0) return;
   const int chunk = min(64, hop), s0 = blockIdx.x * chunk;
   const float *kl = kern + (size_t)row * 24576 + (size_t)layer * 6144;
-  for (int idx = threadIdx.x; idx < 6144; idx += 256) {
-    const int k = idx % 3, ch = (idx / 3) & 63, i = idx / 192;
+  for (int idx = threadIdx.x; idx < 6144; idx += 256) { // idx in lvc_col order (see lvc_mfma_kernel)
+    const int j = idx & 3, ln = (idx >> 2) & 63, nt = (idx >> 8) & 3, g = (idx >> 10) & 1, k = idx >> 11;
+    const int i = g * 16 + 4 * (ln >> 4) + j, ch = nt * 16 + (ln & 15);
     W[(i * 3 + k) * 64 + ch] = kl[idx];
   }
   // y window: positions [row*hop + s0 - 1, +chunk+2); outside the sequence -> 0 (ggml_pad_ext 1,1)
@@ -172,6 +173,121 @@ __global__ __launch_bounds__(256) void lvc_gate_kernel(const float *__restrict__
     const float g = 1.0f / (1.0f + expf(-a0)) * tanhf(a1);
     const int64_t p = (int64_t)row * hop + s0 + sl;
     x[p * 32 + c] += g;
+  }
+}
+
+// Order of the predicted kernel's 6144 values per (frame, layer) — chosen at load by permuting the output
+// channels of kernel_conv, so that the kernel GEMM writes them directly as fp32-MFMA A fragments:
+//   lvc_col(tap, i, ch) = (((tap*2 + g)*4 + nt)*64 + lane)*4 + j,  i = 16 g + 4 (lane>>4) + j,  ch = 16 nt + (lane&15)
+// (reference order: (i*64 + ch)*3 + tap).
+__host__ __device__ inline int lvc_col(int tap, int i, int ch) {
+  const int g = i >> 4, j = i & 3, lane = ((i & 15) >> 2) * 16 + (ch & 15), nt = ch >> 4;
+  return (((tap * 2 + g) * 4 + nt) * 64 + lane) * 4 + j;
+}
+
+// Location-variable convolution + gate + residual on the fp32 MFMA (exact f32 products, as the reference's F32
+// einsum), for hop % 64 == 0. One workgroup = one frame: its 64 x 96 predicted kernel is 24 float4 per lane,
+// loaded once with 1 KB-per-wave loads; a wave walks hop/64 tiles of 16 samples; operands swapped so that a lane
+// ends with 4 consecutive channels of one sample. y is zero on guard frames (voc_dconv_mfma_kernel), so the
+// window's zero padding at the sequence ends needs no branch.
+__global__ __launch_bounds__(256) void lvc_mfma_kernel(const float *__restrict__ y, const float *__restrict__ kern,
+                                                       const float *__restrict__ kb, const int *__restrict__ row_seq, int hop,
+                                                       int layer, float *__restrict__ x) {
+  const int row = blockIdx.x;
+  if (row_seq[row] < 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+  float4 w[3][2][4];
+  {
+    const float4 *wp = (const float4 *)(kern + (size_t)row * 24576 + (size_t)layer * 6144) + lane;
+#pragma unroll
+    for (int tap = 0; tap < 3; tap++)
+#pragma unroll
+      for (int g = 0; g < 2; g++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) w[tap][g][nt] = wp[((tap * 2 + g) * 4 + nt) * 64];
+  }
+  float4 bs[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; nt++) bs[nt] = *(const float4 *)(kb + (size_t)row * 256 + layer * 64 + nt * 16 + 4 * kq);
+  const int per_wave = hop >> 6;
+  for (int t = 0; t < per_wave; t++) {
+    const int64_t pos = (int64_t)row * hop + (wave * per_wave + t) * 16 + m;
+    floatx4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) acc[nt] = (floatx4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 3; tap++)
+#pragma unroll
+      for (int g = 0; g < 2; g++) {
+        const float4 yv = *(const float4 *)(y + (pos + tap - 1) * 32 + g * 16 + 4 * kq);
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][g][nt].x, yv.x, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][g][nt].y, yv.y, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][g][nt].z, yv.z, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][g][nt].w, yv.w, acc[nt], 0, 0, 0);
+        }
+      }
+#pragma unroll
+    for (int nt = 0; nt < 2; nt++) { // channels c = 16 nt + 4 kq + r gate with 32 + c
+      float *xp = x + pos * 32 + nt * 16 + 4 * kq;
+      float4 xv = *(const float4 *)xp;
+      const float lo[4] = {acc[nt][0] + bs[nt].x, acc[nt][1] + bs[nt].y, acc[nt][2] + bs[nt].z, acc[nt][3] + bs[nt].w};
+      const float hi[4] = {acc[nt + 2][0] + bs[nt + 2].x, acc[nt + 2][1] + bs[nt + 2].y, acc[nt + 2][2] + bs[nt + 2].z,
+                           acc[nt + 2][3] + bs[nt + 2].w};
+      xv.x += 1.0f / (1.0f + expf(-lo[0])) * tanhf(hi[0]);
+      xv.y += 1.0f / (1.0f + expf(-lo[1])) * tanhf(hi[1]);
+      xv.z += 1.0f / (1.0f + expf(-lo[2])) * tanhf(hi[2]);
+      xv.w += 1.0f / (1.0f + expf(-lo[3])) * tanhf(hi[3]);
+      *(float4 *)xp = xv;
+    }
+  }
+}
+
+// leaky -> dilated conv k3 32->32 -> leaky at audio rate (main.cpp:4339-4365) on the fp16 MFMA, for hop % 16 == 0
+// and dil < hop (a tap that leaves the sequence lands in a guard frame, where x is zero): a 16-sample tile x one
+// tap = one 16x16x32 MFMA per 16 output channels, K = the tap's 32 input channels. The stage is a pure stream:
+// 128 B read + 128 B written per sample.
+__global__ __launch_bounds__(256) void voc_dconv_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w /*[3][32][32]*/,
+                                                             const float *__restrict__ bias, const int *__restrict__ row_seq, int hop,
+                                                             int dil, int64_t P, float *__restrict__ y) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, fq = lane >> 4;
+  half8 wf[3][2]; // A-role: lane (co = 16 ct + m, fq) holds w[tap][ci = 8 fq .. +7][co]
+#pragma unroll
+  for (int tap = 0; tap < 3; tap++)
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) wf[tap][ct][e] = (_Float16)w[(tap * 32 + 8 * fq + e) * 32 + ct * 16 + m];
+  float4 bs[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ct++) bs[ct] = *(const float4 *)(bias + ct * 16 + 4 * fq);
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int64_t p0 = (int64_t)blockIdx.x * 256 + (wave * 4 + t) * 16, pos = p0 + m;
+    if (p0 >= P) break;
+    const bool live = row_seq[p0 / hop] >= 0; // a tile lies inside one frame
+    floatx4 acc[2] = {(floatx4){0.f, 0.f, 0.f, 0.f}, (floatx4){0.f, 0.f, 0.f, 0.f}};
+    if (live) {
+#pragma unroll
+      for (int tap = 0; tap < 3; tap++) {
+        int64_t q = pos + (int64_t)(tap - 1) * dil;
+        q = q < 0 ? 0 : (q >= P ? P - 1 : q);
+        const float4 a = *(const float4 *)(x + q * 32 + 8 * fq), b = *(const float4 *)(x + q * 32 + 8 * fq + 4);
+        half8 xf;
+        xf[0] = (_Float16)leaky02(a.x); xf[1] = (_Float16)leaky02(a.y); xf[2] = (_Float16)leaky02(a.z); xf[3] = (_Float16)leaky02(a.w);
+        xf[4] = (_Float16)leaky02(b.x); xf[5] = (_Float16)leaky02(b.y); xf[6] = (_Float16)leaky02(b.z); xf[7] = (_Float16)leaky02(b.w);
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tap][ct], xf, acc[ct], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (live) v = make_float4(leaky02(acc[ct][0] + bs[ct].x), leaky02(acc[ct][1] + bs[ct].y), leaky02(acc[ct][2] + bs[ct].z),
+                                leaky02(acc[ct][3] + bs[ct].w));
+      *(float4 *)(y + pos * 32 + ct * 16 + 4 * fq) = v;
+    }
   }
 }
 
@@ -247,14 +363,17 @@ struct VLoader {
     return put(h, dst);
   }
   // -> fp16 [cout][tap*cin + ci] for the MFMA GEMM
-  int conv_gemm(const std::string &name, int cout, int cin, int k, __half **dst) {
+  // (perm: device output channel n holds the file's channel (*perm)[n])
+  int conv_gemm(const std::string &name, int cout, int cin, int k, __half **dst, const std::vector<int> *perm = nullptr) {
     const HostTensor *t = get(name, (int64_t)cout * cin * k);
     if (!t) return TTS_ERR_FORMAT;
     std::vector<__half> h((size_t)cout * k * cin);
-    for (int co = 0; co < cout; co++)
+    for (int n = 0; n < cout; n++) {
+      const int co = perm ? (*perm)[n] : n;
       for (int ci = 0; ci < cin; ci++)
         for (int tap = 0; tap < k; tap++)
-          h[(size_t)co * k * cin + (size_t)tap * cin + ci] = __float2half_rn(t->data[((size_t)co * cin + ci) * k + tap]);
+          h[(size_t)n * k * cin + (size_t)tap * cin + ci] = __float2half_rn(t->data[((size_t)co * cin + ci) * k + tap]);
+    }
     return put(h, dst);
   }
 };
@@ -282,8 +401,19 @@ int voc_load(tts_ctx *ctx, const char *path) {
         R(ld.conv_kcc(p + ".weight", 64, 64, 3, true, &k.rw[c * 2 + j]));
         R(ld.f32(p + ".bias", 64, &k.rb[c * 2 + j]));
       }
-    R(ld.conv_gemm(kp + "kernel_conv.weight", 24576, 64, 3, &k.kc_w));
-    R(ld.f32(kp + "kernel_conv.bias", 24576, &k.kc_b));
+    { // kernel_conv: output channels permuted into lvc_col order (the LVC kernels read MFMA fragments straight from its output)
+      std::vector<int> perm(24576);
+      for (int l = 0; l < 4; l++)
+        for (int i2 = 0; i2 < 32; i2++)
+          for (int ch = 0; ch < 64; ch++)
+            for (int tap = 0; tap < 3; tap++) perm[l * 6144 + lvc_col(tap, i2, ch)] = ((l * 32 + i2) * 64 + ch) * 3 + tap;
+      R(ld.conv_gemm(kp + "kernel_conv.weight", 24576, 64, 3, &k.kc_w, &perm));
+      const HostTensor *tb = ld.get(kp + "kernel_conv.bias", 24576);
+      if (!tb) return TTS_ERR_FORMAT;
+      std::vector<float> hb(24576);
+      for (int n = 0; n < 24576; n++) hb[n] = tb->data[perm[n]];
+      R(ld.put(hb, &k.kc_b));
+    }
     R(ld.conv_gemm(kp + "bias_conv.weight", 256, 64, 3, &k.bc_w));
     R(ld.f32(kp + "bias_conv.bias", 256, &k.bc_b));
     { // ConvTranspose1d: file layout ne=[K,Cout,Cin] -> w[(ci*32+co)*K + k]; device [k][ci][co], F32
@@ -459,6 +589,15 @@ int voc_run(tts_ctx *ctx, const float *mel, const int32_t *frames, int B, const 
     const int dil[4] = {1, 3, 9, 27};
     for (int c = 0; c < 4; c++) {
       // leaky -> dilated conv k3 32->32 -> leaky (main.cpp:4339-4365)
+      if (hop % 64 == 0) { // audio-rate stages: matrix-pipe kernels (frames are whole 16-sample tiles, dil < hop)
+        const int64_t P = (int64_t)R * hop;
+        { ProfScope ps(ctx, "voc_conv");
+          voc_dconv_mfma_kernel<<<(int)((P + 255) / 256), 256, 0, ctx->stream>>>(cur, st->cb_w[i][c], st->cb_b[i][c], d_rs, hop, dil[c], P, yb); }
+        ProfScope ps(ctx, "voc_lvc");
+        lvc_mfma_kernel<<<R, 256, 0, ctx->stream>>>(yb, st->kern.as<float>(), st->kbias.as<float>(), d_rs, hop, c, cur);
+        TTS_HIP(ctx, hipGetLastError());
+        continue;
+      }
       CHECK(conv(ctx, st, cur, st->cb_w[i][c], st->cb_b[i][c], yb, nullptr, (int64_t)R * hop, 32, 32, 3, dil[c], dil[c], hop, 1, 1, 0));
       ProfScope ps(ctx, "voc_lvc");
       dim3 grid(std::max(1, hop / 64), R);
