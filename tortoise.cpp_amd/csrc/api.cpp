@@ -10,6 +10,7 @@ int ar_prefill(tts_ctx *, float *);
 int ar_step(tts_ctx *, const int32_t *, int, float *);
 int ar_latents(tts_ctx *, const int32_t *, int, int, float *);
 int ar_layers(const tts_ctx *);
+float *ar_host_logits(tts_ctx *);
 int diff_layers(const tts_ctx *);
 int diff_forward(tts_ctx *, const float *, int, const float *, int, int, float *);
 int diff_sample(tts_ctx *, const float *, const int32_t *, int, int, const float *, int, float *);
@@ -155,13 +156,19 @@ int tts_sample(tts_ctx *c, const float *logits, const int32_t *ids, int ids_per_
 int tts_autoregressive(tts_ctx *c, const int32_t *text_ids, int n_text, const float *voice, int B, int max_steps,
                        unsigned flags, int32_t *codes_out, int32_t *rows_out, float *latents_out, int32_t *steps_out) {
   NEED_CTX(c);
+  static const bool timing = getenv("TTS_TIMING") != nullptr; // developer aid: host-side breakdown of the stage on stderr
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_begin = now(), t_sample = 0, t_step = 0;
   if (!codes_out || !rows_out) return fail(c, TTS_ERR_ARG, "tts_autoregressive: null output");
   if (max_steps > 500) return fail(c, TTS_ERR_LIMIT, "max_steps %d exceeds the 500 codes apply_padding accepts", max_steps);
   int rc = ar_begin(c, text_ids, n_text, voice, B, max_steps);
   if (rc) return rc;
   const int V = TTS_VOCAB_MEL;
-  std::vector<float> logits((size_t)B * V);
-  if ((rc = ar_prefill(c, logits.data()))) return rc;
+  std::vector<float> logits0((size_t)B * V);
+  const double t_after_begin = now();
+  if ((rc = ar_prefill(c, logits0.data()))) return rc;
+  float *logits = logits0.data(); // after the first step: the pinned buffer the decode graph copies into (no extra host copy)
+  const double t_after_prefill = now();
   // mel_transformer_inputs_vector: [1 ... 1, 8192] per candidate at step 0 (5095-5105), afterwards
   // the previous samples (5208-5217).
   const int P = n_text + 2;
@@ -174,7 +181,9 @@ int tts_autoregressive(tts_ctx *c, const int32_t *text_ids, int n_text, const fl
   for (;;) {
     if (flags & TTS_AR_MASK_STOP)
       for (int b = 0; b < B; b++) logits[(size_t)b * V + 8193] = -1e30f;
-    sample_candidates(c, logits.data(), ids.data(), ids_per_cand, B, samples.data());
+    double t0 = now();
+    sample_candidates(c, logits, ids.data(), ids_per_cand, B, samples.data());
+    t_sample += now() - t0;
     int stops = 0;
     for (int b = 0; b < B; b++) {
       if (!(seq[b].size() > 0 && seq[b].back() == 8193)) seq[b].push_back(samples[b]);
@@ -188,8 +197,12 @@ int tts_autoregressive(tts_ctx *c, const int32_t *text_ids, int n_text, const fl
       if (flags & TTS_AR_MASK_STOP) break;
       return fail(c, TTS_ERR_LIMIT, "no stop token within %d steps", max_steps);
     }
-    if ((rc = ar_step(c, samples.data(), i - 1, logits.data()))) return rc;
+    t0 = now();
+    if ((rc = ar_step(c, samples.data(), i - 1, nullptr))) return rc;
+    logits = ar_host_logits(c);
+    t_step += now() - t0;
   }
+  const double t_after_loop = now();
   if (steps_out) *steps_out = i;
   int max_rows = 0;
   for (int b = 0; b < B; b++) {
@@ -204,7 +217,12 @@ int tts_autoregressive(tts_ctx *c, const int32_t *text_ids, int n_text, const fl
   const int n_mel = std::min(502, max_rows + 1);
   const int n_out = std::min(500, n_mel);
   std::vector<float> lat((size_t)B * n_out * TTS_DMODEL);
+  const double t_before_lat = now();
   if ((rc = ar_latents(c, codes_out, B, n_mel, lat.data()))) return rc;
+  if (timing)
+    fprintf(stderr, "[tts timing] AR: begin %.1f ms, prefill %.1f, loop %.1f (steps %.1f in %d, sampler %.1f), latents %.1f, total %.1f\n",
+            t_after_begin - t_begin, t_after_prefill - t_after_begin, t_after_loop - t_after_prefill, t_step, i - 1, t_sample,
+            now() - t_before_lat, now() - t_begin);
   size_t off = 0;
   for (int b = 0; b < B; b++) {
     std::copy(lat.begin() + (size_t)b * n_out * TTS_DMODEL, lat.begin() + ((size_t)b * n_out + rows_out[b]) * TTS_DMODEL,

@@ -1125,4 +1125,7 @@ int ar_latents(tts_ctx *ctx, const int32_t *codes502, int nb, int n_mel, float *
 
 int ar_layers(const tts_ctx *ctx) { return ctx->ar ? ctx->ar->n_layers : 0; }
 
+// The pinned buffer the decode graph copies the logits into ([B][8194]); valid after ar_step returns.
+float *ar_host_logits(tts_ctx *ctx) { return ctx->ar ? ctx->ar->h_logits : nullptr; }
+
 } // namespace tts
