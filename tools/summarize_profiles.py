@@ -8,6 +8,8 @@ The commands that produce the inputs (on the GPU box):
     TTS_NO_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_e2e -o e2e -- python $R/tools/e2e_once.py 80
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o f -- python $R/tools/diff_prof.py 2
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o w -- python $R/tools/diff_prof.py 2
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmc_mfma -o m -- python $R/tools/diff_prof.py 2
+    python tools/summarize_profiles.py mfma   <m_counter_collection.csv> <out.json> "<note>"
 """
 import csv
 import json
@@ -55,8 +57,35 @@ def pmc(fetch_csv, write_csv, dst, note):
     json.dump(out, open(dst, "w"), indent=1)
 
 
+def mfma(src, dst, note):
+    """MFMA utilisation per kernel = SQ_VALU_MFMA_BUSY_CYCLES / (cycles per SIMD x 1024 SIMDs); GRBM_GUI_ACTIVE is summed
+    over the 8 XCDs (its per-dispatch value / duration = 8 x the shader clock), so cycles per SIMD = GRBM_GUI_ACTIVE / 8."""
+    acc = defaultdict(lambda: defaultdict(float))
+    cnt, dur, seen = defaultdict(int), defaultdict(float), set()
+    for r in csv.DictReader(open(src)):
+        k = r["Kernel_Name"]
+        if not k.startswith(("void tts::", "tts::")):
+            continue
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if (k, r["Dispatch_Id"]) not in seen:
+            seen.add((k, r["Dispatch_Id"]))
+            cnt[k] += 1
+            dur[k] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    out = {"_note": note, "kernels": {}}
+    for k in sorted(acc, key=lambda k: -dur[k]):
+        n, a = cnt[k], acc[k]
+        if a["SQ_VALU_MFMA_BUSY_CYCLES"] <= 0:
+            continue
+        busy, gui, us = a["SQ_VALU_MFMA_BUSY_CYCLES"] / n, a["GRBM_GUI_ACTIVE"] / n, dur[k] / n / 1e3
+        out["kernels"][short(k)] = {"dispatches": n, "avg_us": round(us, 1), "mfma_busy_cycles": int(busy),
+                                    "shader_clock_MHz": round(gui / 8 / us), "mfma_util": round(busy / (gui / 8 * 1024), 4)}
+    json.dump(out, open(dst, "w"), indent=1)
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "mfma":
+        mfma(*sys.argv[2:5])
+    elif sys.argv[1] == "stats":
         stats(*sys.argv[2:5])
     elif sys.argv[1] == "pmc":
         pmc(*sys.argv[2:6])
