@@ -6,6 +6,9 @@
 #include <cstdio>
 #include <vector>
 using namespace tts;
+#ifndef ATT_NR
+#define ATT_NR 3
+#endif
 hipEvent_t tts::prof_event(tts_ctx *) { return nullptr; }
 extern "C" int32_t tts_diffusion_frames(int32_t rows) { return rows * 4 * 24000 / 22050; } // api.cpp is not linked here
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
@@ -31,9 +34,9 @@ int main() {
   CK(hipMemset(tab, 0, 16 * 128 * 4));
   const int nq = (T + 127) / 128;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; i++) diff_attn_kernel<<<nq * 16 * ns, 256, ATT_LDS, 0>>>(qk, vt, ldvt, dst, dln, tab, out, nq);
+  for (int i = 0; i < 3; i++) diff_attn_kernel<ATT_NR><<<nq * 16 * ns, 256, att_lds<ATT_NR>(), 0>>>(qk, vt, ldvt, dst, dln, tab, out, nq);
   CK(hipEventRecord(e0, 0));
-  for (int i = 0; i < 20; i++) diff_attn_kernel<<<nq * 16 * ns, 256, ATT_LDS, 0>>>(qk, vt, ldvt, dst, dln, tab, out, nq);
+  for (int i = 0; i < 20; i++) diff_attn_kernel<ATT_NR><<<nq * 16 * ns, 256, att_lds<ATT_NR>(), 0>>>(qk, vt, ldvt, dst, dln, tab, out, nq);
   CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   double fl = 4.0 * T * (double)T * 64 * 16 * ns;

@@ -223,7 +223,8 @@ __global__ __launch_bounds__(256) void to_f16_kernel(const float *__restrict__ x
 // bias = tab[(q<k)*64 + min(|k-q|,63)] (32-bucket table x8, expanded per distance at load time); blocks
 // of keys at least 63 away from every query of the wave use the saturated constant.
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-static constexpr int ATT_TAB = 320, ATT_LDS = 3 * 16384 + ATT_TAB * 4;
+static constexpr int ATT_TAB = 320;
+template <int NR> constexpr int att_lds() { return NR * 16384 + ATT_TAB * 4; }
 #ifdef TTS_ATT_TRACE // developer build (tools/attn_bench.hip): per-tile phase timestamps of wave 0 of workgroup 0
 __device__ long long tts_att_trace[64 * 8];
 #define ATT_CLK(j) do { if (blockIdx.x == TTS_ATT_TRACE && threadIdx.x == 0) { tts_att_trace[63 * 8 + 2 * (j)] = __builtin_readcyclecounter(); tts_att_trace[63 * 8 + 2 * (j) + 1] = wall_clock64(); } } while (0)
@@ -249,14 +250,15 @@ __device__ __forceinline__ float rows4_sum(float x) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-__global__ __launch_bounds__(256) void diff_attn_kernel(const __half *__restrict__ qk, const __half *__restrict__ vt, int ldvt,
+template <int NR> // K/V ring depth: 3 = two tiles in flight, 3 workgroups per CU; 2 = one tile in flight, 4 workgroups per CU
+__global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const __half *__restrict__ qk, const __half *__restrict__ vt, int ldvt,
                                                         const int *__restrict__ seq_start, const int *__restrict__ seq_len,
                                                         const float *__restrict__ bias_tab, __half *__restrict__ out, int nq) {
   // ONE LDS object: with a second __shared__ variable hipcc puts an s_waitcnt vmcnt(0) in front of the first
   // ds_read of every tile, which drains the DMA prefetch (seen in the ISA; cdna_hip_programming.md §5 trap (a)).
   // (dynamic LDS: with a static array the DMA writes and the fragment reads alias for the waitcnt pass as well)
   extern __shared__ __attribute__((aligned(16))) char smem[]; // 3 x (K tile 8 KB | V^T tile 8 KB) + bias table
-  float *tab = (float *)(smem + 3 * 16384);
+  float *tab = (float *)(smem + NR * 16384);
   // XCD-aware block order: workgroup id b runs on XCD b % 8, so all q-blocks of one (sequence, head) pair
   // get ids congruent mod 8 and reuse that pair's K/V tiles from one L2 (16 heads => pairs % 8 == 0).
   const int xcd = blockIdx.x & 7, tt = blockIdx.x >> 3;
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(256) void diff_attn_kernel(const __half *__restrict
   };
   ATT_CLK(0);
   stage(0, 0);
-  stage(1, 1);
+  if (NR == 3) stage(1, 1);
   half8 ones;
 #pragma unroll
   for (int e = 0; e < 8; e++) ones[e] = (_Float16)1.0f;
@@ -348,13 +350,14 @@ __global__ __launch_bounds__(256) void diff_attn_kernel(const __half *__restrict
     // Tile kb must have landed; the 4 DMA pieces of tile kb+1 may stay in flight across the barrier
     // (counted vmcnt + raw s_barrier: __syncthreads() would drain the prefetch).
     ATT_T(0);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (NR == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ATT_T(1);
     __builtin_amdgcn_s_barrier();
     ATT_T(2);
-    // every wave has passed the barrier => nobody still reads tile kb-1, whose slot receives tile kb+2
-    stage(kb + 2, (kb + 2) % 3);
-    const char *Ks = smem + (kb % 3) * 16384, *Vs = Ks + 8192;
+    // every wave has passed the barrier => nobody still reads tile kb-1, whose slot receives the next tile to stage
+    stage(kb + NR - 1, (kb + NR - 1) % NR);
+    const char *Ks = smem + (kb % NR) * 16384, *Vs = Ks + 8192;
     ATT_T(3);
     floatx4 sc[2][4];
     scores(Ks, sc);
@@ -936,7 +939,12 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
     for (int l : lay.len) aw += 4.0 * l * (double)l * 64 * NHEAD; // QK^T + PV
     ProfScope ps(ctx, "diff_attn", aw);
     const int nq = (lay.max_len() + 127) / 128;
-    diff_attn_kernel<<<nq * NHEAD * lay.ns, 256, ATT_LDS, ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128,
+    // measured (interleaved A/B, tools/diff_prof.py): 4 workgroups per CU with one tile in flight 162.5-163.0 us per
+    // launch, 3 workgroups with two tiles in flight 168.2-168.9 us
+    static const bool ring2 = getenv("TTS_ATT_RING3") == nullptr; // A/B switch
+    if (ring2) diff_attn_kernel<2><<<nq * NHEAD * lay.ns, 256, att_lds<2>(), ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128,
+                                                                   lay.d_start.as<int>(), lay.d_len.as<int>(), w.bias_tab, wk.ATT16(), nq);
+    else diff_attn_kernel<3><<<nq * NHEAD * lay.ns, 256, att_lds<3>(), ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128,
                                                                    lay.d_start.as<int>(), lay.d_len.as<int>(), w.bias_tab, wk.ATT16(), nq);
     TTS_HIP(ctx, hipGetLastError());
   }
