@@ -167,7 +167,7 @@ typedef void __attribute__((address_space(3))) *lptr_t;
 // activation rows), so a lane's 4 accumulator registers are 4 CONSECUTIVE output columns of one row:
 // residual loads and stores are 16 bytes per lane instead of 4. The QKV mode keeps the natural order
 // (a lane holds 4 consecutive rows of one column) because V is stored transposed.
-template <int MODE, int MI>
+template <int MODE, int MI, bool RESID_IN_ACC = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, floatx4 (&acc)[MI][4], int m0, int n0, int wm, int wn, int fr, int fq) {
   if (MODE == GEMM_OUT_QKV) {
     // col = h*192 + {q 0..63 | k 64..127 | v 128..191}; a wave's 64-column span is entirely q, k or v.
@@ -233,7 +233,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, floatx4 (&acc)[
           v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         }
         if (MODE == GEMM_OUT_F32) {
-          if (g.resid) {
+          if (g.resid && !RESID_IN_ACC) {
             const float4 rr = *(const float4 *)(g.resid + (size_t)row * g.ldo + col);
             v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
           }
@@ -248,6 +248,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs &g, floatx4 (&acc)[
           *(uint2 *)(g.outH + (size_t)row * g.ldh + col) = u;
         }
       }
+    }
+  }
+}
+
+// Accumulators start from the residual (F32 outputs, swapped operand order: acc[i][j] = 4 consecutive columns of
+// one row): the residual read is issued with the first operand tile and hides behind it, instead of being a
+// dependent HBM round trip in front of the stores when the K loop is over. The sum is the same set of f32 adds in
+// a different order (the product sums land on the residual one MFMA at a time).
+template <int MI>
+__device__ __forceinline__ void gemm_acc_from_resid(const GemmArgs &g, floatx4 (&acc)[MI][4], int m0, int n0, int wm, int wn, int fr, int fq) {
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+    const int row = min(m0 + wm * (16 * MI) + i * 16 + fr, g.M - 1);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float4 rr = *(const float4 *)(g.resid + (size_t)row * g.ldo + n0 + wn * 64 + j * 16 + fq * 4);
+      acc[i][j] = (floatx4){rr.x, rr.y, rr.z, rr.w};
     }
   }
 }
@@ -287,12 +304,16 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g
     const int row = (wave * 4 + i) * 8 + prow;
     boff[i] = (n0 + row) * ldw + (pslot ^ ((row >> 1) & 7)) * 8;
   }
-  floatx4 acc[MI][4];
-#pragma unroll
-  for (int i = 0; i < MI; i++)
-#pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
   const int fr = lane & 15, fq = lane >> 4;
+  const bool resid_first = MODE == GEMM_OUT_F32 && g.resid != nullptr;
+  floatx4 acc[MI][4];
+  if (resid_first) gemm_acc_from_resid<MI>(g, acc, m0, n0, wm, wn, fr, fq);
+  else {
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  }
   char *sa = smem, *sb = smem + BM * 128;
   // operand order (see gemm_epilogue): natural only for the V columns of a QKV projection (wave-uniform)
   const bool natural = (MODE == GEMM_OUT_QKV) && (((n0 + wn * 64) % 192) >= 128);
@@ -330,7 +351,8 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g
   };
   if (MODE == GEMM_OUT_QKV && natural) kloop(std::true_type{});
   else kloop(std::false_type{});
-  gemm_epilogue<MODE, MI>(g, acc, m0, n0, wm, wn, fr, fq);
+  if (resid_first) gemm_epilogue<MODE, MI, true>(g, acc, m0, n0, wm, wn, fr, fq);
+  else gemm_epilogue<MODE, MI>(g, acc, m0, n0, wm, wn, fr, fq);
 }
 
 // k = 3 convolution as ONE GEMM with a shared activation slab. The three taps are three row-shifted GEMM
@@ -359,12 +381,14 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_kernel(GemmArgs 
   const int m0 = (mfirst + rem / cn) * BM, n0 = (chunk * cn + rem % cn) << 7;
   const int nchunks = g.kseg >> 6, ldw = 3 * g.kseg, nph = 3 * nchunks;
   const int prow = lane >> 3, pslot = lane & 7;
+  const int fr = lane & 15, fq = lane >> 4;
+  // (residual-first accumulators, as in gemm_f16_glds_kernel, were measured SLOWER here: 237-249 vs 216-225 us —
+  //  the pending residual loads sit in front of the pipelined weight DMA in the in-order vmcnt queue)
   floatx4 acc[MI][4];
 #pragma unroll
   for (int i = 0; i < MI; i++)
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
-  const int fr = lane & 15, fq = lane >> 4;
   char *sa = smem, *sb = smem + SLAB;
   // slab row s = activation row m0 - 1 + s (the buffer has its guard rows, as for the plain segments)
   const __half *abase = g.A[0] + (ptrdiff_t)(m0 - 1) * g.lda;
