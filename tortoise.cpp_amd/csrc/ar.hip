@@ -331,8 +331,10 @@ struct DecLnArgs {
   const float *g1, *b1;      // DEC_LOGITS: ln_f (the LayerNorm feeding W is folded into W/bias at load)
   const float *W;            // pack_mfma16 of diag(gamma) W
   const float *bias;         // bias + beta . W
-  int rows, n_valid, ldo;
-  float *out;                // q [rows][1024] | ff [rows][4096] | logits [rows][ldo]
+  int rows, n_valid, ldo;    // ldo: row stride of `out` for DEC_QKV (q) and DEC_LOGITS
+  int prefill_B;             // DEC_QKV: 0 = decode (row = candidate, position n_past); > 0 = prompt pass (row = position,
+                             // K/V replicated into the caches of prefill_B candidates)
+  float *out;                // q [rows][ldo] | ff [rows][4096] | logits [rows][ldo]
   __half *kc, *vc;           // layer's caches [cand][max_pos][1024]
   const StepState *ss;
   int max_pos, lut;
@@ -434,13 +436,15 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
     const int sec = col >> 10, cc = col & (D - 1);
     if (sec == 0) {
       const float2 f01 = __half22float2(h01), f23 = __half22float2(h23);
-      *(float4 *)(a.out + (size_t)row * D + cc) = make_float4(f01.x, f01.y, f23.x, f23.y);
+      *(float4 *)(a.out + (size_t)row * a.ldo + cc) = make_float4(f01.x, f01.y, f23.x, f23.y);
     } else {
-      __half *dst = (sec == 1 ? a.kc : a.vc) + ((size_t)row * a.max_pos + a.ss->n_past) * D + cc;
       uint2 u;
       u.x = *(const unsigned *)&h01;
       u.y = *(const unsigned *)&h23;
-      *(uint2 *)dst = u;
+      __half *base = (sec == 1 ? a.kc : a.vc) + cc;
+      if (a.prefill_B == 0) *(uint2 *)(base + ((size_t)row * a.max_pos + a.ss->n_past) * D) = u;
+      else
+        for (int c = 0; c < a.prefill_B; c++) *(uint2 *)(base + ((size_t)c * a.max_pos + row) * D) = u;
     }
   } else if (EPI == DEC_GELU) {
     v.x = gelu_tanh(v.x, a.lut); v.y = gelu_tanh(v.y, a.lut); v.z = gelu_tanh(v.z, a.lut); v.w = gelu_tanh(v.w, a.lut);
@@ -960,26 +964,6 @@ static int embed(tts_ctx *ctx, ArState *st, const std::vector<int4> &desc) {
   return TTS_OK;
 }
 
-// ln_f -> lm_head.0 LayerNorm -> lm_head.1 on `rows` rows starting at h_rows; logits to host.
-static int head_logits(tts_ctx *ctx, ArState *st, const float *h_rows, int rows, float *logits_host, int replicate) {
-  float *xn = st->xn.as<float>(), *hn = st->hn.as<float>();
-  layernorm_kernel<<<rows, 256, 0, ctx->stream>>>(h_rows, st->lnf_g, st->lnf_b, xn);
-  layernorm_kernel<<<rows, 256, 0, ctx->stream>>>(xn, st->lmh_g, st->lmh_b, hn);
-  int ks;
-  CHECK(launch_gemv(ctx, st, hn, D, rows, st->lm_w, VPAD, D, &ks));
-  TTS_HIP(ctx, st->logits.reserve((size_t)rows * V * 4));
-  KvDst nokv{nullptr, nullptr, 1, 0, 0, 0};
-  CHECK(launch_epilogue<EPI_BIAS>(ctx, st, ks, rows, VPAD, V, st->lm_b, st->logits.as<float>(), V, nokv));
-  if (logits_host) {
-    TTS_HIP(ctx, hipMemcpyAsync(logits_host, st->logits.p, (size_t)rows * V * 4, hipMemcpyDeviceToHost, ctx->stream));
-    TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int c = 1; c < replicate; c++) memcpy(logits_host + (size_t)c * V, logits_host, (size_t)V * 4);
-  } else {
-    TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  return TTS_OK;
-}
-
 int ar_begin(tts_ctx *ctx, const int32_t *text_ids, int n_text, const float *voice, int B, int max_steps) {
   ArState *st = ctx->ar;
   if (!st) return fail(ctx, TTS_ERR_STATE, "AR model not loaded");
@@ -1019,8 +1003,40 @@ int ar_prefill(tts_ctx *ctx, float *logits_out) {
   desc[P - 1] = make_int4(2, 8192, 1, 0);
   CHECK(embed(ctx, st, desc));
   const size_t layer_stride = (size_t)st->B * st->max_pos * D;
-  CHECK(run_layers(ctx, st, P, P, 0, st->kcache.as<__half>(), st->vcache.as<__half>(), layer_stride, st->max_pos, st->B));
-  return head_logits(ctx, st, st->h.as<float>() + (size_t)(P - 1) * D, 1, logits_out, st->B);
+  // The prompt pass runs on the decode-step kernels, tiled over 16 positions (exact f32, weights re-read from L2 per
+  // tile): rows are positions of the one shared prompt, the QKV epilogue replicates K/V into every candidate's cache.
+  const int tiles = (P + 15) / 16;
+  float *h = st->h.as<float>(), *qkv = st->qkv.as<float>(), *att = st->att.as<float>(), *ff = st->ff.as<float>();
+  for (int l = 0; l < st->n_layers; l++) {
+    const ArLayerDev &w = st->L[l];
+    __half *kc = st->kcache.as<__half>() + l * layer_stride, *vc = st->vcache.as<__half>() + l * layer_stride;
+    { ProfScope ps(ctx, "ar_gemv", 3.0 * D * D * 4.0 * tiles);
+      DecLnArgs a{h, nullptr, nullptr, w.d_attn, w.db_attn, P, 3 * D, 3 * D, st->B, qkv, kc, vc, nullptr, st->max_pos, ctx->ggml_lut};
+      dec_ln_gemv_kernel<DEC_QKV><<<dim3(3 * D / 16, tiles), 256, 0, ctx->stream>>>(a); }
+    { ProfScope ps(ctx, "ar_attention");
+      attention_kernel<<<dim3(P, NH), 64, 0, ctx->stream>>>(qkv, kc, vc, att, P, 0, st->max_pos, ctx->ggml_lut); }
+    { ProfScope ps(ctx, "ar_gemv", 1.0 * D * D * 4.0 * tiles);
+      dec_gemv_resid_kernel<1><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, P, w.d_proj, w.b_proj, h); }
+    { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * 4.0 * tiles);
+      DecLnArgs a{h, nullptr, nullptr, w.d_fc, w.db_fc, P, FF, 0, 0, ff, nullptr, nullptr, nullptr, 0, ctx->ggml_lut};
+      dec_ln_gemv_kernel<DEC_GELU><<<dim3(FF / 16, tiles), 256, 0, ctx->stream>>>(a); }
+    { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * 4.0 * tiles);
+      dec_gemv_resid_kernel<4><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(ff, P, w.d_fc2, w.b_fc2, h); }
+  }
+  TTS_HIP(ctx, st->logits.reserve((size_t)V * 4));
+  { ProfScope ps(ctx, "ar_gemv", (double)D * VPAD * 4.0);
+    DecLnArgs a{h + (size_t)(P - 1) * D, st->lnf_g, st->lnf_b, st->d_lm, st->d_lmb, 1, V, V, 0, st->logits.as<float>(),
+                nullptr, nullptr, nullptr, 0, ctx->ggml_lut};
+    dec_ln_gemv_kernel<DEC_LOGITS><<<dim3(VPAD / 16, 1), 256, 0, ctx->stream>>>(a); }
+  TTS_HIP(ctx, hipGetLastError());
+  if (logits_out) {
+    TTS_HIP(ctx, hipMemcpyAsync(logits_out, st->logits.p, (size_t)V * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int c = 1; c < st->B; c++) memcpy(logits_out + (size_t)c * V, logits_out, (size_t)V * 4);
+  } else {
+    TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return TTS_OK;
 }
 
 // One decode step for all candidates, enqueued on the ctx stream (captured once into a hipGraph): five
@@ -1037,20 +1053,20 @@ static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
     const ArLayerDev &w = st->L[l];
     __half *kc = st->kcache.as<__half>() + l * layer_stride, *vc = st->vcache.as<__half>() + l * layer_stride;
     { ProfScope ps(ctx, "ar_gemv", 3.0 * D * D * 4.0 * tiles);
-      DecLnArgs a{h, nullptr, nullptr, w.d_attn, w.db_attn, B, 3 * D, 0, q, kc, vc, ss, st->max_pos, ctx->ggml_lut};
+      DecLnArgs a{h, nullptr, nullptr, w.d_attn, w.db_attn, B, 3 * D, D, 0, q, kc, vc, ss, st->max_pos, ctx->ggml_lut};
       dec_ln_gemv_kernel<DEC_QKV><<<dim3(3 * D / 16, tiles), 256, 0, ctx->stream>>>(a); }
     { ProfScope ps(ctx, "ar_attention");
       attn_decode_kernel<<<dim3(B, NH), 256, 0, ctx->stream>>>(q, kc, vc, ss, st->max_pos, att, ctx->ggml_lut); }
     { ProfScope ps(ctx, "ar_gemv", 1.0 * D * D * 4.0 * tiles);
       dec_gemv_resid_kernel<1><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, w.d_proj, w.b_proj, h); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * 4.0 * tiles);
-      DecLnArgs a{h, nullptr, nullptr, w.d_fc, w.db_fc, B, FF, 0, ff, nullptr, nullptr, ss, 0, ctx->ggml_lut};
+      DecLnArgs a{h, nullptr, nullptr, w.d_fc, w.db_fc, B, FF, 0, 0, ff, nullptr, nullptr, ss, 0, ctx->ggml_lut};
       dec_ln_gemv_kernel<DEC_GELU><<<dim3(FF / 16, tiles), 256, 0, ctx->stream>>>(a); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * 4.0 * tiles);
       dec_gemv_resid_kernel<4><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(ff, B, w.d_fc2, w.b_fc2, h); }
   }
   { ProfScope ps(ctx, "ar_gemv", (double)D * VPAD * 4.0 * tiles);
-    DecLnArgs a{h, st->lnf_g, st->lnf_b, st->d_lm, st->d_lmb, B, V, V, st->logits.as<float>(),
+    DecLnArgs a{h, st->lnf_g, st->lnf_b, st->d_lm, st->d_lmb, B, V, V, 0, st->logits.as<float>(),
                 nullptr, nullptr, ss, 0, ctx->ggml_lut};
     dec_ln_gemv_kernel<DEC_LOGITS><<<dim3(VPAD / 16, tiles), 256, 0, ctx->stream>>>(a); }
   TTS_HIP(ctx, hipMemcpyAsync(st->h_logits, st->logits.p, (size_t)B * V * 4, hipMemcpyDeviceToHost, ctx->stream));
