@@ -123,6 +123,8 @@ def main():
         dist.barrier()
 
     eng = pkg.Engine(local_rank)  # raises without the HIP library/device: there is no fallback path
+    if world > 1:  # N processes share the host: leave each rank's sampler pool its share of the cores
+        eng.set_option("sampler_threads", max(0, min(7, (os.cpu_count() or 8) // world - 2)))
     eng.load(model_dir)
     B, S = a.candidates, a.decode_steps
     toks = synthetic_prompt()

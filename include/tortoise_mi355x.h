@@ -49,7 +49,9 @@ void tts_destroy(tts_ctx *ctx);
 const char *tts_last_error(const tts_ctx *ctx);
 /* Options (all have reference defaults): "gn_eps" (1e-6; ggml's GroupNorm epsilon),
  * "ggml_lut" (0/1: emulate ggml-CPU fp16 lookup tables for GELU/SiLU),
- * "prof_only:<family>" (1: restrict profiling to one kernel family, 0: all). */
+ * "prof_only:<family>" (1: restrict profiling to one kernel family, 0: all),
+ * "sampler_threads" (-1 default = min(7, hardware threads - 1); 0 = sample on the calling thread; the token ids
+ * do not depend on it: the RNG is consumed in candidate order before the per-candidate scans run). */
 int tts_set_option(tts_ctx *ctx, const char *key, double value);
 
 /* ---- weight files (drop-in format: magic 0x67676d6c + name-keyed F32 records) ------------- */

@@ -81,6 +81,10 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
   if (k == "gn_eps") c->gn_eps = (float)value;
   else if (k == "ggml_lut") c->ggml_lut = value != 0;
   else if (k.rfind("prof_only:", 0) == 0) c->prof_filter = value != 0 ? k.substr(10) : std::string();
+  else if (k == "sampler_threads") { // worker threads for the per-candidate sampler scans (0 = run them on the caller)
+    if (c->sampler_pool) { sampler_pool_free(c->sampler_pool); c->sampler_pool = nullptr; }
+    c->sampler_threads = value < 0 ? -1 : (int)value;
+  }
   else return fail(c, TTS_ERR_ARG, "unknown option '%s'", key);
   return TTS_OK;
 }

@@ -76,6 +76,7 @@ struct tts_ctx {
   tts::VocState *voc = nullptr;
   tts::Tokenizer *tok = nullptr;
   tts::SamplerPool *sampler_pool = nullptr; // worker threads for the per-candidate sampler scans (host_logic.cpp)
+  int sampler_threads = -1;                 // -1: min(7, hardware threads - 1); option "sampler_threads"
   // profiling: per kernel family, HIP event pairs recorded on the ctx stream around every launch and
   // resolved lazily (no host sync inside the timed region)
   bool prof_on = false;

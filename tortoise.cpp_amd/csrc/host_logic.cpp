@@ -347,10 +347,11 @@ void sample_candidates(tts_ctx *ctx, const float *logits, const int32_t *ids, in
     samples[c] = sample;
   }
   auto one = [&](int c) { out[c] = sample_one(logits + (size_t)c * V, ids + (size_t)c * ids_per_cand, ids_per_cand, samples[c]); };
-  if (B < 4) { for (int c = 0; c < B; c++) one(c); return; }
+  if (B < 4 || ctx->sampler_threads == 0) { for (int c = 0; c < B; c++) one(c); return; }
   if (!ctx->sampler_pool) {
     const int hw = (int)std::thread::hardware_concurrency();
-    ctx->sampler_pool = new SamplerPool(std::max(1, std::min(7, hw - 1)));
+    const int n = ctx->sampler_threads > 0 ? ctx->sampler_threads : std::max(1, std::min(7, hw - 1));
+    ctx->sampler_pool = new SamplerPool(n);
   }
   ctx->sampler_pool->run(B, one);
 }
