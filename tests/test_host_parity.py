@@ -101,7 +101,7 @@ def test_sampler_fuzz_vs_reference(host, oracle):
         pytest.skip("oracle/_ref/libref.so not built (no /root/reference)")
     rs = np.random.RandomState(1)
     for trial in range(150):
-        B = rs.randint(1, 6)
+        B = 16 if trial % 10 == 9 else rs.randint(1, 6)  # B >= 4 runs on the sampler thread pool
         scale = rs.choice([0.3, 1.0, 3.0, 8.0])
         logits = (rs.randn(B, 8194) * scale).astype(np.float32)
         if trial % 5 == 0:  # ties at the top-k boundary and among survivors
