@@ -217,7 +217,7 @@ def main():
                                                                                   " [QUICK: reduced layer counts]" if a.quick else ""),
                    "candidates_per_gpu": B, "diffusion_steps": a.diff_steps, "decode_steps": S, "parallelism": "candidate-parallel x%d" % world},
         "stage_ms_per_step": {k: round(v / a.steps, 1) for k, v in stage_ms.items()},
-        "roofline": {"kernel": "gemm_f16_kernel (diffusion convs/projections)", "bound": "mfma", "achieved": round(achieved, 1),
+        "roofline": {"kernel": "gemm_f16_glds_kernel + gemm_f16_conv3_kernel (diffusion convs/projections)", "bound": "mfma", "achieved": round(achieved, 1),
                      "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
                      "traffic": traffic, "launches": int(g_n), "avg_launch_us": round(1000.0 * g_ms / max(g_n, 1), 2),
                      "algorithmic_gflop_per_launch": round(g_flops / max(g_n, 1) / 1e9, 2)},
