@@ -14,9 +14,10 @@ def _latents(L, seed):
 
 
 # L=100 (T=435): attention tiles that are far from the diagonal and not the tail tile (constant-bias path);
-# L=250 (T=1088): the 1024-thread GroupNorm path (T > 896) and several query blocks per sequence
+# L=250 (T=1088): the 1024-thread GroupNorm path (T > 896) and several query blocks per sequence;
+# L=500 (T=2176): the largest sequence the AR stage can produce (500 latent rows)
 @pytest.mark.parametrize("models,L,timestep", [("small", 12, 3999), ("small", 43, 51), ("mid", 43, 2025), ("small", 1, 0),
-                                               ("small", 100, 1000), ("small", 250, 500)])
+                                               ("small", 100, 1000), ("small", 250, 500), ("small", 500, 100)])
 @pytest.mark.parametrize("cond_free", [False, True])
 def test_forward_matches_oracle(engine, oracle, small_models, mid_models, models, L, timestep, cond_free):
     """One diffusion_graph evaluation (eps | variance logits), conditioned and conditioning-free."""
