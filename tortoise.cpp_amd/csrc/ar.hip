@@ -569,6 +569,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float *__restric
   const __half *kb = kc + (size_t)c * max_pos * D + h * HD;
   const __half *vb = vc + (size_t)c * max_pos * D + h * HD;
   if (tid < HD) qs[tid] = qbuf[(size_t)c * D + h * HD + tid];
+  // V rows of the first PV batch do not depend on the scores: request them now, they arrive under the score phase
+  const int dl = tid & 15, grp = tid >> 4;
+  uint2 vv0[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    const int j = grp + u * 16;
+    vv0[u] = (j < nk) ? *(const uint2 *)(vb + (size_t)j * D + dl * 4) : make_uint2(0u, 0u);
+  }
   __syncthreads();
   float mx = -INFINITY;
   for (int j = tid; j < nk; j += 256) {
@@ -608,14 +616,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float *__restric
   __syncthreads();
   const float inv = 1.0f / (((wred[4] + wred[5]) + wred[6]) + wred[7]);
   // PV: 16 key groups x 16 lanes; a lane owns 4 consecutive dims (8-byte loads), keys j = grp, grp+16, ...
-  const int dl = tid & 15, grp = tid >> 4;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   for (int j0 = grp; j0 < nk; j0 += 16 * 8) {
     uint2 vv[8];
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int j = j0 + u * 16;
-      vv[u] = (j < nk) ? *(const uint2 *)(vb + (size_t)j * D + dl * 4) : make_uint2(0u, 0u);
+      if (j0 == grp) vv[u] = vv0[u];
+      else vv[u] = (j < nk) ? *(const uint2 *)(vb + (size_t)j * D + dl * 4) : make_uint2(0u, 0u);
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
