@@ -94,3 +94,30 @@ def test_vocoder_batch_invariance(engine, mid_models):
         solo = engine.vocoder([mels[c]], noise=[noise[c]])[0]
         scale = np.abs(solo).max()
         assert np.abs(solo - batch[c]).max() <= 1e-5 * scale, c
+
+
+def test_cli_end_to_end(small_models, tmp_path):
+    """The drop-in CLI (reference flags + --models/--codes) writes a 24 kHz float WAV; same seed -> same bytes."""
+    import os, shutil, struct, subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tortoise.cpp_amd", "tortoise")
+    if not os.path.exists(exe):
+        pytest.skip("CLI binary not built")
+    d = tmp_path / "models"
+    d.mkdir()
+    for f in ("ggml-model.bin", "ggml-diffusion-model.bin", "ggml-vocoder-model.bin"):
+        os.symlink(os.path.join(small_models, f), d / f)
+    shutil.copy(os.path.join(ROOT, "models", "tokenizer.json"), d / "tokenizer.json")
+    outs = []
+    for k in range(2):
+        out = tmp_path / ("out%d.wav" % k)
+        r = subprocess.run([exe, "--models", str(d), "--message", "this is a test message.", "--voice",
+                            os.path.join(ROOT, "models", "mol.bin"), "--seed", "0", "--codes", "24", "--steps", "4",
+                            "--output", str(out)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        outs.append(out.read_bytes())
+    b = outs[0]
+    assert b[:4] == b"RIFF" and b[8:12] == b"WAVE"
+    fmt_tag, channels, rate = struct.unpack("<HHI", b[20:28])
+    assert (fmt_tag, channels, rate) == (3, 1, 24000)  # IEEE float, mono, 24 kHz (main.cpp:4821-4868)
+    assert len(b) > 44 + 4 * 24000 // 10 and outs[0] == outs[1]

@@ -30,7 +30,7 @@ int main(int argc, char **argv) {
   std::string outputPath = "./output.wav";
   std::string modelsDir = "../models";
   bool have_seed = false;
-  int seed = 0, candidates = 1, steps = 80, device = 0;
+  int seed = 0, candidates = 1, steps = 80, device = 0, fixed_codes = 0;
   for (int i = 1; i < argc - 1; ++i) {
     std::string a(argv[i]);
     if (a == "--voice") voicePath = argv[i + 1];
@@ -41,6 +41,7 @@ int main(int argc, char **argv) {
     else if (a == "--candidates") candidates = std::stoi(argv[i + 1]);
     else if (a == "--steps") steps = std::stoi(argv[i + 1]);
     else if (a == "--device") device = std::stoi(argv[i + 1]);
+    else if (a == "--codes") fixed_codes = std::stoi(argv[i + 1]); // exactly N sampled codes, stop token masked (synthetic weights never stop)
   }
   tts_ctx *ctx = tts_create(device);
   if (!ctx) {
@@ -65,7 +66,8 @@ int main(int argc, char **argv) {
   std::vector<int32_t> codes((size_t)B * 502), rows(B);
   std::vector<float> latents((size_t)B * 500 * 1024);
   int32_t nsteps = 0;
-  if (tts_autoregressive(ctx, tokens.data(), n, voice.data(), B, 500, 0, codes.data(), rows.data(), latents.data(), &nsteps))
+  if (tts_autoregressive(ctx, tokens.data(), n, voice.data(), B, fixed_codes > 0 ? fixed_codes : 500, fixed_codes > 0 ? TTS_AR_MASK_STOP : 0,
+                         codes.data(), rows.data(), latents.data(), &nsteps))
     return die(ctx, "autoregressive");
   printf("tokens sampled: %d\n", nsteps);
 
