@@ -97,8 +97,11 @@ def test_autoregressive_driver(engine, oracle, small_models, voice, B, seed):
         for i in range(step):
             lo, lg = ar.step(codes_o[:, 1 + i], i), engine.ar_step(codes_o[:, 1 + i], i)
         assert rel_err(lg, lo) < 1e-4
-        pytest.skip("trajectories split at candidate %d step %d with logits within %.1e (fp16-QKV rounding flip)"
-                    % (c, step, rel_err(lg, lo)))
+        print("trajectories split at candidate %d step %d with logits within %.1e (fp16-QKV rounding flip); "
+              "bookkeeping and latents are checked on the device's own codes" % (c, step, rel_err(lg, lo)))
+        # up to the split everything is identical, and every other candidate's stream is untouched by it
+        assert (codes_g[:, :j] == codes_o[:, :j]).all()
+        codes_o = codes_g  # from here on: the oracle is driven with the device's trajectory
     for c in range(B):
         assert rows_g[c] == oracle.trimmed_rows(codes_o[c])
     lat_o = ar.latents(codes_o, min(502, int(rows_g.max()) + 1))
