@@ -48,6 +48,7 @@ int main() {
     CK(hipMemcpy(hres, d, 24, hipMemcpyDeviceToHost));
     printf("cycle counter: %lld ticks in %.1f us -> %.0f MHz\n", hres[0], hres[1] * 0.01, hres[0] / (hres[1] * 0.01));
   }
+#ifdef TTS_ATT_TRACE
   std::vector<long long> t(64 * 8);
   CK(hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(tts_att_trace), t.size() * 8));
   printf("traced workgroup: %lld cycles in %.2f us -> %.0f MHz\n", t[63 * 8 + 2] - t[63 * 8], (t[63 * 8 + 3] - t[63 * 8 + 1]) * 0.01,
@@ -58,5 +59,6 @@ int main() {
     printf("  %2d: %6lld %6lld %6lld %6lld %6lld %6lld | %6lld\n", kb, p[1] - p[0], p[2] - p[1], p[3] - p[2], p[4] - p[3], p[5] - p[4], p[6] - p[5],
            kb + 1 < 14 ? t[(kb + 1) * 8] - p[0] : p[6] - p[0]);
   }
+#endif
   return 0;
 }
