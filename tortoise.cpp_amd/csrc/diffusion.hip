@@ -27,12 +27,16 @@ static constexpr int C = 1024, NHEAD = 16, XTC = 128 /* x_t channels padded 100 
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
+// SiLU. The default path is x * rcp(1 + exp2(-x log2 e)) on the hardware exp2/rcp (about 1e-7 relative, the result is
+// rounded to an fp16 GEMM operand right after): libm's expf plus an IEEE division cost ~30 VALU instructions per
+// element and made the GroupNorm kernel VALU-bound instead of HBM-bound (seen in its ISA: 2100 instructions per
+// thread). lut = 1 (option "ggml_lut") keeps the exact fp16-table emulation.
 __device__ __forceinline__ float silu_dev(float x, int lut) {
   if (lut) {
     float xr = __half2float(__float2half_rn(x));
     return __half2float(__float2half_rn(xr / (1.0f + expf(-xr))));
   }
-  return x / (1.0f + expf(-x));
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896f));
 }
 
 // GroupNorm statistics, 32 groups of 32 channels over the T rows of one sequence (ggml_group_norm on
@@ -884,27 +888,35 @@ __global__ __launch_bounds__(NT) void gn_reg_kernel(int getenv_gn_xcd, const flo
   for (int w = 0; w < NW; w++) tsq += sh[1][w];
   const float rstd = 1.0f / sqrtf(tsq / n + eps);
   const float ge[4] = {gg.x, gg.y, gg.z, gg.w}, be[4] = {bb.x, bb.y, bb.z, bb.w};
+  // the activation mode is workgroup-uniform: one copy of the unrolled store loop per mode, no per-element branch
+  auto apply = [&](auto mode) {
+    constexpr int MODE = decltype(mode)::value; // 0 none, 1 SiLU, 2 SiLU through the fp16 table emulation
 #pragma unroll
-  for (int j = 0; j < NJ; j++) {
-    const int t = t0 + j * SWEEP;
-    if (t < T) {
-      float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+    for (int j = 0; j < NJ; j++) {
+      const int t = t0 + j * SWEEP;
+      if (t < T) {
+        float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        float u = e[i] * rstd;
-        u = u * ge[i];
-        u = u + be[i];
-        if (ss) { u = u * sc4[i]; u = u + sh4[i]; }
-        if (do_silu) u = silu_dev(u, lut);
-        e[i] = u;
+        for (int i = 0; i < 4; i++) {
+          float u = e[i] * rstd;
+          u = u * ge[i];
+          u = u + be[i];
+          u = u * sc4[i]; // (1, 0 without scale/shift: exact no-ops)
+          u = u + sh4[i];
+          if (MODE) u = silu_dev(u, MODE == 2);
+          e[i] = u;
+        }
+        const __half2 p0 = __floats2half2_rn(e[0], e[1]), p1 = __floats2half2_rn(e[2], e[3]);
+        uint2 o;
+        o.x = *(const unsigned *)&p0;
+        o.y = *(const unsigned *)&p1;
+        *(uint2 *)(y + (size_t)(r0 + t) * C + c) = o;
       }
-      const __half2 p0 = __floats2half2_rn(e[0], e[1]), p1 = __floats2half2_rn(e[2], e[3]);
-      uint2 o;
-      o.x = *(const unsigned *)&p0;
-      o.y = *(const unsigned *)&p1;
-      *(uint2 *)(y + (size_t)(r0 + t) * C + c) = o;
     }
-  }
+  };
+  if (!do_silu) apply(std::integral_constant<int, 0>{});
+  else if (!lut) apply(std::integral_constant<int, 1>{});
+  else apply(std::integral_constant<int, 2>{});
   // zero the guard/padding rows that follow this sequence (and those before the first one)
   const int gend = (s + 1 < ns) ? seq_start[s + 1] : rows_total;
   for (int r = r0 + T + t0; r < gend; r += SWEEP) *(uint2 *)(y + (size_t)r * C + c) = make_uint2(0u, 0u);

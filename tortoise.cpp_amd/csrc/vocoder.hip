@@ -21,6 +21,13 @@ namespace tts {
 
 __device__ __forceinline__ float leaky02(float v) { return v > 0.f ? v : 0.2f * v; }
 __device__ __forceinline__ float r16(float v) { return __half2float(__float2half_rn(v)); }
+// sigmoid(a) * tanh(b) on the hardware exp2/rcp (1e-7-level relative error; libm's expf + tanhf + a division are ~70
+// VALU instructions per gate, more than half of the LVC kernel's time)
+__device__ __forceinline__ float gate_dev(float a, float b) {
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a * -1.44269504088896f));
+  const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(b * 2.88539008177793f)); // tanh b = 1 - 2/(1+e^{2b})
+  return sg * th;
+}
 
 // Generic direct conv1d over packed positions. x [P][Cin] f32 -> y [P][Cout].
 //   w: [K][Cin][Cout] f32 holding fp16-rounded values. Position p belongs to frame p / hop; taps that
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256) void lvc_gate_kernel(const float *__restrict__
     const float *bl = kb + (size_t)row * 256 + layer * 64;
     a0 += bl[c];
     a1 += bl[32 + c];
-    const float g = 1.0f / (1.0f + expf(-a0)) * tanhf(a1);
+    const float g = gate_dev(a0, a1);
     const int64_t p = (int64_t)row * hop + s0 + sl;
     x[p * 32 + c] += g;
   }
@@ -235,10 +242,10 @@ __global__ __launch_bounds__(256) void lvc_mfma_kernel(const float *__restrict__
       const float lo[4] = {acc[nt][0] + bs[nt].x, acc[nt][1] + bs[nt].y, acc[nt][2] + bs[nt].z, acc[nt][3] + bs[nt].w};
       const float hi[4] = {acc[nt + 2][0] + bs[nt + 2].x, acc[nt + 2][1] + bs[nt + 2].y, acc[nt + 2][2] + bs[nt + 2].z,
                            acc[nt + 2][3] + bs[nt + 2].w};
-      xv.x += 1.0f / (1.0f + expf(-lo[0])) * tanhf(hi[0]);
-      xv.y += 1.0f / (1.0f + expf(-lo[1])) * tanhf(hi[1]);
-      xv.z += 1.0f / (1.0f + expf(-lo[2])) * tanhf(hi[2]);
-      xv.w += 1.0f / (1.0f + expf(-lo[3])) * tanhf(hi[3]);
+      xv.x += gate_dev(lo[0], hi[0]);
+      xv.y += gate_dev(lo[1], hi[1]);
+      xv.z += gate_dev(lo[2], hi[2]);
+      xv.w += gate_dev(lo[3], hi[3]);
       *(float4 *)xp = xv;
     }
   }
