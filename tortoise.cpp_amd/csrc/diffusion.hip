@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
   const int pair = (tt / nq) * 8 + xcd, h = pair & 15, s = pair >> 4;
   const int T = seq_len[s], r0 = seq_start[s], q0 = (tt % nq) * 128;
   if (q0 >= T) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fq = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fq = lane >> 4;
   const float L2E = 1.44269504088896f;
   // Bias by SIGNED key-query distance d in [-160, 160), saturated outside +-63, in raw-score units (added to q.k
   // before the 1/8 * log2e scaling): a lane's 16 keys of a tile sit at compile-time offsets from one base distance,

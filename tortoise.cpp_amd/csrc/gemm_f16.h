@@ -169,7 +169,7 @@ template <int MODE, int MI>
 static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g) {
   constexpr int BM = 32 * MI;
   __shared__ __attribute__((aligned(16))) char smem[BM * 128 + 16384];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: LDS-DMA bases stay in SGPRs
   const int wm = wave >> 1, wn = wave & 1;
   // L2-aware tile order. Workgroup b runs on XCD b % 8 (each XCD has its own 4 MB L2). An XCD owns a
   // contiguous range of m-tiles and walks them once per chunk of `cn` n-tiles, chunk outermost: the chunk's
@@ -183,7 +183,7 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g
   const int cn = g.cn > 0 ? g.cn : NT, per_chunk = mcount * cn;
   const int chunk = idx / per_chunk, rem = idx - chunk * per_chunk;
   const int m0 = (mfirst + rem / cn) * BM, n0 = (chunk * cn + rem % cn) << 7;
-  const int tiles_per_seg = g.kseg >> 6, nk = g.nseg * tiles_per_seg;
+  const int tiles_per_seg = g.kseg >> 6;
   const int ldw = g.custom_w ? g.ldw_ : g.nseg * g.kseg;
   // DMA roles: wave w, piece i covers rows (w*MI+i)*8 .. +7 of the A tile; (w*4+i)*8 .. +7 of the B tile
   const int prow = lane >> 3, pslot = lane & 7;
@@ -214,10 +214,13 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g
   // the K loop is instantiated once per operand order so the choice costs nothing inside it
   auto kloop = [&](auto nat) {
     constexpr bool NAT = decltype(nat)::value;
-    for (int kt = 0; kt < nk; kt++) {
-      const int seg = kt / tiles_per_seg, kk = (kt - seg * tiles_per_seg) << 6;
-      const __half *abase = g.A[seg] + (ptrdiff_t)g.row_off[seg] * g.lda + kk;
-      const __half *wbase = g.W + (g.custom_w ? g.w_off_[seg] : seg * g.kseg) + kk;
+    // segment loop outside, K tiles inside: the segment's base pointers are fetched from the kernel arguments once,
+    // not by a scalar load (and an integer division) in front of every tile's DMA issue
+    for (int seg = 0; seg < g.nseg; seg++) {
+    const __half *aseg = g.A[seg] + (ptrdiff_t)g.row_off[seg] * g.lda;
+    const __half *wseg = g.W + (g.custom_w ? g.w_off_[seg] : seg * g.kseg);
+    for (int kt = 0; kt < tiles_per_seg; kt++) {
+      const __half *abase = aseg + (kt << 6), *wbase = wseg + (kt << 6);
 #pragma unroll
       for (int i = 0; i < MI; i++)
         __builtin_amdgcn_global_load_lds((gptr_t)(abase + aoff[i]), (lptr_t)(sa + (wave * MI + i) * 1024), 16, 0, 0);
@@ -242,6 +245,7 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g
       }
       __syncthreads();
     }
+    }
   };
   if (MODE == GEMM_OUT_QKV && natural) kloop(std::true_type{});
   else kloop(std::false_type{});
@@ -263,7 +267,7 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_kernel(GemmArgs 
   constexpr int BM = 32 * MI, SLAB = (BM + 8) * 128;
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[]; // A slab BM+8 rows | B tile x 2
   char *smem = smem_dyn;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: LDS-DMA bases stay in SGPRs
   const int wm = wave >> 1, wn = wave & 1;
   const int MT = (g.M + BM - 1) / BM, NT = g.N >> 7;
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
