@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void lvc_mfma_kernel(const float *__restrict__
 // tap = one 16x16x32 MFMA per 16 output channels, K = the tap's 32 input channels. The stage is a pure stream:
 // 128 B read + 128 B written per sample.
 __global__ __launch_bounds__(256) void voc_dconv_mfma_kernel(const float *__restrict__ x, const float *__restrict__ w /*[3][32][32]*/,
-                                                             const float *__restrict__ bias, const int *__restrict__ row_seq, int hop,
+                                                             const float *__restrict__ bias, const int *__restrict__ row_seq, int hop_shift,
                                                              int dil, int64_t P, float *__restrict__ y) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, fq = lane >> 4;
   half8 wf[3][2]; // A-role: lane (co = 16 ct + m, fq) holds w[tap][ci = 8 fq .. +7][co]
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void voc_dconv_mfma_kernel(const float *__rest
   for (int t = 0; t < 4; t++) {
     const int64_t p0 = (int64_t)blockIdx.x * 256 + (wave * 4 + t) * 16, pos = p0 + m;
     if (p0 >= P) break;
-    const bool live = row_seq[p0 / hop] >= 0; // a tile lies inside one frame
+    const bool live = row_seq[(int)(p0 >> hop_shift)] >= 0; // a tile lies inside one frame (hop = 1 << hop_shift: no 64-bit division)
     floatx4 acc[2] = {(floatx4){0.f, 0.f, 0.f, 0.f}, (floatx4){0.f, 0.f, 0.f, 0.f}};
     if (live) {
 #pragma unroll
@@ -596,10 +596,10 @@ int voc_run(tts_ctx *ctx, const float *mel, const int32_t *frames, int B, const 
     const int dil[4] = {1, 3, 9, 27};
     for (int c = 0; c < 4; c++) {
       // leaky -> dilated conv k3 32->32 -> leaky (main.cpp:4339-4365)
-      if (hop % 64 == 0) { // audio-rate stages: matrix-pipe kernels (frames are whole 16-sample tiles, dil < hop)
+      if (hop == 64 || hop == 256) { // audio-rate stages: matrix-pipe kernels (frames are whole 16-sample tiles, dil < hop)
         const int64_t P = (int64_t)R * hop;
         { ProfScope ps(ctx, "voc_conv");
-          voc_dconv_mfma_kernel<<<(int)((P + 255) / 256), 256, 0, ctx->stream>>>(cur, st->cb_w[i][c], st->cb_b[i][c], d_rs, hop, dil[c], P, yb); }
+          voc_dconv_mfma_kernel<<<(int)((P + 255) / 256), 256, 0, ctx->stream>>>(cur, st->cb_w[i][c], st->cb_b[i][c], d_rs, hop == 64 ? 6 : 8, dil[c], P, yb); }
         ProfScope ps(ctx, "voc_lvc");
         lvc_mfma_kernel<<<R, 256, 0, ctx->stream>>>(yb, st->kern.as<float>(), st->kbias.as<float>(), d_rs, hop, c, cur);
         TTS_HIP(ctx, hipGetLastError());
