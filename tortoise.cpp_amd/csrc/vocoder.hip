@@ -106,29 +106,31 @@ __global__ __launch_bounds__(256) void convt_kernel(const float *__restrict__ x,
                                                     const float *__restrict__ bias, const int *__restrict__ row_seq,
                                                     const int *__restrict__ seq_start, const int *__restrict__ seq_len, int hop_in,
                                                     int s, int64_t Pout, float *__restrict__ y) {
+  // (all index arithmetic in 32 bits with shifts: hop_in and s are powers of two and Pout < 2^31; three 64-bit
+  //  divisions per thread cost more than the 64 FMAs they index)
   const int co = threadIdx.x & 31;
-  const int64_t p = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int p = blockIdx.x * 8 + (threadIdx.x >> 5);
   if (p >= Pout) return;
-  const int hop_out = hop_in * s;
-  const int sq = row_seq[p / hop_out];
-  if (sq < 0) { y[p * 32 + co] = 0.f; return; }
-  const int64_t lo_in = (int64_t)seq_start[sq] * hop_in, n_in = (int64_t)seq_len[sq] * hop_in;
-  const int64_t tl = p - lo_in * s; // local output index (after crop)
-  const int64_t u = tl + s / 2;     // index in the uncropped transposed-conv output
+  const int ls = 31 - __clz(s), lh = 31 - __clz(hop_in * s);
+  const int sq = row_seq[p >> lh];
+  if (sq < 0) { y[(size_t)p * 32 + co] = 0.f; return; }
+  const int lo_in = seq_start[sq] * hop_in, n_in = seq_len[sq] * hop_in;
+  const int tl = p - lo_in * s; // local output index (after crop)
+  const int u = tl + s / 2;     // index in the uncropped transposed-conv output
   float acc = bias[co];
   // contributions: u = t*s + k, k in [0, 2s)  ->  t = u/s (k = u%s) and t-1 (k = u%s + s)
-  const int64_t t0 = u / s;
-  const int k0 = (int)(u - t0 * s);
+  const int t0 = u >> ls;
+  const int k0 = u - (t0 << ls);
 #pragma unroll
   for (int j = 0; j < 2; j++) {
-    const int64_t t = t0 - j;
+    const int t = t0 - j;
     const int k = k0 + j * s;
     if (t < 0 || t >= n_in) continue;
-    const float *xr = x + (lo_in + t) * 32;
+    const float *xr = x + (size_t)(lo_in + t) * 32;
     const float *wr = w + (size_t)k * 32 * 32 + co;
     for (int ci = 0; ci < 32; ci++) acc = fmaf(leaky02(xr[ci]), wr[ci * 32], acc);
   }
-  y[p * 32 + co] = acc;
+  y[(size_t)p * 32 + co] = acc;
 }
 
 // Fused location-variable convolution + gate + residual (main.cpp:4365-4455):
