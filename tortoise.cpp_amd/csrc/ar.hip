@@ -33,7 +33,11 @@ __device__ __forceinline__ float gelu_tanh(float x, int lut) {
     float xr = f16_round(x);
     return f16_round(0.5f * xr * (1.0f + tanhf(S * xr * (1.0f + A * xr * xr))));
   }
-  return 0.5f * x * (1.0f + tanhf(S * x * (1.0f + A * x * x)));
+  // tanh u = 1 - 2 / (1 + e^{2u}) on the hardware exp2/rcp (absolute error ~1e-7; libm's tanhf is ~40 instructions and
+  // sits in the serial tail of the c_fc decode kernel)
+  const float u = S * x * (1.0f + A * x * x);
+  const float th = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * 2.88539008177793f));
+  return 0.5f * x * (1.0f + th);
 }
 
 // rows of the transformer input: out[r] = tabA[ia[r]] + tabB[ib[r]]  (ib < 0: no second term).
