@@ -65,12 +65,12 @@ int main(int argc, char **argv) {
     printf("%-28s %7.2f us/launch  %6.2f TB/s\n", tag, 1e3 * ms / reps, bytes / (ms / reps * 1e-3) / 1e12);
   };
   timeit("dec_ln_gemv<GELU> fc", [&](int l) {
-    DecLnArgs a{h, nullptr, nullptr, wfc[l], bvec, B, 4096, 0, 0, ff, nullptr, nullptr, ss, 0, 0};
-    dec_ln_gemv_kernel<DEC_GELU><<<dim3(256, 1), 256, 0, st>>>(a); }, 16.8e6);
+    DecLnArgs a{h, nullptr, nullptr, wfc[l], (const __half *)wfc[l], bvec, B, 4096, 0, 0, ff, nullptr, nullptr, ss, 0, 0};
+    dec_ln_gemv_kernel<DEC_GELU, 1><<<dim3(256, 1), 256, 0, st>>>(a); }, 16.8e6);
   dump_trace("fc", 256, 5);
   timeit("dec_ln_gemv<QKV>", [&](int l) {
-    DecLnArgs a{h, nullptr, nullptr, wqkv[l], bvec, B, 3072, 1024, 0, q, kc, vc, ss, 256, 0};
-    dec_ln_gemv_kernel<DEC_QKV><<<dim3(192, 1), 256, 0, st>>>(a); }, 12.6e6);
+    DecLnArgs a{h, nullptr, nullptr, wqkv[l], (const __half *)wqkv[l], bvec, B, 3072, 1024, 0, q, kc, vc, ss, 256, 0};
+    dec_ln_gemv_kernel<DEC_QKV, 1><<<dim3(192, 1), 256, 0, st>>>(a); }, 12.6e6);
   dump_trace("qkv", 192, 5);
   timeit("dec_gemv_resid<4> fc2", [&](int l) { dec_gemv_resid_kernel<4><<<dim3(256, 1), 256, 0, st>>>(ff, B, wfc2[l], bvec, h); }, 16.8e6);
   dump_trace("fc2", 256, 4);

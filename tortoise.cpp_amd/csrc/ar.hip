@@ -22,6 +22,10 @@ namespace tts {
 
 static constexpr int D = 1024, NH = 16, HD = 64, FF = 4096, V = TTS_VOCAB_MEL, VPAD = 8256;
 
+// A/B switch for the LayerNorm-GEMV decode kernels: split-precision fp16 MFMA (default: three products per K step,
+// 2^-22 relative) vs exact-f32 MFMA products (TTS_DEC_F32MFMA=1, read at load time: it selects the weight packing)
+static const bool dec_f32_mfma = getenv("TTS_DEC_F32MFMA") != nullptr;
+
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
@@ -316,8 +320,10 @@ __global__ __launch_bounds__(256) void embed_step_kernel(const float *__restrict
 //   dec_gemv_resid<16>: h += ff . c_proj2 + b
 // and the head is dec_ln_gemv<LOGITS> (ln_f, lm_head LayerNorm, lm_head linear) straight to the logits.
 
-// K = 1024 GEMV with LayerNorm prologue for 16 candidates x 16 output columns per workgroup, on the fp32 MFMA
-// (v_mfma_f32_16x16x4_f32). Wave w covers k in [256w, 256w+256). Operands are fed swapped (A = weights,
+// K = 1024 GEMV with LayerNorm prologue for 16 candidates x 16 output columns per workgroup. Default: split-precision
+// operands on the fp16 MFMA (x = xh + xl split in registers, 64 W = wh + wl packed at load; wh.xh + wl.xh + wh.xl, 24
+// MFMAs of 16 cycles per wave); TTS_DEC_F32MFMA=1: the fp32 MFMA (v_mfma_f32_16x16x4_f32, exact f32 products, 64 MFMAs of
+// 32 cycles). Wave w covers k in [256w, 256w+256). Operands are fed swapped (A = weights,
 // B = activations) so that a lane ends with 4 consecutive output columns of one candidate. The 4 k values of
 // one MFMA are k0 + 4q + j for lane quarter q — a lane's activations are then one float4 of the natural
 // [row][k] layout; the weights are packed to match (pack_mfma16 below). LayerNorm is evaluated on the
@@ -334,6 +340,7 @@ struct DecLnArgs {
   const float *h;            // [rows][1024]
   const float *g1, *b1;      // DEC_LOGITS: ln_f (the LayerNorm feeding W is folded into W/bias at load)
   const float *W;            // pack_mfma16 of diag(gamma) W
+  const __half *Wh;          // pack_mfma16h: the same matrix x 64 as fp16 hi|lo pairs (SPLIT variant)
   const float *bias;         // bias + beta . W
   int rows, n_valid, ldo;    // ldo: row stride of `out` for DEC_QKV (q) and DEC_LOGITS
   int prefill_B;             // DEC_QKV: 0 = decode (row = candidate, position n_past); > 0 = prompt pass (row = position,
@@ -354,6 +361,9 @@ __device__ __forceinline__ float rows4_sum(float x) {
 
 // sred: two [4][16] arrays (one per pass, so each pass costs one barrier). g == nullptr: the affine part has
 // been folded into the weights/bias at load (fold_layernorm).
+// KSTEP: k of the i-th float4 of a lane = koff + (i >> KSH) * KSTEP + (i & ((1 << KSH) - 1)) * 4
+//   fp32-MFMA operand order: KSH = 0, KSTEP = 16;  fp16-MFMA (split) order: KSH = 1, KSTEP = 32
+template <int KSH, int KSTEP>
 __device__ __forceinline__ void dec_layernorm(float4 (&x)[16], const float *__restrict__ g, const float *__restrict__ b,
                                               int koff, float (*sred)[4][16], int wave, int m) {
   float s = 0.f;
@@ -375,7 +385,8 @@ __device__ __forceinline__ void dec_layernorm(float4 (&x)[16], const float *__re
   if (g) {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-      const float4 gg = *(const float4 *)(g + koff + i * 16), bb = *(const float4 *)(b + koff + i * 16);
+      const int k = koff + (i >> KSH) * KSTEP + (i & ((1 << KSH) - 1)) * 4;
+      const float4 gg = *(const float4 *)(g + k), bb = *(const float4 *)(b + k);
       x[i].x = x[i].x * sc * gg.x + bb.x; x[i].y = x[i].y * sc * gg.y + bb.y;
       x[i].z = x[i].z * sc * gg.z + bb.z; x[i].w = x[i].w * sc * gg.w + bb.w;
     }
@@ -385,7 +396,7 @@ __device__ __forceinline__ void dec_layernorm(float4 (&x)[16], const float *__re
   }
 }
 
-template <int EPI>
+template <int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
   __shared__ float sred[4][4][16];
   __shared__ float4 accs[4][64];
@@ -394,35 +405,57 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
   DEC_T(0);
   // activations first (L2 hits), then the weight slab (HBM): vmcnt retires in order, so the LayerNorm runs on
   // the activations while the 16 x 1 KB-per-wave weight loads are still streaming in
-  const int koff = wave * 256 + 4 * q;
+  const int koff = wave * 256 + (SPLIT ? 8 : 4) * q;
   float4 x[16];
   {
     // rows past the batch re-read the last candidate (branch-free); their results are never stored
     const float *hp = a.h + (size_t)min(row, a.rows - 1) * D + koff;
 #pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = *(const float4 *)(hp + i * 16);
+    for (int i = 0; i < 16; i++) x[i] = *(const float4 *)(hp + (SPLIT ? (i >> 1) * 32 + (i & 1) * 4 : i * 16));
   }
-  float4 w[16];
+  float4 w[16]; // SPLIT: step s = (w[2s] = 8 fp16 hi, w[2s+1] = 8 fp16 lo) of 64*W[k = koff + 32 s + e][col]
   {
-    const float4 *wp = (const float4 *)a.W + ((size_t)(cb * 4 + wave) * 16) * 64 + lane;
+    const float4 *wp = (SPLIT ? (const float4 *)a.Wh : (const float4 *)a.W) + ((size_t)(cb * 4 + wave) * 16) * 64;
 #pragma unroll
-    for (int i = 0; i < 16; i++) w[i] = wp[i * 64];
+    for (int i = 0; i < 16; i++) w[i] = SPLIT ? wp[((i >> 1) * 64 + lane) * 2 + (i & 1)] : wp[i * 64 + lane];
   }
   DEC_T(1);
   // the (last) LayerNorm's gamma/beta are folded into W/bias; the head's ln_f keeps its own
-  if (EPI == DEC_LOGITS) dec_layernorm(x, a.g1, a.b1, koff, sred, wave, m);
-  dec_layernorm(x, nullptr, nullptr, koff, sred + (EPI == DEC_LOGITS ? 2 : 0), wave, m);
+  if (EPI == DEC_LOGITS) dec_layernorm<SPLIT, SPLIT ? 32 : 16>(x, a.g1, a.b1, koff, sred, wave, m);
+  dec_layernorm<SPLIT, SPLIT ? 32 : 16>(x, nullptr, nullptr, koff, sred + (EPI == DEC_LOGITS ? 2 : 0), wave, m);
   DEC_T(2);
-  // four independent accumulator chains keep the fp32 MFMA pipe issue-bound instead of latency-bound
-  floatx4 ac0 = {0.f, 0.f, 0.f, 0.f}, ac1 = ac0, ac2 = ac0, ac3 = ac0;
+  floatx4 acc;
+  if (SPLIT) {
+    // split precision on the fp16 MFMA: x = xh + xl, 64 W = wh + wl; wh.xh + wl.xh + wh.xl (the dropped wl.xl term is
+    // 2^-22 relative), 24 MFMAs of 16 cycles instead of 64 fp32 MFMAs of 32
+    floatx4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    ac0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, x[i].x, ac0, 0, 0, 0);
-    ac1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].y, x[i].y, ac1, 0, 0, 0);
-    ac2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, x[i].z, ac2, 0, 0, 0);
-    ac3 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, x[i].w, ac3, 0, 0, 0);
+    for (int s = 0; s < 8; s++) {
+      const float xs[8] = {x[2 * s].x, x[2 * s].y, x[2 * s].z, x[2 * s].w, x[2 * s + 1].x, x[2 * s + 1].y, x[2 * s + 1].z, x[2 * s + 1].w};
+      half8 xh, xl;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        xh[e] = (_Float16)xs[e];
+        xl[e] = (_Float16)(xs[e] - (float)xh[e]);
+      }
+      const half8 wh = *(const half8 *)&w[2 * s], wl = *(const half8 *)&w[2 * s + 1];
+      a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, a0, 0, 0, 0);
+      a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, a1, 0, 0, 0);
+      a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, a2, 0, 0, 0);
+    }
+    acc = ((a1 + a2) + a0) * (1.0f / 64.0f);
+  } else {
+    // four independent accumulator chains keep the fp32 MFMA pipe issue-bound instead of latency-bound
+    floatx4 ac0 = {0.f, 0.f, 0.f, 0.f}, ac1 = ac0, ac2 = ac0, ac3 = ac0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      ac0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].x, x[i].x, ac0, 0, 0, 0);
+      ac1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].y, x[i].y, ac1, 0, 0, 0);
+      ac2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].z, x[i].z, ac2, 0, 0, 0);
+      ac3 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i].w, x[i].w, ac3, 0, 0, 0);
+    }
+    acc = (ac0 + ac1) + (ac2 + ac3);
   }
-  const floatx4 acc = (ac0 + ac1) + (ac2 + ac3);
   DEC_T(3);
   accs[wave][lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
   __syncthreads();
@@ -656,6 +689,7 @@ struct ArLayerDev {
   float *w_attn, *b_attn, *w_proj, *b_proj, *w_fc, *b_fc, *w_fc2, *b_fc2;
   __half *s_attn = nullptr, *s_proj = nullptr, *s_fc = nullptr, *s_fc2 = nullptr; // [N][2K] hi|lo of 64*W^T
   float *d_attn = nullptr, *d_fc = nullptr;   // pack_mfma16 of diag(ln gamma) W (decode step)
+  __half *dh_attn = nullptr, *dh_fc = nullptr; // pack_mfma16h of the same (split-precision variant)
   float *db_attn = nullptr, *db_fc = nullptr; // bias + ln beta . W
   float *d_proj = nullptr, *d_fc2 = nullptr;  // pack_cols4  (decode step)
 };
@@ -666,6 +700,7 @@ struct ArState {
   float *text_emb = nullptr, *text_pos = nullptr, *mel_emb = nullptr, *mel_pos = nullptr;
   float *lnf_g = nullptr, *lnf_b = nullptr, *lmh_g = nullptr, *lmh_b = nullptr;
   float *lm_w = nullptr /*[1024][VPAD] strip-major*/, *lm_b = nullptr /*[VPAD]*/, *d_lm = nullptr /*pack_mfma16, lm_head.0 folded*/, *d_lmb = nullptr;
+  __half *dh_lm = nullptr; // pack_mfma16h
   std::vector<void *> owned;
   // run state
   int B = 0, n_text = 0, P = 0, max_pos = 0;
@@ -692,6 +727,15 @@ struct ArState {
 };
 
 void ar_free(ArState *s) { delete s; }
+
+static int upload_h(tts_ctx *ctx, ArState *st, const std::vector<__half> &src, __half **dst) {
+  void *p = nullptr;
+  TTS_HIP(ctx, hipMalloc(&p, src.size() * sizeof(__half)));
+  st->owned.push_back(p);
+  TTS_HIP(ctx, hipMemcpy(p, src.data(), src.size() * sizeof(__half), hipMemcpyHostToDevice));
+  *dst = (__half *)p;
+  return TTS_OK;
+}
 
 static int upload(tts_ctx *ctx, ArState *st, const std::vector<float> &src, float **dst) {
   void *p = nullptr;
@@ -725,6 +769,24 @@ static std::vector<float> pack_mfma16(const float *w, int K, int N) {
           for (int j = 0; j < 4; j++)
             t[((((size_t)cb * 4 + wv) * 16 + g) * 64 + lane) * 4 + j] =
                 w[(size_t)(wv * 256 + g * 16 + 4 * (lane >> 4) + j) * N + cb * 16 + (lane & 15)];
+  return t;
+}
+// pack_mfma16h (K = 1024): the same slab for the split-precision fp16 MFMA. Lane (m, q) of wave wv holds for K step s
+// (32 k) the 8 values k = 256 wv + 32 s + 8 q + e of column 16 cb + m, times 64, as 8 fp16 hi followed by 8 fp16 lo
+// (hi = fp16(64 w), lo = fp16(64 w - hi)): 32 contiguous bytes per lane, 2 KB per wave and step.
+static std::vector<__half> pack_mfma16h(const float *w, int K, int N) {
+  std::vector<__half> t((size_t)K * N * 2);
+  for (int cb = 0; cb < N / 16; cb++)
+    for (int wv = 0; wv < 4; wv++)
+      for (int s2 = 0; s2 < 8; s2++)
+        for (int lane = 0; lane < 64; lane++)
+          for (int e = 0; e < 8; e++) {
+            const float v = 64.0f * w[(size_t)(wv * 256 + s2 * 32 + 8 * (lane >> 4) + e) * N + cb * 16 + (lane & 15)];
+            const __half hi = __float2half_rn(v);
+            const size_t base = ((((size_t)cb * 4 + wv) * 8 + s2) * 64 + lane) * 16;
+            t[base + e] = hi;
+            t[base + 8 + e] = __float2half_rn(v - __half2float(hi));
+          }
   return t;
 }
 // pack_cols4 (K = 1024 KG): slab of workgroup cb (4 columns) = KG x 4 x 256 threads x float4 (the 4 columns),
@@ -806,11 +868,13 @@ int ar_load(tts_ctx *ctx, const char *path) {
     std::vector<float> wfold, cfold;
     fold_layernorm(wf.t.at(p + ".attn.c_attn.weight").data.data(), D, 3 * D, wf.t.at(p + ".ln_1.weight").data.data(),
                    wf.t.at(p + ".ln_1.bias").data.data(), wf.t.at(p + ".attn.c_attn.bias").data.data(), wfold, cfold);
-    if ((r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, 3 * D), &l.d_attn))) return r;
+    if (dec_f32_mfma && (r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, 3 * D), &l.d_attn))) return r;
+    if ((r = upload_h(ctx, st.get(), pack_mfma16h(wfold.data(), D, 3 * D), &l.dh_attn))) return r;
     if ((r = upload(ctx, st.get(), cfold, &l.db_attn))) return r;
     fold_layernorm(wf.t.at(p + ".mlp.c_fc.weight").data.data(), D, FF, wf.t.at(p + ".ln_2.weight").data.data(),
                    wf.t.at(p + ".ln_2.bias").data.data(), wf.t.at(p + ".mlp.c_fc.bias").data.data(), wfold, cfold);
-    if ((r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, FF), &l.d_fc))) return r;
+    if (dec_f32_mfma && (r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, FF), &l.d_fc))) return r;
+    if ((r = upload_h(ctx, st.get(), pack_mfma16h(wfold.data(), D, FF), &l.dh_fc))) return r;
     if ((r = upload(ctx, st.get(), cfold, &l.db_fc))) return r;
     if ((r = upload(ctx, st.get(), pack_cols4(wf.t.at(p + ".attn.c_proj.weight").data.data(), D, D), &l.d_proj))) return r;
     if ((r = upload(ctx, st.get(), pack_cols4(wf.t.at(p + ".mlp.c_proj.weight").data.data(), FF, D), &l.d_fc2))) return r;
@@ -846,7 +910,8 @@ int ar_load(tts_ctx *ctx, const char *path) {
       std::vector<float> wfold, cfold;
       fold_layernorm(wt.data(), D, VPAD, wf.t.at("inference_model.lm_head.0.weight").data.data(),
                      wf.t.at("inference_model.lm_head.0.bias").data.data(), bt.data(), wfold, cfold);
-      r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, VPAD), &st->d_lm); if (r) return r;
+      if (dec_f32_mfma) { r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, VPAD), &st->d_lm); if (r) return r; }
+      r = upload_h(ctx, st.get(), pack_mfma16h(wfold.data(), D, VPAD), &st->dh_lm); if (r) return r;
       r = upload(ctx, st.get(), cfold, &st->d_lmb); if (r) return r;
     }
     r = upload(ctx, st.get(), bt, &st->lm_b); if (r) return r;
@@ -920,6 +985,12 @@ static int launch_mfma_matmul(tts_ctx *ctx, ArState *st, const float *X, int row
 }
 
 #define CHECK(x) do { int _r = (x); if (_r) return _r; } while (0)
+#define DEC_LN_LAUNCH(EPI_, GRID_)                                                         \
+  do {                                                                                     \
+    if (dec_f32_mfma) dec_ln_gemv_kernel<EPI_, 0><<<GRID_, 256, 0, ctx->stream>>>(a);       \
+    else dec_ln_gemv_kernel<EPI_, 1><<<GRID_, 256, 0, ctx->stream>>>(a);                    \
+  } while (0)
+
 
 // Transformer stack over rows = n_cand_rows * S laid out [cand][pos] in st->h.
 //   kc/vc: fp16 K/V destination [cand][kv_max_pos][1024] per layer (layer_stride halves apart).
@@ -1023,23 +1094,23 @@ int ar_prefill(tts_ctx *ctx, float *logits_out) {
     const ArLayerDev &w = st->L[l];
     __half *kc = st->kcache.as<__half>() + l * layer_stride, *vc = st->vcache.as<__half>() + l * layer_stride;
     { ProfScope ps(ctx, "ar_gemv", 3.0 * D * D * 4.0 * tiles);
-      DecLnArgs a{h, nullptr, nullptr, w.d_attn, w.db_attn, P, 3 * D, 3 * D, st->B, qkv, kc, vc, nullptr, st->max_pos, ctx->ggml_lut};
-      dec_ln_gemv_kernel<DEC_QKV><<<dim3(3 * D / 16, tiles), 256, 0, ctx->stream>>>(a); }
+      DecLnArgs a{h, nullptr, nullptr, w.d_attn, w.dh_attn, w.db_attn, P, 3 * D, 3 * D, st->B, qkv, kc, vc, nullptr, st->max_pos, ctx->ggml_lut};
+      DEC_LN_LAUNCH(DEC_QKV, dim3(3 * D / 16, tiles)); }
     { ProfScope ps(ctx, "ar_attention");
       attention_kernel<<<dim3(P, NH), 64, 0, ctx->stream>>>(qkv, kc, vc, att, P, 0, st->max_pos, ctx->ggml_lut); }
     { ProfScope ps(ctx, "ar_gemv", 1.0 * D * D * 4.0 * tiles);
       dec_gemv_resid_kernel<1><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, P, w.d_proj, w.b_proj, h); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * 4.0 * tiles);
-      DecLnArgs a{h, nullptr, nullptr, w.d_fc, w.db_fc, P, FF, 0, 0, ff, nullptr, nullptr, nullptr, 0, ctx->ggml_lut};
-      dec_ln_gemv_kernel<DEC_GELU><<<dim3(FF / 16, tiles), 256, 0, ctx->stream>>>(a); }
+      DecLnArgs a{h, nullptr, nullptr, w.d_fc, w.dh_fc, w.db_fc, P, FF, 0, 0, ff, nullptr, nullptr, nullptr, 0, ctx->ggml_lut};
+      DEC_LN_LAUNCH(DEC_GELU, dim3(FF / 16, tiles)); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * 4.0 * tiles);
       dec_gemv_resid_kernel<4><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(ff, P, w.d_fc2, w.b_fc2, h); }
   }
   TTS_HIP(ctx, st->logits.reserve((size_t)V * 4));
   { ProfScope ps(ctx, "ar_gemv", (double)D * VPAD * 4.0);
-    DecLnArgs a{h + (size_t)(P - 1) * D, st->lnf_g, st->lnf_b, st->d_lm, st->d_lmb, 1, V, V, 0, st->logits.as<float>(),
+    DecLnArgs a{h + (size_t)(P - 1) * D, st->lnf_g, st->lnf_b, st->d_lm, st->dh_lm, st->d_lmb, 1, V, V, 0, st->logits.as<float>(),
                 nullptr, nullptr, nullptr, 0, ctx->ggml_lut};
-    dec_ln_gemv_kernel<DEC_LOGITS><<<dim3(VPAD / 16, 1), 256, 0, ctx->stream>>>(a); }
+    DEC_LN_LAUNCH(DEC_LOGITS, dim3(VPAD / 16, 1)); }
   TTS_HIP(ctx, hipGetLastError());
   if (logits_out) {
     TTS_HIP(ctx, hipMemcpyAsync(logits_out, st->logits.p, (size_t)V * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1065,22 +1136,22 @@ static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
     const ArLayerDev &w = st->L[l];
     __half *kc = st->kcache.as<__half>() + l * layer_stride, *vc = st->vcache.as<__half>() + l * layer_stride;
     { ProfScope ps(ctx, "ar_gemv", 3.0 * D * D * 4.0 * tiles);
-      DecLnArgs a{h, nullptr, nullptr, w.d_attn, w.db_attn, B, 3 * D, D, 0, q, kc, vc, ss, st->max_pos, ctx->ggml_lut};
-      dec_ln_gemv_kernel<DEC_QKV><<<dim3(3 * D / 16, tiles), 256, 0, ctx->stream>>>(a); }
+      DecLnArgs a{h, nullptr, nullptr, w.d_attn, w.dh_attn, w.db_attn, B, 3 * D, D, 0, q, kc, vc, ss, st->max_pos, ctx->ggml_lut};
+      DEC_LN_LAUNCH(DEC_QKV, dim3(3 * D / 16, tiles)); }
     { ProfScope ps(ctx, "ar_attention");
       attn_decode_kernel<<<dim3(B, NH), 256, 0, ctx->stream>>>(q, kc, vc, ss, st->max_pos, att, ctx->ggml_lut); }
     { ProfScope ps(ctx, "ar_gemv", 1.0 * D * D * 4.0 * tiles);
       dec_gemv_resid_kernel<1><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, w.d_proj, w.b_proj, h); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * 4.0 * tiles);
-      DecLnArgs a{h, nullptr, nullptr, w.d_fc, w.db_fc, B, FF, 0, 0, ff, nullptr, nullptr, ss, 0, ctx->ggml_lut};
-      dec_ln_gemv_kernel<DEC_GELU><<<dim3(FF / 16, tiles), 256, 0, ctx->stream>>>(a); }
+      DecLnArgs a{h, nullptr, nullptr, w.d_fc, w.dh_fc, w.db_fc, B, FF, 0, 0, ff, nullptr, nullptr, ss, 0, ctx->ggml_lut};
+      DEC_LN_LAUNCH(DEC_GELU, dim3(FF / 16, tiles)); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * 4.0 * tiles);
       dec_gemv_resid_kernel<4><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(ff, B, w.d_fc2, w.b_fc2, h); }
   }
   { ProfScope ps(ctx, "ar_gemv", (double)D * VPAD * 4.0 * tiles);
-    DecLnArgs a{h, st->lnf_g, st->lnf_b, st->d_lm, st->d_lmb, B, V, V, 0, st->logits.as<float>(),
+    DecLnArgs a{h, st->lnf_g, st->lnf_b, st->d_lm, st->dh_lm, st->d_lmb, B, V, V, 0, st->logits.as<float>(),
                 nullptr, nullptr, ss, 0, ctx->ggml_lut};
-    dec_ln_gemv_kernel<DEC_LOGITS><<<dim3(VPAD / 16, tiles), 256, 0, ctx->stream>>>(a); }
+    DEC_LN_LAUNCH(DEC_LOGITS, dim3(VPAD / 16, tiles)); }
   TTS_HIP(ctx, hipMemcpyAsync(st->h_logits, st->logits.p, (size_t)B * V * 4, hipMemcpyDeviceToHost, ctx->stream));
   TTS_HIP(ctx, hipGetLastError());
   return TTS_OK;
