@@ -73,6 +73,7 @@ int main(int argc, char **argv) {
     dec_ln_gemv_kernel<DEC_QKV, 1><<<dim3(192, 1), 256, 0, st>>>(a); }, 12.6e6);
   dump_trace("qkv", 192, 5);
   timeit("dec_gemv_resid<4> fc2", [&](int l) { dec_gemv_resid_kernel<4><<<dim3(256, 1), 256, 0, st>>>(ff, B, wfc2[l], bvec, h); }, 16.8e6);
+  timeit("dec_gemv_resid<4,512> fc2", [&](int l) { dec_gemv_resid_kernel<4, 512><<<dim3(256, 1), 512, 0, st>>>(ff, B, wfc2[l], bvec, h); }, 16.8e6);
   dump_trace("fc2", 256, 4);
   timeit("dec_gemv_resid<1> proj", [&](int l) { dec_gemv_resid_kernel<1><<<dim3(256, 1), 256, 0, st>>>(att, B, wproj[l], bvec, h); }, 4.2e6);
   dump_trace("proj", 256, 4);

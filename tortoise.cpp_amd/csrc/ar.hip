@@ -499,28 +499,32 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
 // whole K (W packed by pack_cols4: 16 KB x KG contiguous per workgroup); thread t holds k = 1024 i + 4 t + kk.
 // The 64 per-thread sums (16 candidates x 4 columns) are reduced with a 6-step exchange butterfly that
 // leaves output t on lane t, then across the 4 waves through LDS — a fixed summation tree.
-template <int KG>
-__global__ __launch_bounds__(256) void dec_gemv_resid_kernel(const float *__restrict__ X, int rows, const float *__restrict__ W,
-                                                             const float *__restrict__ bias, float *__restrict__ h) {
-  constexpr int K = 1024 * KG;
-  __shared__ float red[4][64];
+// NT threads per workgroup (256 or 512): with 512 the K range of a thread halves and twice as many activation loads
+// are in flight per CU — the c_proj of the MLP (K = 4096) reads 256 KB of activations per workgroup and is bound by how
+// many of those loads the CU keeps in flight.
+template <int KG, int NT = 256>
+__global__ __launch_bounds__(NT) void dec_gemv_resid_kernel(const float *__restrict__ X, int rows, const float *__restrict__ W,
+                                                            const float *__restrict__ bias, float *__restrict__ h) {
+  constexpr int K = 1024 * KG, NW = NT / 64, NG = K / (NT * 4); // NG K groups of NT*4 values per workgroup
+  __shared__ float red[NW][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cb = blockIdx.x, row0 = blockIdx.y * 16;
   DEC_T(0);
   float4 xa0[8]; // candidates 0-7 of K group 0: requested before the weight stream
 #pragma unroll
   for (int r = 0; r < 8; r++) xa0[r] = *(const float4 *)(X + (size_t)min(row0 + r, rows - 1) * K + 4 * tid);
-  float4 w[KG][4];
+  float4 w[NG][4];
   {
-    const float4 *wp = (const float4 *)W + (size_t)cb * KG * 1024 + tid;
+    // pack_cols4 order: float4 index ((k / 1024) * 4 + kk) * 256 + (k % 1024) / 4 for k = g * NT * 4 + 4 * tid + kk
+    const float4 *wp = (const float4 *)W + (size_t)cb * KG * 1024 + (tid & 255);
 #pragma unroll
-    for (int i = 0; i < KG; i++)
+    for (int i = 0; i < NG; i++)
 #pragma unroll
-      for (int kk = 0; kk < 4; kk++) w[i][kk] = wp[(i * 4 + kk) * 256];
+      for (int kk = 0; kk < 4; kk++) w[i][kk] = wp[((i * (NT / 256) + (tid >> 8)) * 4 + kk) * 256];
   }
   // Activations (L2 hits) are fetched 8 candidates at a time, double-buffered against the FMAs; K group i of the
   // weight slab is consumed for all 16 candidates as soon as it has arrived (vmcnt retires in order), so the
-  // FMAs of groups 0..KG-2 overlap the rest of the weight stream. Two columns per v_pk_fma_f32.
+  // FMAs of groups 0..NG-2 overlap the rest of the weight stream. Two columns per v_pk_fma_f32.
   floatx2 acc[32];
 #pragma unroll
   for (int j = 0; j < 32; j++) acc[j] = (floatx2){0.f, 0.f};
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(256) void dec_gemv_resid_kernel(const float *__rest
 #pragma unroll
   for (int r = 0; r < 8; r++) { xa[r] = xa0[r]; xb[r] = *(const float4 *)(xbase + rowoff[8 + r]); }
 #pragma unroll
-  for (int i = 0; i < KG; i++) {
+  for (int i = 0; i < NG; i++) {
 #pragma unroll
     for (int half = 0; half < 2; half++) {
       // half 0 consumes xa (candidates 0-7), half 1 consumes xb (8-15); the other buffer is refilled meanwhile
@@ -549,9 +553,9 @@ __global__ __launch_bounds__(256) void dec_gemv_resid_kernel(const float *__rest
         }
         acc[(half * 8 + r) * 2] = a01; acc[(half * 8 + r) * 2 + 1] = a23;
       }
-      if (i + 1 < KG) { // refill the buffer just consumed with the next K group
+      if (i + 1 < NG) { // refill the buffer just consumed with the next K group
 #pragma unroll
-        for (int r = 0; r < 8; r++) cur[r] = *(const float4 *)(xbase + rowoff[half * 8 + r] + (i + 1) * 1024);
+        for (int r = 0; r < 8; r++) cur[r] = *(const float4 *)(xbase + rowoff[half * 8 + r] + (i + 1) * (NT * 4));
       }
     }
   }
@@ -587,7 +591,12 @@ __global__ __launch_bounds__(256) void dec_gemv_resid_kernel(const float *__rest
   DEC_T(3);
   if (tid < 64) {
     const int r = row0 + (tid >> 2), col = cb * 4 + (tid & 3);
-    if (r < rows) h[(size_t)r * D + col] += (((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid]) + bias[col];
+    if (r < rows) {
+      float t = red[0][tid];
+#pragma unroll
+      for (int w2 = 1; w2 < NW; w2++) t += red[w2][tid];
+      h[(size_t)r * D + col] += t + bias[col];
+    }
   }
 }
 
@@ -1104,7 +1113,7 @@ int ar_prefill(tts_ctx *ctx, float *logits_out) {
       DecLnArgs a{h, nullptr, nullptr, w.d_fc, w.dh_fc, w.db_fc, P, FF, 0, 0, ff, nullptr, nullptr, nullptr, 0, ctx->ggml_lut};
       DEC_LN_LAUNCH(DEC_GELU, dim3(FF / 16, tiles)); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * 4.0 * tiles);
-      dec_gemv_resid_kernel<4><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(ff, P, w.d_fc2, w.b_fc2, h); }
+      dec_gemv_resid_kernel<4, 512><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, P, w.d_fc2, w.b_fc2, h); }
   }
   TTS_HIP(ctx, st->logits.reserve((size_t)V * 4));
   { ProfScope ps(ctx, "ar_gemv", (double)D * VPAD * 4.0);
@@ -1146,7 +1155,7 @@ static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
       DecLnArgs a{h, nullptr, nullptr, w.d_fc, w.dh_fc, w.db_fc, B, FF, 0, 0, ff, nullptr, nullptr, ss, 0, ctx->ggml_lut};
       DEC_LN_LAUNCH(DEC_GELU, dim3(FF / 16, tiles)); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * 4.0 * tiles);
-      dec_gemv_resid_kernel<4><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(ff, B, w.d_fc2, w.b_fc2, h); }
+      dec_gemv_resid_kernel<4, 512><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, w.d_fc2, w.b_fc2, h); }
   }
   { ProfScope ps(ctx, "ar_gemv", (double)D * VPAD * 4.0 * tiles);
     DecLnArgs a{h, st->lnf_g, st->lnf_b, st->d_lm, st->dh_lm, st->d_lmb, B, V, V, 0, st->logits.as<float>(),
