@@ -77,6 +77,14 @@ int main(int argc, char **argv) {
   dump_trace("fc2", 256, 4);
   timeit("dec_gemv_resid<1> proj", [&](int l) { dec_gemv_resid_kernel<1><<<dim3(256, 1), 256, 0, st>>>(att, B, wproj[l], bvec, h); }, 4.2e6);
   dump_trace("proj", 256, 4);
-  timeit("attn_decode", [&](int l) { attn_decode_kernel<<<dim3(B, 16), 256, 0, st>>>(q, kc, vc, ss, 256, att, 0); }, 0);
+  for (int np : {20, 100, 164, 250}) {
+    StepState hs2{np, 3}; CK(hipMemcpy(ss, &hs2, sizeof(hs2), hipMemcpyHostToDevice));
+    char tag[64];
+    snprintf(tag, sizeof tag, "attn_decode (exact) nk=%d", np + 1);
+    timeit(tag, [&](int l) { attn_decode_kernel<<<dim3(B, 16), 256, 0, st>>>(q, kc, vc, ss, 256, att, 0); }, 0);
+    snprintf(tag, sizeof tag, "attn_decode_fast nk=%d", np + 1);
+    timeit(tag, [&](int l) { attn_decode_fast_kernel<<<dim3(B, 16), 256, 0, st>>>(q, kc, vc, ss, 256, att); }, 0);
+  }
+  CK(hipMemcpy(ss, &hs, sizeof(hs), hipMemcpyHostToDevice));
   return 0;
 }

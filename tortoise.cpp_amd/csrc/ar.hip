@@ -600,6 +600,137 @@ __global__ __launch_bounds__(NT) void dec_gemv_resid_kernel(const float *__restr
   }
 }
 
+// max over the four 16-lane rows of a wave (see rows4_sum)
+__device__ __forceinline__ float rows4_max(float x) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) { // lane i reads x of the lane the DPP control names (full row/bank masks)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+typedef _Float16 dhalf2 __attribute__((ext_vector_type(2)));
+
+// 32 * NR keys starting at j0 for one (candidate, head): 8 lanes per key (16 B of K and of V each: whole 128 B rows per
+// 8 lanes), key group kg = tid >> 3 owns keys j0 + kg + 32 r. All K and V rows of the chunk are requested before the
+// first use, so the chunk costs one memory round trip. Online softmax state (m, l, acc) is per wave: m is uniform over
+// the wave, l and acc are the lane's partial sums over its own keys.
+template <int NR>
+__device__ __forceinline__ void attn_decode_chunk(const __half *__restrict__ kb, const __half *__restrict__ vb, int j0, int nk, int kg,
+                                                  int l8, const float4 &qa, const float4 &qb, float &m, float &l, float (&acc)[8]) {
+  constexpr float L2E = 1.4426950408889634f;
+  uint4 kq[NR], vq[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++) // uniform base + 32-bit byte offset (one candidate's cache is < 4 GB): saddr-form loads
+    kq[r] = *(const uint4 *)((const char *)kb + ((unsigned)min(j0 + kg + 32 * r, nk - 1) * (unsigned)(D * 2) + (unsigned)l8 * 16u));
+#pragma unroll
+  for (int r = 0; r < NR; r++)
+    vq[r] = *(const uint4 *)((const char *)vb + ((unsigned)min(j0 + kg + 32 * r, nk - 1) * (unsigned)(D * 2) + (unsigned)l8 * 16u));
+  __builtin_amdgcn_sched_barrier(0); // keep every request in front of the first use (the scheduler would sink the V loads)
+  // q was rounded to fp16 by the QKV epilogue: the conversion back is exact. The empty asm pins the first use of q
+  // behind the requests above (the conversion is common to all chunk sizes and would be hoisted in front of them).
+  float4 qc = qa, qd = qb;
+  asm volatile("" : "+v"(qc.x), "+v"(qc.y), "+v"(qc.z), "+v"(qc.w), "+v"(qd.x), "+v"(qd.y), "+v"(qd.z), "+v"(qd.w));
+  const dhalf2 q2[4] = {{(_Float16)qc.x, (_Float16)qc.y}, {(_Float16)qc.z, (_Float16)qc.w},
+                        {(_Float16)qd.x, (_Float16)qd.y}, {(_Float16)qd.z, (_Float16)qd.w}};
+  float s[NR], mc = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    const dhalf2 *k2 = (const dhalf2 *)&kq[r];
+    float d = __builtin_amdgcn_fdot2(k2[0], q2[0], 0.f, false);
+    d = __builtin_amdgcn_fdot2(k2[1], q2[1], d, false);
+    d = __builtin_amdgcn_fdot2(k2[2], q2[2], d, false);
+    d = __builtin_amdgcn_fdot2(k2[3], q2[3], d, false);
+    d += dpp_f32<0xB1>(d);  // quad_perm [1,0,3,2]
+    d += dpp_f32<0x4E>(d);  // quad_perm [2,3,0,1]
+    d += dpp_f32<0x141>(d); // row_half_mirror: lane i <-> 7 - i of each 8
+    s[r] = (j0 + kg + 32 * r < nk) ? d * 0.125f : -INFINITY;
+    mc = fmaxf(mc, s[r]);
+  }
+  mc = rows4_max(fmaxf(mc, __shfl_xor(mc, 8)));
+  const float mn = fmaxf(m, mc);
+  const float mu = (mn == -INFINITY) ? 0.f : mn; // a wave without a valid key yet: all weights 0
+  const float alpha = __builtin_amdgcn_exp2f((m - mu) * L2E);
+  l *= alpha;
+#pragma unroll
+  for (int e = 0; e < 8; e++) acc[e] *= alpha;
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    const float p = __builtin_amdgcn_exp2f((s[r] - mu) * L2E);
+    l += p;
+    const __half2 *v2 = (const __half2 *)&vq[r];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const float2 f = __half22float2(v2[e]);
+      acc[2 * e] = fmaf(p, f.x, acc[2 * e]);
+      acc[2 * e + 1] = fmaf(p, f.y, acc[2 * e + 1]);
+    }
+  }
+  m = mn;
+}
+
+// Decode attention for one (candidate, head), the default (non-LUT) path: softmax(q.K/8) V over n_past+1 keys with the
+// hardware exp2 (relative error ~1e-6 on a weight). Up to 288 keys go through one chunk = one memory round trip
+// (attn_decode_chunk); the four waves keep separate online-softmax states that are merged once at the end.
+__global__ __launch_bounds__(256) void attn_decode_fast_kernel(const float *__restrict__ qbuf, const __half *__restrict__ kc,
+                                                               const __half *__restrict__ vc, const StepState *__restrict__ ss,
+                                                               int max_pos, float *__restrict__ out) {
+  constexpr float L2E = 1.4426950408889634f;
+  __shared__ float red[4][HD];
+  __shared__ float wm[4], wl[4];
+  const int c = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l8 = tid & 7, kg = tid >> 3;
+  const int nk = ss->n_past + 1;
+  const __half *kb = kc + (size_t)c * max_pos * D + h * HD;
+  const __half *vb = vc + (size_t)c * max_pos * D + h * HD;
+  const float4 qa = *(const float4 *)(qbuf + (size_t)c * D + h * HD + l8 * 8), qb = *(const float4 *)(qbuf + (size_t)c * D + h * HD + l8 * 8 + 4);
+  float m = -INFINITY, l = 0.f, acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) acc[e] = 0.f;
+  for (int j0 = 0; j0 < nk; j0 += 288) {
+    const int rem = nk - j0; // workgroup-uniform
+    if (rem <= 96) attn_decode_chunk<3>(kb, vb, j0, nk, kg, l8, qa, qb, m, l, acc);
+    else if (rem <= 160) attn_decode_chunk<5>(kb, vb, j0, nk, kg, l8, qa, qb, m, l, acc);
+    else if (rem <= 224) attn_decode_chunk<7>(kb, vb, j0, nk, kg, l8, qa, qb, m, l, acc);
+    else attn_decode_chunk<9>(kb, vb, j0, nk, kg, l8, qa, qb, m, l, acc);
+  }
+  // sum over the wave's 8 key groups (lane bits 3-5). l: plain reduction. acc: exchange butterfly, 8 values -> the
+  // wave total of dim l8 * 8 + (lane >> 3)
+  l += __shfl_xor(l, 8);
+  l = rows4_sum(l);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i]), __float_as_uint(acc[i + 4]), false, false);
+    acc[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i]), __float_as_uint(acc[i + 2]), false, false);
+    acc[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  {
+    const bool up = (lane & 8) != 0;
+    const float send = up ? acc[0] : acc[1], keep = up ? acc[1] : acc[0];
+    acc[0] = keep + __shfl_xor(send, 8);
+  }
+  red[wave][l8 * 8 + (lane >> 3)] = acc[0];
+  if (lane == 0) { wm[wave] = m; wl[wave] = l; }
+  __syncthreads();
+  if (tid < HD) {
+    const float M = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])); // wave 0 always holds key 0: finite
+    float tot = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      const float sc = __builtin_amdgcn_exp2f((wm[w] - M) * L2E); // exp2(-inf) = 0 for a wave without keys
+      tot = fmaf(sc, wl[w], tot);
+      o = fmaf(sc, red[w][tid], o);
+    }
+    out[(size_t)c * D + h * HD + tid] = o / tot;
+  }
+}
+
 // Decode attention for one (candidate, head): q is this step's (fp16-rounded) query, K/V of the new position
 // are already in the fp16 cache; softmax(q.K/8) V over n_past+1 keys. 4 waves: keys are spread over all 256
 // threads for the scores and over 16 groups for PV.
@@ -1148,7 +1279,8 @@ static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
       DecLnArgs a{h, nullptr, nullptr, w.d_attn, w.dh_attn, w.db_attn, B, 3 * D, D, 0, q, kc, vc, ss, st->max_pos, ctx->ggml_lut};
       DEC_LN_LAUNCH(DEC_QKV, dim3(3 * D / 16, tiles)); }
     { ProfScope ps(ctx, "ar_attention");
-      attn_decode_kernel<<<dim3(B, NH), 256, 0, ctx->stream>>>(q, kc, vc, ss, st->max_pos, att, ctx->ggml_lut); }
+      if (ctx->ggml_lut) attn_decode_kernel<<<dim3(B, NH), 256, 0, ctx->stream>>>(q, kc, vc, ss, st->max_pos, att, 1);
+      else attn_decode_fast_kernel<<<dim3(B, NH), 256, 0, ctx->stream>>>(q, kc, vc, ss, st->max_pos, att); }
     { ProfScope ps(ctx, "ar_gemv", 1.0 * D * D * 4.0 * tiles);
       dec_gemv_resid_kernel<1><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, w.d_proj, w.b_proj, h); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * 4.0 * tiles);
