@@ -51,7 +51,10 @@ const char *tts_last_error(const tts_ctx *ctx);
  * "ggml_lut" (0/1: emulate ggml-CPU fp16 lookup tables for GELU/SiLU),
  * "prof_only:<family>" (1: restrict profiling to one kernel family, 0: all),
  * "sampler_threads" (-1 default = min(7, hardware threads - 1); 0 = sample on the calling thread; the token ids
- * do not depend on it: the RNG is consumed in candidate order before the per-candidate scans run). */
+ * do not depend on it: the RNG is consumed in candidate order before the per-candidate scans run),
+ * "share_uncond" (1 default: in tts_diffusion the conditioning_timestep_integrator layers of the unconditioned branch,
+ * whose input does not depend on the candidate, are evaluated once per distinct sequence length instead of once per
+ * candidate; 0 = once per candidate. Same arithmetic per row either way). */
 int tts_set_option(tts_ctx *ctx, const char *key, double value);
 
 /* ---- weight files (drop-in format: magic 0x67676d6c + name-keyed F32 records) ------------- */

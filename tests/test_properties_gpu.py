@@ -80,6 +80,32 @@ def test_diffusion_batch_invariance(engine, mid_models, pkg, noise_mode):
             assert (x == y).all() and np.isfinite(x).all() and np.abs(x).max() <= 1.0 + 1e-6
 
 
+def test_diffusion_shared_unconditioned_integrator(engine, mid_models):
+    """Unconditioned sequences of equal length share one evaluation of the conditioning_timestep_integrator layers
+    (option share_uncond, default on). Same math per row: the mel must agree with the unshared evaluation and with a
+    batch of one to rounding level."""
+    engine.load(diffusion=mid_models + "/ggml-diffusion-model.bin")
+    lats = [_latents(61, 1), _latents(61, 5), _latents(130, 4), _latents(61, 6)]  # T = 265, 265, 565, 265
+    n_steps = 3
+    rs = np.random.RandomState(9)
+    noise = [rs.randn(n_steps + 1, 100 * engine.frames(len(l))).astype(np.float32) for l in lats]
+    try:
+        engine.set_option("share_uncond", 1)
+        shared = engine.diffusion(lats, n_steps=n_steps, noise=noise)
+        engine.set_option("share_uncond", 0)
+        plain = engine.diffusion(lats, n_steps=n_steps, noise=noise)
+    finally:
+        engine.set_option("share_uncond", 1)
+    for c in range(len(lats)):
+        assert np.isfinite(shared[c]).all()
+        err = np.abs(shared[c] - plain[c]).max()
+        assert err < 1e-4, (c, err)
+        solo = engine.diffusion([lats[c]], n_steps=n_steps, noise=[noise[c]])[0]
+        err = np.abs(solo - shared[c]).max()
+        assert err < 1e-4, (c, err)
+    assert np.abs(shared[0] - shared[1]).max() > 1e-3  # different latents and noise: the candidates are not copies
+
+
 def test_vocoder_batch_invariance(engine, mid_models):
     engine.load(vocoder=mid_models + "/ggml-vocoder-model.bin")
     rs = np.random.RandomState(4)

@@ -85,6 +85,7 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
     if (c->sampler_pool) { sampler_pool_free(c->sampler_pool); c->sampler_pool = nullptr; }
     c->sampler_threads = value < 0 ? -1 : (int)value;
   }
+  else if (k == "share_uncond") c->share_uncond = value != 0;
   else return fail(c, TTS_ERR_ARG, "unknown option '%s'", key);
   return TTS_OK;
 }

@@ -77,6 +77,7 @@ struct tts_ctx {
   tts::Tokenizer *tok = nullptr;
   tts::SamplerPool *sampler_pool = nullptr; // worker threads for the per-candidate sampler scans (host_logic.cpp)
   int sampler_threads = -1;                 // -1: min(7, hardware threads - 1); option "sampler_threads"
+  bool share_uncond = true;                 // option "share_uncond": see DiffState::share_integ (diffusion.hip)
   // profiling: per kernel family, HIP event pairs recorded on the ctx stream around every launch and
   // resolved lazily (no host sync inside the timed region)
   bool prof_on = false;

@@ -216,6 +216,20 @@ __global__ __launch_bounds__(256) void to_f16_kernel(const float *__restrict__ x
   *(uint2 *)(y + (size_t)r * C + c) = o;
 }
 
+// f32 -> fp16 copy of rows gathered from another layout: y[r] = x[src_row[r]], zero where src_row[r] < 0 (guard rows).
+__global__ __launch_bounds__(256) void gather_f16_kernel(const float *__restrict__ x, const int *__restrict__ src_row,
+                                                         __half *__restrict__ y) {
+  const int r = blockIdx.x, c = threadIdx.x * 4, sr = src_row[r];
+  uint2 o = make_uint2(0u, 0u);
+  if (sr >= 0) {
+    float4 v = *(const float4 *)(x + (size_t)sr * C + c);
+    __half2 p0 = __floats2half2_rn(v.x, v.y), p1 = __floats2half2_rn(v.z, v.w);
+    o.x = *(unsigned *)&p0;
+    o.y = *(unsigned *)&p1;
+  }
+  *(uint2 *)(y + (size_t)r * C + c) = o;
+}
+
 // Multi-head attention with T5 relative-position bias (AttentionBlock, main.cpp:3232-3275).
 // One block = 128 queries of one (sequence, head): 4 waves x 32 queries; keys stream through a double
 // buffered LDS stage (global->LDS DMA) in tiles of 64. Everything is computed TRANSPOSED so that a lane owns
@@ -648,8 +662,14 @@ struct DiffState {
   __half *lc_w = nullptr, *inp_w = nullptr, *integ_w = nullptr, *out_w = nullptr;
   std::vector<void *> owned;
   // run state
-  Layout lay, lat_lay;
-  Work wk, lat_wk;
+  Layout lay, lat_lay, ilay;
+  Work wk, lat_wk, iwk;
+  // The conditioning_timestep_integrator stage sees only (code embedding, timestep): for the unconditioned branch its
+  // input is the same vector at every position, so unconditioned sequences of equal length give identical results. With
+  // share_integ the stage runs on ilay = [conditioned sequences | one unconditioned sequence per distinct length] and
+  // its output rows are gathered into the full layout (ce_src: source row per row of `lay`).
+  bool share_integ = false;
+  DevBuf ce_src, iseq_src;
   DevBuf code_emb, ce, ce16, xt16, inp16, net, temb, e1, emb, ss_all, xbuf, xoff, noise, seq_src, lat_in16, out_ct;
   ~DiffState() { for (void *p : owned) (void)hipFree(p); }
   int n_res() const { return n_integ + n_main + n_tail; }
@@ -977,6 +997,48 @@ static int res_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, f
   return gemm(ctx, "diff_gemm", c3, lay, 0, 0, &wk);
 }
 
+// x = silu(x) in place (exact expf and division; lut: through fp16 on both sides like ggml's table). Applied once to the
+// time-MLP activations so that linear_nk_kernel does not redo it for every output column.
+static __global__ __launch_bounds__(256) void silu_inplace_kernel(float *__restrict__ x, int n, int lut) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = x[i];
+  if (lut) v = __half2float(__float2half_rn(v));
+  v = v / (1.f + expf(-v));
+  if (lut) v = __half2float(__float2half_rn(v));
+  x[i] = v;
+}
+
+// out[r][n] = sum_k x[r][k] * W[n][k] + b[n] for small row counts (time MLP, emb_layers):
+// one wave per output column, 16-byte loads along K, shuffle reduction. F32 exact (reference: F32 mul_mat).
+static __global__ __launch_bounds__(256) void linear_nk_kernel(const float *__restrict__ x, int ldx, int rows, const float *__restrict__ W,
+                                                        int K, int N, const float *__restrict__ b, float *__restrict__ out, int ldo) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const float *wr = W + (size_t)n * K;
+  for (int r0 = 0; r0 < rows; r0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+      const float4 w = *(const float4 *)(wr + k);
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const float4 xv = *(const float4 *)(x + (size_t)min(r0 + i, rows - 1) * ldx + k);
+        acc[i] = fmaf(xv.x, w.x, acc[i]); acc[i] = fmaf(xv.y, w.y, acc[i]);
+        acc[i] = fmaf(xv.z, w.z, acc[i]); acc[i] = fmaf(xv.w, w.w, acc[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      float v = acc[i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0 && r0 + i < rows) out[(size_t)(r0 + i) * ldo + n] = v + (b ? b[n] : 0.f);
+    }
+  }
+}
+
 // Timestep MLP + every emb_layers linear for `n` timesteps at once:
 //   emb = W2 silu(W0 te + b0) + b2 (main.cpp:3331-3343); ss[j] = Wemb_j silu(emb) + bemb_j (3410-3428).
 static int precompute_time(tts_ctx *ctx, DiffState *st, const std::vector<int> &timesteps) {
@@ -987,14 +1049,16 @@ static int precompute_time(tts_ctx *ctx, DiffState *st, const std::vector<int> &
   TTS_HIP(ctx, st->ss_all.reserve((size_t)n * nres * 2 * C * 4));
   TTS_HIP(ctx, hipMemcpyAsync(st->temb.p, te.data(), te.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  linear_nk_kernel<0><<<C / 4, 256, 0, ctx->stream>>>(st->temb.as<float>(), C, n, st->te0_w, C, C, st->te0_b, st->e1.as<float>(), C, 0);
-  linear_nk_kernel<1><<<C / 4, 256, 0, ctx->stream>>>(st->e1.as<float>(), C, n, st->te2_w, C, C, st->te2_b, st->emb.as<float>(), C, ctx->ggml_lut);
+  linear_nk_kernel<<<C / 4, 256, 0, ctx->stream>>>(st->temb.as<float>(), C, n, st->te0_w, C, C, st->te0_b, st->e1.as<float>(), C);
+  silu_inplace_kernel<<<(n * C + 255) / 256, 256, 0, ctx->stream>>>(st->e1.as<float>(), n * C, ctx->ggml_lut);
+  linear_nk_kernel<<<C / 4, 256, 0, ctx->stream>>>(st->e1.as<float>(), C, n, st->te2_w, C, C, st->te2_b, st->emb.as<float>(), C);
+  silu_inplace_kernel<<<(n * C + 255) / 256, 256, 0, ctx->stream>>>(st->emb.as<float>(), n * C, ctx->ggml_lut); // emb is only used activated
   for (int j = 0; j < nres; j++) {
     const ResDev &w = j < st->n_integ ? st->integ_res[j] : j < st->n_integ + st->n_main ? st->main_res[j - st->n_integ]
                                                                                         : st->tail_res[j - st->n_integ - st->n_main];
     // out row i -> ss_all[(i*nres + j)*2048]
-    linear_nk_kernel<1><<<2 * C / 4, 256, 0, ctx->stream>>>(st->emb.as<float>(), C, n, w.emb_w, C, 2 * C, w.emb_b,
-                                                            st->ss_all.as<float>() + (size_t)j * 2 * C, nres * 2 * C, ctx->ggml_lut);
+    linear_nk_kernel<<<2 * C / 4, 256, 0, ctx->stream>>>(st->emb.as<float>(), C, n, w.emb_w, C, 2 * C, w.emb_b,
+                                                         st->ss_all.as<float>() + (size_t)j * 2 * C, nres * 2 * C);
   }
   TTS_HIP(ctx, hipGetLastError());
   return TTS_OK;
@@ -1033,16 +1097,20 @@ static int latent_conditioner(tts_ctx *ctx, DiffState *st, const float *latents_
 static int network_forward(tts_ctx *ctx, DiffState *st, const float *ss) {
   Layout &lay = st->lay;
   Work &wk = st->wk;
+  Layout &il = st->share_integ ? st->ilay : st->lay; // layout of the integrator stage
+  Work &iw = st->share_integ ? st->iwk : st->wk;
   float *ce = st->ce.as<float>();
   wk.raw_owner = nullptr;
-  TTS_HIP(ctx, hipMemcpyAsync(ce, st->code_emb.p, (size_t)lay.rows * C * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  iw.raw_owner = nullptr;
+  TTS_HIP(ctx, hipMemcpyAsync(ce, st->code_emb.p, (size_t)il.rows * C * 4, hipMemcpyDeviceToDevice, ctx->stream));
   int j = 0;
   for (int i = 0; i < st->n_integ; i++, j++) {
-    CHECK(res_block(ctx, st, lay, wk, ce, st->integ_res[i], ss + (size_t)j * 2 * C));
-    CHECK(attention_block(ctx, st, lay, wk, ce, st->integ_attn[i]));
+    CHECK(res_block(ctx, st, il, iw, ce, st->integ_res[i], ss + (size_t)j * 2 * C));
+    CHECK(attention_block(ctx, st, il, iw, ce, st->integ_attn[i]));
   }
   __half *ce16 = st->ce16.as<__half>(), *inp16 = st->inp16.as<__half>();
-  to_f16_kernel<<<lay.rows, 256, 0, ctx->stream>>>(ce, lay.d_row_seq.as<int>(), ce16);
+  if (st->share_integ) gather_f16_kernel<<<lay.rows, 256, 0, ctx->stream>>>(ce, st->ce_src.as<int>(), ce16);
+  else to_f16_kernel<<<lay.rows, 256, 0, ctx->stream>>>(ce, lay.d_row_seq.as<int>(), ce16);
   // inp_block: conv k3 100(->128) -> 1024 on x_t, output rounded to fp16 (operand of the next conv)
   GemmArgs gi = gemm_base(lay, st->xt16.as<__half>() + XTC, XTC, 3, XTC, st->inp_w, C, st->inp_bias);
   gi.mode = GEMM_OUT_F16; gi.outH = inp16; gi.ldh = C;
@@ -1088,14 +1156,43 @@ static int setup_batch(tts_ctx *ctx, DiffState *st, const float *latents, const 
   TTS_HIP(ctx, rz(st->net, (size_t)lay.rows * 256 * 4));
   TTS_HIP(ctx, st->seq_src.reserve(lay.ns * 4));
   TTS_HIP(ctx, hipMemcpy(st->seq_src.p, src.data(), lay.ns * 4, hipMemcpyHostToDevice));
+  // integrator layout: every conditioned sequence, one unconditioned sequence per distinct length
+  std::vector<int> ilens, isrc, seq_map(lay.ns);
+  {
+    std::vector<std::pair<int, int>> uniq; // (length, sequence of ilay)
+    for (int s = 0; s < lay.ns; s++) {
+      int found = -1;
+      if (src[s] < 0)
+        for (auto &u : uniq) if (u.first == lens[s]) found = u.second;
+      if (found < 0) {
+        found = (int)ilens.size();
+        ilens.push_back(lens[s]); isrc.push_back(src[s]);
+        if (src[s] < 0) uniq.push_back({lens[s], found});
+      }
+      seq_map[s] = found;
+    }
+  }
+  st->share_integ = ctx->share_uncond && (int)ilens.size() < lay.ns; // option off: every unconditioned sequence is evaluated
+  if (st->share_integ) {
+    CHECK(st->ilay.build(ctx, ilens));
+    CHECK(st->iwk.reserve(ctx, st->ilay.rows, st->ilay.ns));
+    std::vector<int> cs(lay.rows, -1);
+    for (int s = 0; s < lay.ns; s++)
+      for (int t = 0; t < lens[s]; t++) cs[lay.start[s] + t] = st->ilay.start[seq_map[s]] + t;
+    TTS_HIP(ctx, st->ce_src.reserve((size_t)lay.rows * 4));
+    TTS_HIP(ctx, hipMemcpy(st->ce_src.p, cs.data(), (size_t)lay.rows * 4, hipMemcpyHostToDevice));
+    TTS_HIP(ctx, st->iseq_src.reserve(st->ilay.ns * 4));
+    TTS_HIP(ctx, hipMemcpy(st->iseq_src.p, isrc.data(), st->ilay.ns * 4, hipMemcpyHostToDevice));
+  }
+  Layout &il = st->share_integ ? st->ilay : st->lay;
   if (cond) CHECK(latent_conditioner(ctx, st, latents, L));
   else { // layout still needed by build_code_emb (never dereferenced for uncond rows)
     CHECK(st->lat_lay.build(ctx, L));
     CHECK(st->lat_wk.reserve(ctx, st->lat_lay.rows, st->lat_lay.ns));
   }
-  build_code_emb_kernel<<<lay.rows, 256, 0, ctx->stream>>>(st->lat_wk.H(), st->lat_lay.d_start.as<int>(), st->lat_lay.d_len.as<int>(),
-                                                           st->uncond_emb, lay.d_row_seq.as<int>(), lay.d_row_t.as<int>(),
-                                                           lay.d_len.as<int>(), st->seq_src.as<int>(), st->code_emb.as<float>());
+  build_code_emb_kernel<<<il.rows, 256, 0, ctx->stream>>>(st->lat_wk.H(), st->lat_lay.d_start.as<int>(), st->lat_lay.d_len.as<int>(),
+                                                          st->uncond_emb, il.d_row_seq.as<int>(), il.d_row_t.as<int>(), il.d_len.as<int>(),
+                                                          (st->share_integ ? st->iseq_src : st->seq_src).as<int>(), st->code_emb.as<float>());
   TTS_HIP(ctx, hipGetLastError());
   return TTS_OK;
 }

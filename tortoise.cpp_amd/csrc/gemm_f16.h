@@ -398,50 +398,4 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
   return hipGetLastError();
 }
 
-// out[r][n] = act(sum_k x[r][k] * W[n][k] + b[n]) for small row counts (time MLP, emb_layers):
-// one wave per output column, 16-byte loads along K, shuffle reduction. F32 exact (reference: F32 mul_mat).
-template <int ACT_SILU_IN>
-static __global__ __launch_bounds__(256) void linear_nk_kernel(const float *__restrict__ x, int ldx, int rows, const float *__restrict__ W,
-                                                        int K, int N, const float *__restrict__ b, float *__restrict__ out, int ldo,
-                                                        int lut) {
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (n >= N) return;
-  const float *wr = W + (size_t)n * K;
-  for (int r0 = 0; r0 < rows; r0 += 8) {
-    float acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) acc[i] = 0.f;
-    for (int k = lane * 4; k < K; k += 256) {
-      const float4 w = *(const float4 *)(wr + k);
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        if (r0 + i < rows) {
-          float4 xv = *(const float4 *)(x + (size_t)(r0 + i) * ldx + k);
-          if (ACT_SILU_IN) {
-            if (lut) {
-              xv.x = __half2float(__float2half_rn(xv.x)); xv.y = __half2float(__float2half_rn(xv.y));
-              xv.z = __half2float(__float2half_rn(xv.z)); xv.w = __half2float(__float2half_rn(xv.w));
-            }
-            xv.x = xv.x / (1.f + expf(-xv.x)); xv.y = xv.y / (1.f + expf(-xv.y));
-            xv.z = xv.z / (1.f + expf(-xv.z)); xv.w = xv.w / (1.f + expf(-xv.w));
-            if (lut) {
-              xv.x = __half2float(__float2half_rn(xv.x)); xv.y = __half2float(__float2half_rn(xv.y));
-              xv.z = __half2float(__float2half_rn(xv.z)); xv.w = __half2float(__float2half_rn(xv.w));
-            }
-          }
-          acc[i] = fmaf(xv.x, w.x, acc[i]); acc[i] = fmaf(xv.y, w.y, acc[i]);
-          acc[i] = fmaf(xv.z, w.z, acc[i]); acc[i] = fmaf(xv.w, w.w, acc[i]);
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      float v = acc[i];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-      if (lane == 0 && r0 + i < rows) out[(size_t)(r0 + i) * ldo + n] = v + (b ? b[n] : 0.f);
-    }
-  }
-}
-
 } // namespace tts
