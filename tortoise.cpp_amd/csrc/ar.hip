@@ -844,6 +844,7 @@ struct ArState {
   std::vector<void *> owned;
   // run state
   int B = 0, n_text = 0, P = 0, max_pos = 0;
+  bool prefill_done = false; // the prompt's K/V rows are in the decode cache (set by ar_prefill, cleared by ar_begin)
   std::vector<int> tokens;
   DevBuf voice, kcache, vcache, lat_k, lat_v;
   DevBuf h, xn, qkv, att, ff, part, desc, logits, hn, a_hi, a_lo;
@@ -1196,6 +1197,7 @@ int ar_begin(tts_ctx *ctx, const int32_t *text_ids, int n_text, const float *voi
   for (int i = 0; i < n_text; i++)
     if (text_ids[i] < 0 || text_ids[i] >= 256) return fail(ctx, TTS_ERR_ARG, "text id %d out of range", text_ids[i]);
   st->B = B; st->n_text = n_text; st->P = n_text + 2;
+  st->prefill_done = false;
   st->max_pos = st->P + max_steps + 1;
   if (st->max_pos > 1024) return fail(ctx, TTS_ERR_LIMIT, "context of %d positions exceeds 1024", st->max_pos);
   st->tokens.assign(text_ids, text_ids + n_text);
@@ -1259,6 +1261,7 @@ int ar_prefill(tts_ctx *ctx, float *logits_out) {
   } else {
     TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
+  st->prefill_done = true;
   return TTS_OK;
 }
 
@@ -1310,7 +1313,9 @@ int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out
   st->h_toks[st->B] = st->P + step_i; // n_past
   st->h_toks[st->B + 1] = step_i + 2; // mel position id (main.cpp:5244)
   static const bool no_graph = getenv("TTS_NO_GRAPH") != nullptr; // e.g. under rocprofv3, which crashes on graph replays here
-  if (ctx->prof_on || no_graph) { // event records are not captured: run eagerly when profiling
+  // event records are not captured: the step runs eagerly while one of its own kernel families ("ar_*") is profiled
+  const bool prof_ar = ctx->prof_on && (ctx->prof_filter.empty() || ctx->prof_filter.rfind("ar_", 0) == 0);
+  if (prof_ar || no_graph) {
     CHECK(enqueue_decode_step(ctx, st));
   } else {
     if (!st->graph_exec) {
@@ -1329,36 +1334,54 @@ int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out
 }
 
 // Latent pass (main.cpp:2053-2519, 5280-5352): full causal forward without the decode cache.
+// dst[l][c][p][:] = src[l][0][p][:] for p < n_prompt: the prompt rows of the decode cache (identical for every candidate)
+// become the first rows of every candidate in the latent pass' K/V buffers. grid (n_prompt, nb, 2 * n_layers).
+__global__ __launch_bounds__(256) void copy_prompt_kv_kernel(const __half *__restrict__ ksrc, const __half *__restrict__ vsrc,
+                                                             size_t src_layer_stride, __half *__restrict__ kdst, __half *__restrict__ vdst,
+                                                             size_t dst_layer_stride, int S, int n_layers) {
+  const int p = blockIdx.x, c = blockIdx.y, l = blockIdx.z % n_layers;
+  const bool isv = (int)blockIdx.z >= n_layers;
+  const __half *src = (isv ? vsrc : ksrc) + l * src_layer_stride + (size_t)p * D;
+  __half *dst = (isv ? vdst : kdst) + l * dst_layer_stride + ((size_t)c * S + p) * D;
+  ((uint2 *)dst)[threadIdx.x] = ((const uint2 *)src)[threadIdx.x];
+}
+
+// Latent pass (main.cpp:2053-2519): the full stack over [voice | text | mel codes at mel positions 0..] without the
+// decode cache's position quirk. The 1 + n_text prompt rows are the same for every candidate and do not depend on the
+// mel rows (causal mask): their K/V rows are taken from the decode cache (written by the prompt pass), so the stack runs
+// over the mel rows only, with n_past = 1 + n_text.
 int ar_latents(tts_ctx *ctx, const int32_t *codes502, int nb, int n_mel, float *out) {
   ArState *st = ctx->ar;
   if (!st || st->n_text == 0) return fail(ctx, TTS_ERR_STATE, "tts_ar_begin not called");
   if (nb < 1 || n_mel < 1 || n_mel > 502) return fail(ctx, TTS_ERR_ARG, "tts_ar_latents: bad argument");
-  const int S = 1 + st->n_text + n_mel, rows = nb * S;
+  const int Sp = 1 + st->n_text, S = Sp + n_mel, rows = nb * n_mel;
   if (S > 1024) return fail(ctx, TTS_ERR_LIMIT, "latent pass of %d positions exceeds 1024", S);
-  CHECK(reserve_rows(ctx, st, rows));
-  TTS_HIP(ctx, st->lat_k.reserve((size_t)rows * D * sizeof(__half)));
-  TTS_HIP(ctx, st->lat_v.reserve((size_t)rows * D * sizeof(__half)));
-  std::vector<int4> desc(rows);
-  for (int c = 0; c < nb; c++) {
-    int4 *d = desc.data() + (size_t)c * S;
-    d[0] = make_int4(0, 0, -1, 0);
-    for (int i = 0; i < st->n_text; i++) d[1 + i] = make_int4(1, st->tokens[i], 0, i);
+  for (int c = 0; c < nb; c++)
     for (int j = 0; j < n_mel; j++) {
-      int code = codes502[c * 502 + j];
+      const int code = codes502[c * 502 + j];
       if (code < 0 || code >= V) return fail(ctx, TTS_ERR_ARG, "mel code %d out of range", code);
-      d[1 + st->n_text + j] = make_int4(2, code, 1, j);
     }
-  }
+  if (!st->prefill_done) CHECK(ar_prefill(ctx, nullptr));
+  CHECK(reserve_rows(ctx, st, rows));
+  const size_t lat_stride = (size_t)nb * S * D; // per layer: [cand][S][1024]
+  TTS_HIP(ctx, st->lat_k.reserve(st->n_layers * lat_stride * sizeof(__half)));
+  TTS_HIP(ctx, st->lat_v.reserve(st->n_layers * lat_stride * sizeof(__half)));
+  copy_prompt_kv_kernel<<<dim3(Sp, nb, 2 * st->n_layers), 256, 0, ctx->stream>>>(
+      st->kcache.as<__half>(), st->vcache.as<__half>(), (size_t)st->B * st->max_pos * D, st->lat_k.as<__half>(), st->lat_v.as<__half>(),
+      lat_stride, S, st->n_layers);
+  std::vector<int4> desc(rows);
+  for (int c = 0; c < nb; c++)
+    for (int j = 0; j < n_mel; j++) desc[(size_t)c * n_mel + j] = make_int4(2, codes502[c * 502 + j], 1, j);
   CHECK(embed(ctx, st, desc));
-  CHECK(run_layers(ctx, st, rows, S, 0, st->lat_k.as<__half>(), st->lat_v.as<__half>(), 0, S, 0));
+  CHECK(run_layers(ctx, st, rows, n_mel, Sp, st->lat_k.as<__half>(), st->lat_v.as<__half>(), lat_stride, S, 0));
   float *xn = st->xn.as<float>(), *hn = st->hn.as<float>();
   layernorm_kernel<<<rows, 256, 0, ctx->stream>>>(st->h.as<float>(), st->lnf_g, st->lnf_b, xn);
   layernorm_kernel<<<rows, 256, 0, ctx->stream>>>(xn, st->lmh_g, st->lmh_b, hn);
   TTS_HIP(ctx, hipGetLastError());
   const int n_out = std::min(500, n_mel);
   for (int c = 0; c < nb; c++)
-    TTS_HIP(ctx, hipMemcpyAsync(out + (size_t)c * n_out * D, hn + ((size_t)c * S + 1 + st->n_text) * D,
-                                (size_t)n_out * D * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TTS_HIP(ctx, hipMemcpyAsync(out + (size_t)c * n_out * D, hn + (size_t)c * n_mel * D, (size_t)n_out * D * 4, hipMemcpyDeviceToHost,
+                                ctx->stream));
   TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return TTS_OK;
 }
