@@ -70,45 +70,6 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__
   }
 }
 
-// y = [silu]( (((x-mean)*rstd)*g + b) [* (1+scale) + shift] ) -> fp16 GEMM operand (the reference's
-// im2col rounds conv inputs to fp16). Guard/padding rows are written as zeros. One block per row.
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const int *__restrict__ row_seq,
-                                                       const float2 *__restrict__ stats, const float *__restrict__ g,
-                                                       const float *__restrict__ b, const float *__restrict__ ss /*[2048] or null*/,
-                                                       int do_silu, int lut, __half *__restrict__ y,
-                                                       const int *__restrict__ seq_len, float raw_eps) {
-  const int r = blockIdx.x, c = threadIdx.x * 4, s = row_seq[r];
-  uint2 o = make_uint2(0u, 0u);
-  if (s >= 0) {
-    float2 st = stats[s * 32 + (c >> 5)];
-    if (seq_len) { // raw (sum, sum of squares) accumulated by the producing GEMM's epilogue
-      const float n = (float)seq_len[s] * 32.f, mean = st.x / n;
-      st = make_float2(mean, 1.0f / sqrtf(fmaxf(st.y / n - mean * mean, 0.f) + raw_eps));
-    }
-    float4 v = *(const float4 *)(x + (size_t)r * C + c);
-    const float4 gg = *(const float4 *)(g + c), bb = *(const float4 *)(b + c);
-    float e[4] = {v.x, v.y, v.z, v.w};
-    const float ge[4] = {gg.x, gg.y, gg.z, gg.w}, be[4] = {bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      float t = (e[i] - st.x) * st.y;
-      t = t * ge[i];
-      t = t + be[i];
-      if (ss) {
-        t = t * (ss[c + i] + 1.0f); // conditioning_scale_offset = 1.0 (main.cpp:5778)
-        t = t + ss[C + c + i];
-      }
-      if (do_silu) t = silu_dev(t, lut);
-      e[i] = t;
-    }
-    __half2 p0 = __floats2half2_rn(e[0], e[1]), p1 = __floats2half2_rn(e[2], e[3]);
-    o.x = *(unsigned *)&p0;
-    o.y = *(unsigned *)&p1;
-  }
-  *(uint2 *)(y + (size_t)r * C + c) = o;
-}
-
-
 // Fused GroupNorm: statistics AND normalise/affine/[scale-shift]/[SiLU]/fp16 in one launch. One block owns
 // two adjacent groups (64 channels) of one sequence: pass 1 reads the [T][64] slab (256 B per row) and
 // reduces sum / sum of squares around a pivot, pass 2 re-reads it (L2-resident: T*256 B) and writes the fp16
@@ -624,9 +585,7 @@ struct Layout {
 // k=3 taps read rows -1 and `rows`) plus 128 rows of slack for the attention tiles.
 struct Work {
   int rows = 0;
-  DevBuf x, hbuf, a16, att16, qk16, vt16, stats, raw;
-  const float *raw_owner = nullptr; // tensor whose raw GroupNorm sums (from a GEMM epilogue) are in `raw`
-  bool use_raw = false;
+  DevBuf x, hbuf, a16, att16, qk16, vt16, stats;
   float *X() { return x.as<float>(); }
   float *H() { return hbuf.as<float>(); }
   __half *A16() { return a16.as<__half>() + C; }
@@ -646,8 +605,6 @@ struct Work {
     TTS_HIP(ctx, rz(qk16, (size_t)(r + 128) * 2048 * 2));
     TTS_HIP(ctx, rz(vt16, (size_t)C * (r + 128) * 2));
     TTS_HIP(ctx, rz(stats, (size_t)ns * 32 * sizeof(float2)));
-    TTS_HIP(ctx, rz(raw, (size_t)ns * 32 * sizeof(float2)));
-    raw_owner = nullptr;
     return TTS_OK;
   }
 };
@@ -670,6 +627,7 @@ struct DiffState {
   // its output rows are gathered into the full layout (ce_src: source row per row of `lay`).
   bool share_integ = false;
   DevBuf ce_src, iseq_src;
+  DevBuf h0; // in_layers of the first integrator ResBlock applied to the code embedding: the same at every step
   DevBuf code_emb, ce, ce16, xt16, inp16, net, temb, e1, emb, ss_all, xbuf, xoff, noise, seq_src, lat_in16, out_ct;
   ~DiffState() { for (void *p : owned) (void)hipFree(p); }
   int n_res() const { return n_integ + n_main + n_tail; }
@@ -815,13 +773,11 @@ int diff_load(tts_ctx *ctx, const char *path) {
 #define CHECK(x) do { int _r = (x); if (_r) return _r; } while (0)
 
 // algorithmic FLOPs of one launch: valid rows (no guard/pad rows) x valid columns x valid K
-static int gemm(tts_ctx *ctx, const char *fam, GemmArgs &g, const Layout &lay, int n_valid = 0, int k_valid = 0,
-                Work *stats_wk = nullptr) {
+static int gemm(tts_ctx *ctx, const char *fam, GemmArgs &g, const Layout &lay, int n_valid = 0, int k_valid = 0) {
   double mv = 0;
   for (int l : lay.len) mv += l;
   // (GroupNorm statistics fused into this epilogue were tried and measured slower: +2.7 ms/step of GEMM
   //  time for 1.0 ms/step of gn_stats saved — register pressure costs a resident workgroup per CU.)
-  (void)stats_wk;
   static const bool log_shapes = getenv("TTS_GEMM_LOG") != nullptr; // developer aid: one line per launch
   if (log_shapes) fprintf(stderr, "gemm M=%d N=%d K=%dx%d mode=%d resid=%d\n", g.M, g.N, g.nseg, g.kseg, g.mode, g.resid != nullptr);
   ProfScope ps(ctx, fam, 2.0 * mv * (n_valid ? n_valid : g.N) * (k_valid ? k_valid : g.nseg * g.kseg));
@@ -840,8 +796,6 @@ static GemmArgs gemm_base(const Layout &lay, const __half *A, int lda, int nseg,
 }
 
 static int gn_stats(tts_ctx *ctx, const Layout &lay, Work &wk, const float *x) {
-  wk.use_raw = (wk.raw_owner == x);
-  if (wk.use_raw) return TTS_OK; // sums were produced by the GEMM that wrote x
   ProfScope ps(ctx, "diff_gn_stats");
   gn_stats_kernel<<<dim3(32, lay.ns), 256, 0, ctx->stream>>>(x, lay.d_start.as<int>(), lay.d_len.as<int>(), ctx->gn_eps,
                                                              wk.stats.as<float2>());
@@ -960,6 +914,14 @@ static int gn_fused(tts_ctx *ctx, const Layout &lay, const float *x, const float
   return TTS_OK;
 }
 
+// in_layers of a ResBlock (GroupNorm, SiLU, conv k=1): H = conv(silu(gn(x))). No timestep dependence.
+static int res_in_layers(tts_ctx *ctx, const Layout &lay, Work &wk, const float *x, const ResDev &w, float *H) {
+  CHECK(gn_fused(ctx, lay, x, w.in_g, w.in_b, nullptr, 1, wk.A16()));
+  GemmArgs g = gemm_base(lay, wk.A16(), C, 1, C, w.in_w, C, w.in_bias);
+  g.mode = GEMM_OUT_F32; g.outF = H; g.ldo = C; g.resid = nullptr;
+  return gemm(ctx, "diff_gemm", g, lay);
+}
+
 // AttentionBlock on X (in place).
 static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, float *X, const AttnDev &w) {
   CHECK(gn_fused(ctx, lay, X, w.norm_g, w.norm_b, nullptr, 0, wk.A16()));
@@ -982,19 +944,23 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
   }
   GemmArgs p = gemm_base(lay, wk.ATT16(), C, 1, C, w.proj_w, C, w.proj_b);
   p.mode = GEMM_OUT_F32; p.outF = X; p.ldo = C; p.resid = X;
-  return gemm(ctx, "diff_gemm", p, lay, 0, 0, &wk);
+  return gemm(ctx, "diff_gemm", p, lay);
 }
 
-// ResBlock on X (in place); ss = this step's [scale | shift] for this block (device, 2048 floats).
-static int res_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, float *X, const ResDev &w, const float *ss) {
-  CHECK(gn_fused(ctx, lay, X, w.in_g, w.in_b, nullptr, 1, wk.A16()));
-  GemmArgs g = gemm_base(lay, wk.A16(), C, 1, C, w.in_w, C, w.in_bias);
-  g.mode = GEMM_OUT_F32; g.outF = wk.H(); g.ldo = C; g.resid = nullptr;
-  CHECK(gemm(ctx, "diff_gemm", g, lay, 0, 0, &wk));
-  CHECK(gn_fused(ctx, lay, wk.H(), w.out_g, w.out_b, ss, 1, wk.A16()));
+// ResBlock: X = Xin + out_layers(in_layers(Xin) with the step's scale/shift); Xin == nullptr: in place on X.
+// ss = this step's [scale | shift] for this block (device, 2048 floats). Hpre: in_layers(Xin) computed earlier (it does
+// not depend on the timestep), nullptr: computed here.
+static int res_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, float *X, const ResDev &w, const float *ss,
+                     const float *Xin = nullptr, const float *Hpre = nullptr) {
+  const float *xin = Xin ? Xin : X;
+  if (!Hpre) {
+    CHECK(res_in_layers(ctx, lay, wk, xin, w, wk.H()));
+    Hpre = wk.H();
+  }
+  CHECK(gn_fused(ctx, lay, Hpre, w.out_g, w.out_b, ss, 1, wk.A16()));
   GemmArgs c3 = gemm_base(lay, wk.A16(), C, 3, C, w.out_w, C, w.out_bias);
-  c3.mode = GEMM_OUT_F32; c3.outF = X; c3.ldo = C; c3.resid = X;
-  return gemm(ctx, "diff_gemm", c3, lay, 0, 0, &wk);
+  c3.mode = GEMM_OUT_F32; c3.outF = X; c3.ldo = C; c3.resid = xin;
+  return gemm(ctx, "diff_gemm", c3, lay);
 }
 
 // x = silu(x) in place (exact expf and division; lut: through fp16 on both sides like ggml's table). Applied once to the
@@ -1082,9 +1048,8 @@ static int latent_conditioner(tts_ctx *ctx, DiffState *st, const float *latents_
   to_f16_kernel<<<ll.rows, 256, 0, ctx->stream>>>(wk.X(), ll.d_row_seq.as<int>(), wk.A16());
   GemmArgs c3 = gemm_base(ll, wk.A16(), C, 3, C, st->lc_w, C, st->lc_bias);
   c3.mode = GEMM_OUT_F32; c3.outF = wk.X(); c3.ldo = C; c3.resid = nullptr;
-  CHECK(gemm(ctx, "diff_gemm", c3, ll, 0, 0, &wk));
+  CHECK(gemm(ctx, "diff_gemm", c3, ll));
   for (int i = 0; i < st->n_lc; i++) CHECK(attention_block(ctx, st, ll, wk, wk.X(), st->lc_attn[i]));
-  wk.raw_owner = nullptr; // code_norm uses the (mean, rstd) form of the standalone kernel
   CHECK(gn_stats(ctx, ll, wk, wk.X()));
   gn_apply_f32_kernel<<<ll.rows, 256, 0, ctx->stream>>>(wk.X(), ll.d_row_seq.as<int>(), wk.stats.as<float2>(), st->code_g, st->code_b,
                                                         st->cond_latent, wk.H());
@@ -1100,12 +1065,12 @@ static int network_forward(tts_ctx *ctx, DiffState *st, const float *ss) {
   Layout &il = st->share_integ ? st->ilay : st->lay; // layout of the integrator stage
   Work &iw = st->share_integ ? st->iwk : st->wk;
   float *ce = st->ce.as<float>();
-  wk.raw_owner = nullptr;
-  iw.raw_owner = nullptr;
-  TTS_HIP(ctx, hipMemcpyAsync(ce, st->code_emb.p, (size_t)il.rows * C * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  if (st->n_integ == 0) TTS_HIP(ctx, hipMemcpyAsync(ce, st->code_emb.p, (size_t)il.rows * C * 4, hipMemcpyDeviceToDevice, ctx->stream));
   int j = 0;
   for (int i = 0; i < st->n_integ; i++, j++) {
-    CHECK(res_block(ctx, st, il, iw, ce, st->integ_res[i], ss + (size_t)j * 2 * C));
+    // first block: reads the code embedding directly, its timestep-independent half (st->h0) comes from setup_batch
+    if (i == 0) CHECK(res_block(ctx, st, il, iw, ce, st->integ_res[0], ss, st->code_emb.as<float>(), st->h0.as<float>()));
+    else CHECK(res_block(ctx, st, il, iw, ce, st->integ_res[i], ss + (size_t)j * 2 * C));
     CHECK(attention_block(ctx, st, il, iw, ce, st->integ_attn[i]));
   }
   __half *ce16 = st->ce16.as<__half>(), *inp16 = st->inp16.as<__half>();
@@ -1119,7 +1084,7 @@ static int network_forward(tts_ctx *ctx, DiffState *st, const float *ss) {
   GemmArgs gc = gemm_base(lay, inp16, C, 2, C, st->integ_w, C, st->integ_bias);
   gc.A[1] = ce16;
   gc.mode = GEMM_OUT_F32; gc.outF = wk.X(); gc.ldo = C; gc.resid = nullptr;
-  CHECK(gemm(ctx, "diff_gemm", gc, lay, 0, 0, &wk));
+  CHECK(gemm(ctx, "diff_gemm", gc, lay));
   for (int i = 0; i < st->n_main; i++, j++) {
     CHECK(res_block(ctx, st, lay, wk, wk.X(), st->main_res[i], ss + (size_t)j * 2 * C));
     CHECK(attention_block(ctx, st, lay, wk, wk.X(), st->main_attn[i]));
@@ -1194,6 +1159,10 @@ static int setup_batch(tts_ctx *ctx, DiffState *st, const float *latents, const 
                                                           st->uncond_emb, il.d_row_seq.as<int>(), il.d_row_t.as<int>(), il.d_len.as<int>(),
                                                           (st->share_integ ? st->iseq_src : st->seq_src).as<int>(), st->code_emb.as<float>());
   TTS_HIP(ctx, hipGetLastError());
+  if (st->n_integ > 0) {
+    TTS_HIP(ctx, rz(st->h0, (size_t)il.rows * C * 4));
+    CHECK(res_in_layers(ctx, il, st->share_integ ? st->iwk : st->wk, st->code_emb.as<float>(), st->integ_res[0], st->h0.as<float>()));
+  }
   return TTS_OK;
 }
 
