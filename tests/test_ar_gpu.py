@@ -29,6 +29,60 @@ def test_prefill_and_steps_logits(engine, oracle, small_models, voice, B):
         assert rel_err(lg, lo) < 1e-4, i
 
 
+def test_long_context_crosses_attention_chunk(engine, oracle, small_models, voice):
+    """A 280-id prompt: the decode attention walks its keys in chunks of 288, so these steps cross from one chunk to two
+    (283 -> 294 keys); the prompt pass runs 18 position tiles; the latent pass takes 281 prompt K/V rows from the cache."""
+    engine.load(ar=small_models + "/ggml-model.bin")
+    ar = oracle.AR(oracle.Model(small_models + "/ggml-model.bin"))
+    toks = np.random.RandomState(11).randint(1, 250, 280).astype(np.int32)
+    B = 3
+    engine.ar_begin(toks, voice, B, 16)
+    ar.start(toks, voice, B, len(toks) + 2 + 17)
+    assert rel_err(engine.ar_prefill(), ar.prefill()) < 1e-4
+    rs = np.random.RandomState(12)
+    for i in range(12):
+        prev = rs.randint(0, 8192, B).astype(np.int32)
+        assert rel_err(engine.ar_step(prev, i), ar.step(prev, i)) < 1e-4, i
+    codes = rs.randint(0, 8192, (B, 502)).astype(np.int32)
+    codes[:, 0] = 8192
+    lg, lo = engine.ar_latents(codes, 20), ar.latents(codes, 20)
+    assert lg.shape == lo.shape == (B, 20, 1024)
+    assert rel_err(lg, lo) < 1e-4
+
+
+def test_ggml_lut_mode(engine, oracle, small_models, voice):
+    """Option ggml_lut = 1 (GELU through fp16 on both sides, decode softmax exp through fp16) against the
+    oracle's emulation of the same tables. A value that straddles an fp16 rounding boundary can round differently on the
+    two sides (5e-4 relative on that element), hence the wider gate than the default mode's 1e-4."""
+    engine.load(ar=small_models + "/ggml-model.bin")
+    engine.set_option("ggml_lut", 1)
+    oracle.set_flags(lut=1)
+    try:
+        ar = oracle.AR(oracle.Model(small_models + "/ggml-model.bin"))
+        toks, B = DEFAULT_TOKENS, 4
+        engine.ar_begin(toks, voice, B, 8)
+        ar.start(toks, voice, B, len(toks) + 2 + 9)
+        errs = [rel_err(engine.ar_prefill(), ar.prefill())]
+        rs = np.random.RandomState(21)
+        for i in range(5):
+            prev = rs.randint(0, 8192, B).astype(np.int32)
+            errs.append(rel_err(engine.ar_step(prev, i), ar.step(prev, i)))
+        codes = rs.randint(0, 8192, (B, 502)).astype(np.int32)
+        codes[:, 0] = 8192
+        errs.append(rel_err(engine.ar_latents(codes, 24), ar.latents(codes, 24)))
+        print("ggml_lut AR rel errs:", ["%.1e" % e for e in errs])
+        assert max(errs) < 1e-3, errs
+        # the switch does something: default-mode logits differ from LUT-mode logits
+        oracle.set_flags(lut=0)
+        ar2 = oracle.AR(oracle.Model(small_models + "/ggml-model.bin"))
+        ar2.start(toks, voice, B, len(toks) + 2 + 9)
+        engine.ar_begin(toks, voice, B, 8)
+        assert rel_err(engine.ar_prefill(), ar2.prefill()) > 1e-6
+    finally:
+        oracle.set_flags()
+        engine.set_option("ggml_lut", 0)  # the engine fixture is shared by the whole session
+
+
 def test_latents(engine, oracle, small_models, voice):
     engine.load(ar=small_models + "/ggml-model.bin")
     m = oracle.Model(small_models + "/ggml-model.bin")

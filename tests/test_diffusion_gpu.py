@@ -38,6 +38,32 @@ def test_forward_matches_oracle(engine, oracle, small_models, mid_models, models
     assert e < 1e-3, e
 
 
+@pytest.mark.parametrize("gn_eps,lut", [(1e-5, 0), (1e-6, 1)])
+def test_numerics_switches(engine, oracle, small_models, gn_eps, lut):
+    """The two [ggml-unverified] switches (GroupNorm epsilon, fp16 SiLU table) against the oracle's implementation of the
+    same switches, conditioned forward. The flash attention keeps the hardware exp in LUT mode (documented): within the
+    same 1e-3 gate."""
+    engine.load(diffusion=small_models + "/ggml-diffusion-model.bin")
+    engine.set_option("gn_eps", gn_eps)
+    engine.set_option("ggml_lut", lut)
+    oracle.set_flags(gn_eps=gn_eps, lut=lut)
+    try:
+        od = oracle.Diffusion(oracle.Model(small_models + "/ggml-diffusion-model.bin"))
+        L = 30
+        lat = _latents(L, 5)
+        T = engine.frames(L)
+        x_t = np.random.RandomState(9).randn(100, T).astype(np.float32)
+        got = engine.diffusion_forward(lat, x_t, 1500, False)
+        want = od.forward(od.code_embedding(lat, T), x_t, 1500)
+        e = rel_err(got, want)
+        print("switches gn_eps=%g lut=%d: rel err %.2e" % (gn_eps, lut, e))
+        assert e < 1e-3, e
+    finally:
+        oracle.set_flags()
+        engine.set_option("gn_eps", 1e-6)  # the engine fixture is shared by the whole session
+        engine.set_option("ggml_lut", 0)
+
+
 def test_sampling_loop_matches_oracle(engine, oracle, small_models):
     """diffusion(): 6 respaced steps, 2 candidates of different length in one batch, explicit noise."""
     engine.load(diffusion=small_models + "/ggml-diffusion-model.bin")
