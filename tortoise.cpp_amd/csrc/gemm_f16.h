@@ -165,8 +165,10 @@ __device__ __forceinline__ void gemm_acc_from_resid(const GemmArgs &g, floatx4 (
 
 // MI = 16-row MFMA tiles per wave along M: the workgroup tile is (32 MI) x 128. MI = 4 (128 rows) is the default;
 // MI = 5 (160 rows) is chosen by launch_gemm_f16 when it turns a 2.3-round grid into fewer, fuller rounds.
-template <int MODE, int MI>
-static __global__ __launch_bounds__(256, 3) void gemm_f16_glds_kernel(GemmArgs g) {
+// WGS: workgroups per CU the register allocation is bounded for. The F32/F16 modes fit 128 VGPRs (4 per CU) unforced;
+// the QKV mode needs 138 and gets 4 per CU with WGS = 4 at the price of 9 VGPRs spilled around (not inside) the K loop.
+template <int MODE, int MI, int WGS = 3>
+static __global__ __launch_bounds__(256, WGS) void gemm_f16_glds_kernel(GemmArgs g) {
   constexpr int BM = 32 * MI;
   __shared__ __attribute__((aligned(16))) char smem[BM * 128 + 16384];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: LDS-DMA bases stay in SGPRs
@@ -377,6 +379,7 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
   static const bool no_conv3 = getenv("TTS_GEMM_NOCONV3") != nullptr; // A/B switch for tools/gemm_bench
   const bool conv3 = !no_conv3 && g.nseg == 3 && !g.custom_w && g.A[0] == g.A[1] && g.A[1] == g.A[2] && g.row_off[0] == -1 &&
                      g.row_off[1] == 0 && g.row_off[2] == 1 && g.mode != GEMM_OUT_QKV;
+  static const bool qkv3 = getenv("TTS_GEMM_QKV3") != nullptr; // A/B switch: QKV projection at 3 workgroups per CU (138 VGPRs, no spills)
 #define TTS_LAUNCH_MI(MI_)                                                                                              \
   do {                                                                                                                  \
     if (conv3) {                                                                                                        \
@@ -390,7 +393,8 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
       else gemm_f16_conv3_kernel<GEMM_OUT_F16, MI_><<<grid1, 256, conv3_lds<MI_>(), s>>>(gg);                            \
     } else if (g.mode == GEMM_OUT_F32) gemm_f16_glds_kernel<GEMM_OUT_F32, MI_><<<grid1, 256, 0, s>>>(gg);                \
     else if (g.mode == GEMM_OUT_F16) gemm_f16_glds_kernel<GEMM_OUT_F16, MI_><<<grid1, 256, 0, s>>>(gg);                  \
-    else gemm_f16_glds_kernel<GEMM_OUT_QKV, MI_><<<grid1, 256, 0, s>>>(gg);                                              \
+    else if (qkv3) gemm_f16_glds_kernel<GEMM_OUT_QKV, MI_><<<grid1, 256, 0, s>>>(gg);                                    \
+    else gemm_f16_glds_kernel<GEMM_OUT_QKV, MI_, 4><<<grid1, 256, 0, s>>>(gg);                                           \
   } while (0)
   if (mi == 5) TTS_LAUNCH_MI(5);
   else TTS_LAUNCH_MI(4);
