@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--decode-steps", type=int, default=192, help="sampled codes per candidate (stop token masked) -> L=200, T=870")
     ap.add_argument("--quick", action="store_true", help="tiny layer counts (plumbing check only; NOT the benchmark)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-share-uncond", action="store_true", help="evaluate the unconditioned integrator layers once per candidate")
     ap.add_argument("--models", default=None)
     a = ap.parse_args()
 
@@ -126,6 +127,8 @@ def main():
     if world > 1:  # N processes share the host: leave each rank's sampler pool its share of the cores
         eng.set_option("sampler_threads", max(0, min(7, (os.cpu_count() or 8) // world - 2)))
     eng.load(model_dir)
+    if a.no_share_uncond:
+        eng.set_option("share_uncond", 0)
     B, S = a.candidates, a.decode_steps
     toks = synthetic_prompt()
     voice = np.fromfile(os.path.join(ROOT, "models", "mol.bin"), np.float32)
@@ -215,7 +218,10 @@ def main():
                                "UnivNet vocoder; full-size synthetic weights%s" % (B, S, int(rows[0]), int(Ts[0]),
                                                                                   ((Ts[0] + 10) * 256 - 6) / 24000.0, a.diff_steps,
                                                                                   " [QUICK: reduced layer counts]" if a.quick else ""),
-                   "candidates_per_gpu": B, "diffusion_steps": a.diff_steps, "decode_steps": S, "parallelism": "candidate-parallel x%d" % world},
+                   "candidates_per_gpu": B, "diffusion_steps": a.diff_steps, "decode_steps": S, "parallelism": "candidate-parallel x%d" % world,
+                   # the unconditioned branch's integrator layers (input independent of the candidate) are evaluated once per distinct
+                   # sequence length; with the stop token masked all candidates have one length (option share_uncond)
+                   "uncond_integrator_shared": not a.no_share_uncond},
         "stage_ms_per_step": {k: round(v / a.steps, 1) for k, v in stage_ms.items()},
         "roofline": {"kernel": "gemm_f16_glds_kernel + gemm_f16_conv3_kernel (diffusion convs/projections)", "bound": "mfma", "achieved": round(achieved, 1),
                      "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
