@@ -50,6 +50,8 @@ const char *tts_last_error(const tts_ctx *ctx);
 /* Options (all have reference defaults): "gn_eps" (1e-6; ggml's GroupNorm epsilon),
  * "ggml_lut" (0/1: emulate ggml-CPU fp16 lookup tables for GELU/SiLU),
  * "prof_only:<family>" (1: restrict profiling to one kernel family, 0: all),
+ * "prof_stride" (1 default: every launch of a profiled family is bracketed by an event pair; N: every Nth launch —
+ * an event pair drains the pipeline around the launch, so bracketing all 9 600 GEMM launches of a pass costs ~5 %),
  * "sampler_threads" (-1 default = min(7, hardware threads - 1); 0 = sample on the calling thread; the token ids
  * do not depend on it: the RNG is consumed in candidate order before the per-candidate scans run),
  * "share_uncond" (1 default: in tts_diffusion the conditioning_timestep_integrator layers of the unconditioned branch,

@@ -86,6 +86,7 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
     c->sampler_threads = value < 0 ? -1 : (int)value;
   }
   else if (k == "share_uncond") c->share_uncond = value != 0;
+  else if (k == "prof_stride") c->prof_stride = value < 1 ? 1 : (int)value;
   else return fail(c, TTS_ERR_ARG, "unknown option '%s'", key);
   return TTS_OK;
 }

@@ -852,8 +852,24 @@ struct ArState {
   DevBuf d_toks;
   int32_t *h_toks = nullptr;   // pinned
   float *h_logits = nullptr;   // pinned [B][8194]
+  int h_cap_B = 0;             // candidates the pinned buffers were sized for
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
+  // everything the captured step bakes into its nodes: the graph of the previous utterance is replayed when nothing moved
+  struct GraphSig {
+    int B = 0, max_pos = 0, lut = 0;
+    const void *p[10] = {};
+    bool operator==(const GraphSig &o) const {
+      return B == o.B && max_pos == o.max_pos && lut == o.lut && std::equal(p, p + 10, o.p);
+    }
+  } graph_sig;
+  GraphSig current_sig(int lut) const {
+    GraphSig g;
+    g.B = B; g.max_pos = max_pos; g.lut = lut;
+    const void *q[10] = {h.p, qkv.p, att.p, ff.p, kcache.p, vcache.p, d_toks.p, logits.p, h_toks, h_logits};
+    std::copy(q, q + 10, g.p);
+    return g;
+  }
   void drop_graph() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
@@ -1206,13 +1222,17 @@ int ar_begin(tts_ctx *ctx, const int32_t *text_ids, int n_text, const float *voi
   size_t cache = (size_t)st->n_layers * B * st->max_pos * D * sizeof(__half);
   TTS_HIP(ctx, st->kcache.reserve(cache));
   TTS_HIP(ctx, st->vcache.reserve(cache));
-  st->drop_graph(); // buffers may have moved
   TTS_HIP(ctx, st->d_toks.reserve((size_t)(B + 2) * 4)); // [tokens | n_past, pos_id]
   TTS_HIP(ctx, st->logits.reserve((size_t)B * V * 4));
-  if (st->h_toks) (void)hipHostFree(st->h_toks);
-  if (st->h_logits) (void)hipHostFree(st->h_logits);
-  TTS_HIP(ctx, hipHostMalloc((void **)&st->h_toks, (size_t)(B + 2) * 4));
-  TTS_HIP(ctx, hipHostMalloc((void **)&st->h_logits, (size_t)B * V * 4));
+  if (B > st->h_cap_B) { // pinned allocations are slow (milliseconds): keep them across utterances
+    if (st->h_toks) (void)hipHostFree(st->h_toks);
+    if (st->h_logits) (void)hipHostFree(st->h_logits);
+    st->h_toks = nullptr; st->h_logits = nullptr; st->h_cap_B = 0;
+    TTS_HIP(ctx, hipHostMalloc((void **)&st->h_toks, (size_t)(B + 2) * 4));
+    TTS_HIP(ctx, hipHostMalloc((void **)&st->h_logits, (size_t)B * V * 4));
+    st->h_cap_B = B;
+  }
+  // the decode-step graph is kept: ar_step re-captures it only if a buffer moved or the batch shape changed (GraphSig)
   return reserve_rows(ctx, st, std::max(B, st->P));
 }
 
@@ -1318,7 +1338,10 @@ int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out
   if (prof_ar || no_graph) {
     CHECK(enqueue_decode_step(ctx, st));
   } else {
+    const ArState::GraphSig sig = st->current_sig(ctx->ggml_lut);
+    if (st->graph_exec && !(sig == st->graph_sig)) st->drop_graph();
     if (!st->graph_exec) {
+      st->graph_sig = sig;
       TTS_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
       int rc = enqueue_decode_step(ctx, st);
       hipError_t e = hipStreamEndCapture(ctx->stream, &st->graph);

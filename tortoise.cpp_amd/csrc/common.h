@@ -47,7 +47,7 @@ struct DevBuf {
   template <class T> T *as() const { return (T *)p; }
 };
 
-struct ProfEntry { double ms = 0, work = 0; int64_t launches = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
+struct ProfEntry { double ms = 0, work = 0; int64_t launches = 0, seen = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
 
 struct ArState;
 struct DiffState;
@@ -82,6 +82,7 @@ struct tts_ctx {
   // resolved lazily (no host sync inside the timed region)
   bool prof_on = false;
   std::string prof_filter; // empty = every family
+  int prof_stride = 1;     // option "prof_stride": every Nth launch of a family is bracketed (an event pair drains the pipeline)
   std::map<std::string, tts::ProfEntry> prof;
   std::vector<hipEvent_t> ev_pool;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -106,9 +107,12 @@ struct ProfScope {
   // work: algorithmic FLOPs (MFMA-bound families) or bytes (HBM-bound families) of this launch
   ProfScope(tts_ctx *ctx, const char *family, double work = 0) : c(ctx), fam(family) {
     if (c->prof_on && (c->prof_filter.empty() || c->prof_filter == fam)) {
-      a = prof_event(c);
-      (void)hipEventRecord(a, c->stream);
-      c->prof[fam].work += work;
+      ProfEntry &e = c->prof[fam];
+      if (e.seen++ % c->prof_stride == 0) { // work and time are accumulated over the bracketed launches only
+        a = prof_event(c);
+        (void)hipEventRecord(a, c->stream);
+        e.work += work;
+      }
     }
   }
   ~ProfScope() {

@@ -18,6 +18,7 @@
 #include "common.h"
 #include "gemm_f16.h"
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 namespace tts {
@@ -1200,7 +1201,15 @@ int diff_sample(tts_ctx *ctx, const float *latents, const int32_t *rows, int B, 
   if (!latents || !rows || !mel_out || B < 1 || n_steps < 2) return fail(ctx, TTS_ERR_ARG, "tts_diffusion: bad argument");
   std::vector<int> L(rows, rows + B);
   for (int l : L) if (l < 1 || l > 500) return fail(ctx, TTS_ERR_ARG, "latent rows %d out of range", l);
+  static const bool timing = getenv("TTS_TIMING") != nullptr; // host-side breakdown on stderr
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+  };
+  const auto t_begin = now();
   CHECK(setup_batch(ctx, st, latents, L, true, true));
+  if (timing) (void)hipStreamSynchronize(ctx->stream);
+  const auto t_setup = now();
   Layout &lay = st->lay;
   DiffSchedule sched;
   sched.build(n_steps);
@@ -1242,6 +1251,8 @@ int diff_sample(tts_ctx *ctx, const float *latents, const int32_t *rows, int B, 
       philox_fill_kernel<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(st->xbuf.as<float>() + xoff[c], n, ctx->seed_value, (uint32_t)c, 0xFFFFFFFFu);
     }
   }
+  if (timing) (void)hipStreamSynchronize(ctx->stream);
+  const auto t_pre = now();
   const size_t ss_stride = (size_t)st->n_res() * 2 * C;
   for (int idx = 0; idx < n_steps; idx++) {
     const int t = n_steps - 1 - idx;
@@ -1258,8 +1269,14 @@ int diff_sample(tts_ctx *ctx, const float *latents, const int32_t *rows, int B, 
         ctx->seed_value, (uint32_t)idx);
     TTS_HIP(ctx, hipGetLastError());
   }
+  const auto t_issued = now();
+  if (timing) (void)hipStreamSynchronize(ctx->stream);
+  const auto t_loop = now();
   TTS_HIP(ctx, hipMemcpyAsync(mel_out, st->xbuf.p, total * 4, hipMemcpyDeviceToHost, ctx->stream));
   TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (timing)
+    fprintf(stderr, "[tts timing] diffusion: setup %.1f ms, time MLP + noise %.1f, %d steps %.1f (issued in %.1f), mel copy %.1f\n",
+            ms(t_begin, t_setup), ms(t_setup, t_pre), n_steps, ms(t_pre, t_loop), ms(t_pre, t_issued), ms(t_loop, now()));
   return TTS_OK;
 }
 
