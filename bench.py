@@ -55,7 +55,7 @@ def cpu_baseline(model_dir, voice, toks, S, L_bench, n_diff_steps, quick):
     ar = O.AR(O.Model(os.path.join(model_dir, "ggml-model.bin")))
     ar.start(toks, voice, 1, n + 2 + 16)
     t0 = time.time(); ar.prefill(); t_prefill = time.time() - t0
-    nstep = 4
+    nstep = 16 if not quick else 4
     t0 = time.time()
     for i in range(nstep):
         ar.step(np.array([100 + i], np.int32), i)
@@ -63,9 +63,10 @@ def cpu_baseline(model_dir, voice, toks, S, L_bench, n_diff_steps, quick):
     row_s = t_prefill / (n + 2)                                   # seconds per transformer row (dense part)
     t_ar = t_prefill + S * t_step + (n + 1 + L_bench) * row_s     # + latent pass over the needed prefix
     del ar
-    # --- diffusion: conditioner + one cond and one uncond forward at the fixture size L=43 (T=187)
+    # --- diffusion: conditioner + one cond and one uncond forward at the bench's own size (L=200, T=870): only the
+    # number of repetitions (80 steps) is extrapolated
     od = O.Diffusion(O.Model(os.path.join(model_dir, "ggml-diffusion-model.bin")))
-    Ls = 43 if not quick else 12
+    Ls = L_bench if not quick else 12
     Ts = od.T_of(Ls)
     lat = np.random.RandomState(0).randn(Ls, 1024).astype(np.float32)
     x = np.random.RandomState(1).randn(100, Ts).astype(np.float32)
@@ -75,7 +76,7 @@ def cpu_baseline(model_dir, voice, toks, S, L_bench, n_diff_steps, quick):
     Tb = od.T_of(L_bench)
     t_diff = n_diff_steps * t_pair * fl(Tb) / fl(Ts)
     del od
-    # --- vocoder at T=187, scaled by frames
+    # --- vocoder at the same T
     ov = O.Vocoder(O.Model(os.path.join(model_dir, "ggml-vocoder-model.bin")))
     mel = np.clip(np.random.RandomState(2).randn(100, Ts) * 0.5, -1, 1).astype(np.float32)
     t0 = time.time(); ov.run(mel, rng=O.Rng(0)); t_voc_s = time.time() - t0
@@ -86,7 +87,7 @@ def cpu_baseline(model_dir, voice, toks, S, L_bench, n_diff_steps, quick):
         "sample": "oracle (f32 C++/OpenMP restatement of the ggml graphs; the reference itself cannot be built: ggml "
                   "submodule absent). Measured B=1: prefill(P=%d) %.2fs, %d decode steps %.3fs/step, diffusion conditioner+cond+uncond "
                   "forward at L=%d/T=%d %.2fs, vocoder T=%d %.2fs (%.0fs total); extrapolated per candidate to S=%d steps, L=%d/T=%d, "
-                  "%d diffusion steps with the SURVEY 8d work formulae: AR %.1fs + diffusion %.1fs + vocoder %.1fs for %.2fs of audio"
+                  "%d diffusion steps (repetition counts; SURVEY 8d work formulae where a sample is smaller than the workload): AR %.1fs + diffusion %.1fs + vocoder %.1fs for %.2fs of audio"
                   % (n + 2, t_prefill, nstep, t_step, Ls, Ts, t_pair, Ts, t_voc_s, time.time() - t_all, S, L_bench, Tb, n_diff_steps,
                      t_ar, t_diff, t_voc, audio_s),
     }
