@@ -147,3 +147,28 @@ def test_cli_end_to_end(small_models, tmp_path):
     fmt_tag, channels, rate = struct.unpack("<HHI", b[20:28])
     assert (fmt_tag, channels, rate) == (3, 1, 24000)  # IEEE float, mono, 24 kHz (main.cpp:4821-4868)
     assert len(b) > 44 + 4 * 24000 // 10 and outs[0] == outs[1]
+
+
+def test_bench_contract_quick():
+    """bench.py prints ONE JSON line with the contract's keys (tiny layer counts: plumbing only, not a measurement)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--quick", "--steps", "1", "--warmup", "1", "--candidates", "4",
+                        "--decode-steps", "24", "--diff-steps", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["value"] > 0 and d["n_gpus"] == 1 and d["steps"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] > 0 and rf["achieved"] > 0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == d["unit"] and cb["sample"]
