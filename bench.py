@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--diff-steps", type=int, default=80)
     ap.add_argument("--decode-steps", type=int, default=192, help="sampled codes per candidate (stop token masked) -> L=200, T=870")
     ap.add_argument("--quick", action="store_true", help="tiny layer counts (plumbing check only; NOT the benchmark)")
+    ap.add_argument("--prof-stride", type=int, default=13, help="every Nth GEMM launch is bracketed by a HIP event pair (roofline timing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-share-uncond", action="store_true", help="evaluate the unconditioned integrator layers once per candidate")
     ap.add_argument("--models", default=None)
@@ -176,10 +177,10 @@ def main():
     for w in range(a.warmup):
         one_pass(-1 - w)
     eng.set_option("prof_only:diff_gemm", 1)
-    # every 7th GEMM launch is bracketed by a HIP event pair (60 launches per diffusion step, 7 is coprime: every launch
-    # position is sampled equally often over the 80 steps). Bracketing all ~9 600 launches of the timed region drains the
-    # pipeline that often and cost 5 % of the pass.
-    eng.set_option("prof_stride", 7)
+    # every 13th GEMM launch is bracketed by a HIP event pair (60 launches per diffusion step, 13 is coprime: every launch
+    # position is sampled equally often over the 80 steps). An event pair drains the pipeline around its launch: bracketing
+    # all ~9 600 launches of the timed region cost 5 % of the pass, every 7th 0.5 %, every 29th nothing measurable.
+    eng.set_option("prof_stride", a.prof_stride)
     eng.prof_reset(True)
     sync()
     t0 = time.time()
@@ -230,7 +231,7 @@ def main():
         "stage_ms_per_step": {k: round(v / a.steps, 1) for k, v in stage_ms.items()},
         "roofline": {"kernel": "gemm_f16_glds_kernel + gemm_f16_conv3_kernel (diffusion convs/projections)", "bound": "mfma", "achieved": round(achieved, 1),
                      "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
-                     "traffic": traffic, "launches_timed": int(g_n), "launch_sampling": "every 7th launch of the family is bracketed by HIP events", "avg_launch_us": round(1000.0 * g_ms / max(g_n, 1), 2),
+                     "traffic": traffic, "launches_timed": int(g_n), "launch_sampling": "every %dth launch of the family is bracketed by HIP events" % a.prof_stride, "avg_launch_us": round(1000.0 * g_ms / max(g_n, 1), 2),
                      "algorithmic_gflop_per_launch": round(g_flops / max(g_n, 1) / 1e9, 2)},
     }
     if world == 1 and not a.no_cpu_baseline:
