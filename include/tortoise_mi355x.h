@@ -147,6 +147,22 @@ int tts_vocoder(tts_ctx *ctx, const float *mel, const int32_t *frames, int n_can
 /* writeWav (main.cpp:4821-4868): RIFF, fmt 16 B, tag 3 (IEEE float), mono, 32-bit. */
 int tts_write_wav(const char *path, const float *samples, int64_t n, int sample_rate);
 
+/* ---- host-logic probes ---------------------------------------------------------------------- */
+/* The host-side arithmetic of the diffusion and AR drivers, callable without a device so that it can be checked
+ * against the reference's own code on any machine. Not needed by an integration.
+ * tts_host_schedule: respaced schedule + per-step scalars exactly as tts_diffusion uses them (main.cpp:5370-5493,
+ *   5641-5716, 5988-6015); every output is [n_steps]. max_log = log(beta_t), min_log = posterior log variance (clipped),
+ *   cfk = conditioning-free k, coef1/coef2 = posterior mean coefficients.
+ * tts_host_timestep_embedding: main.cpp:5496-5521. tts_host_rel_bucket: main.cpp:4722-4749.
+ * tts_host_pad_codes: apply_padding, main.cpp:4510-4532 (n <= 500 sampled codes -> 502). tts_host_trimmed_rows: trim_latents
+ *   row count, main.cpp:4873-4915. */
+int tts_host_schedule(int n_steps, int32_t *timestep_map, float *max_log, float *min_log, float *cfk, float *sqrt_recip,
+                      float *sqrt_recipm1, float *coef1, float *coef2);
+void tts_host_timestep_embedding(int t, float *out1024);
+int tts_host_rel_bucket(int query, int key);
+int tts_host_pad_codes(const int32_t *codes, int n, int32_t *out502);
+int tts_host_trimmed_rows(const int32_t *codes502);
+
 /* ---- measurement hooks (bench.py; not part of the reference seam) -------------------------- */
 /* Accumulated device time (ms; HIP event pairs recorded on the ctx stream around every launch, resolved
  * lazily so the timed region is not synchronised) and launch count of the named kernel family since the

@@ -119,3 +119,72 @@ def test_sampler_fuzz_vs_reference(host, oracle):
         got = host.sample(logits, ids)
         assert (got == want).all(), (trial, got, want)
         assert host.rng_uniform() == R.ref_uniform()
+
+
+def test_schedule_scalars_golden_and_oracle(pkg, oracle):
+    """The diffusion driver's schedule arithmetic (host_logic.cpp: DiffSchedule) against the committed golden vectors of
+    the reference's own code (80 steps) and against the oracle for other step counts (SURVEY 8d config 5 uses 200)."""
+    g = np.load(os.path.join(GOLDEN, "schedule_golden.npz"))
+    tm, s = pkg.host_schedule(80)
+    assert (tm == g["timestep_map"]).all()
+    f32 = lambda a: np.asarray(a, np.float64).astype(np.float32)
+    assert (s["min_log"] == f32(g["post_logvar"])).all()
+    assert (s["coef1"] == f32(g["coef1"])).all() and (s["coef2"] == f32(g["coef2"])).all()
+    assert (s["sqrt_recip"] == f32(g["sqrt_recip"])).all() and (s["sqrt_recipm1"] == f32(g["sqrt_recipm1"])).all()
+    assert np.abs(s["max_log"] - f32(np.log(g["betas"]))).max() <= 1e-6  # log in double on both sides, one float ulp at most
+    t = np.arange(80, dtype=np.float32)
+    assert (s["cfk"] == np.float32(2.0) * (np.float32(1) - t / np.float32(80))).all()
+    for n in (2, 6, 200):
+        tm, s = pkg.host_schedule(n)
+        tmo = oracle.default_timestep_map(n)
+        assert (tm == tmo).all() and tm[0] == 0 and tm[-1] == 3999
+        o = oracle.schedule(tmo)
+        assert (s["min_log"] == f32(o["post_logvar"])).all(), n
+        assert (s["coef1"] == f32(o["coef1"])).all() and (s["coef2"] == f32(o["coef2"])).all(), n
+        assert (s["sqrt_recip"] == f32(o["sqrt_recip"])).all() and (s["sqrt_recipm1"] == f32(o["sqrt_recipm1"])).all(), n
+        assert np.abs(s["max_log"] - f32(np.log(o["betas"]))).max() <= 1e-6, n
+
+
+def test_timestep_embedding_and_buckets_golden(pkg, oracle):
+    g = np.load(os.path.join(GOLDEN, "schedule_golden.npz"))
+    for t in (0, 51, 2025, 3999):
+        assert (pkg.host_timestep_embedding(t) == g["temb_%d" % t]).all(), t
+    hg = json.load(open(os.path.join(GOLDEN, "host_golden.json")))
+    for n, tab in hg["buckets"].items():
+        assert (pkg.host_rel_buckets(int(n)) == np.array(tab)).all(), n
+    assert (pkg.host_rel_buckets(130) == oracle.buckets(130)).all()  # distances past the saturation point (>= 50)
+
+
+def test_padding_and_trim_vs_oracle(pkg, oracle):
+    """apply_padding / trim_latents of the product against the oracle's restatement (itself pinned to the reference's
+    code by tests/test_oracle_golden.py), on sequences with stop-typo tokens (8139), real stops and long runs of 83."""
+    rs = np.random.RandomState(3)
+    cases = [np.array([], np.int32), np.array([8139], np.int32), np.array([5, 6, 83, 83, 7], np.int32),
+             np.full(500, 83, np.int32), np.full(500, 7, np.int32)]
+    for _ in range(40):
+        n = int(rs.randint(0, 501))
+        c = rs.choice([83, 83, 83, 45, 248, 8139, 8193, 17, 4000], n).astype(np.int32)
+        if n and rs.rand() < 0.5:
+            c[-int(rs.randint(1, min(n, 12) + 1)):] = 8139
+        cases.append(c)
+    for c in cases:
+        got, want = pkg.host_pad_codes(c), oracle.apply_padding(c)
+        assert (got == want).all(), c[:20]
+        assert pkg.host_trimmed_rows(got) == oracle.trimmed_rows(want)
+    with pytest.raises(pkg.TtsError):
+        pkg.host_pad_codes(np.zeros(501, np.int32))
+
+
+def test_wav_writer_header(pkg, tmp_path):
+    """RIFF/WAVE, fmt chunk 16 bytes, format tag 3 (IEEE float), mono, 24 kHz, 32 bit, raw f32 data (main.cpp:4821-4868)."""
+    import struct
+    x = np.linspace(-1, 1, 1000).astype(np.float32)
+    p = str(tmp_path / "a.wav")
+    assert pkg.write_wav(p, x) == 0
+    b = open(p, "rb").read()
+    assert len(b) == 44 + 4000
+    assert b[:4] == b"RIFF" and struct.unpack("<i", b[4:8])[0] == 36 + 4000 and b[8:16] == b"WAVEfmt "
+    fmt_size, tag, ch, rate, brate, align, bits = struct.unpack("<ihhiihh", b[16:36])
+    assert (fmt_size, tag, ch, rate, brate, align, bits) == (16, 3, 1, 24000, 96000, 4, 32)
+    assert b[36:40] == b"data" and struct.unpack("<i", b[40:44])[0] == 4000
+    assert (np.frombuffer(b[44:], np.float32) == x).all()

@@ -61,6 +61,8 @@ def lib():
         "tts_vocoder_samples": (ci, [ci]),
         "tts_vocoder": (ci, [vp, _f32p, _i32p, ci, vp, ci, _f32p]),
         "tts_write_wav": (ci, [C.c_char_p, _f32p, C.c_int64, ci]),
+        "tts_host_schedule": (ci, [ci, _i32p] + [_f32p] * 7), "tts_host_timestep_embedding": (None, [ci, _f32p]),
+        "tts_host_rel_bucket": (ci, [ci, ci]), "tts_host_pad_codes": (ci, [_i32p, ci, _i32p]), "tts_host_trimmed_rows": (ci, [_i32p]),
         "tts_prof_reset": (ci, [vp, ci]), "tts_prof_get": (ci, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
@@ -248,6 +250,43 @@ class Engine:
         ms, n, w = C.c_double(0), C.c_int64(0), C.c_double(0)
         self.L.tts_prof_get(self.h, family.encode(), C.byref(ms), C.byref(n), C.byref(w))
         return ms.value, n.value, w.value
+
+
+HOST_SCHED_KEYS = ["max_log", "min_log", "cfk", "sqrt_recip", "sqrt_recipm1", "coef1", "coef2"]
+
+
+def host_schedule(n_steps):
+    """The diffusion driver's respaced schedule and per-step scalars (host arithmetic, no device needed)."""
+    tm = np.empty(n_steps, np.int32)
+    arrs = [np.empty(n_steps, np.float32) for _ in HOST_SCHED_KEYS]
+    rc = lib().tts_host_schedule(n_steps, tm, *arrs)
+    if rc:
+        raise TtsError("tts_host_schedule failed (%d)" % rc)
+    return tm, dict(zip(HOST_SCHED_KEYS, arrs))
+
+
+def host_timestep_embedding(t):
+    out = np.empty(1024, np.float32)
+    lib().tts_host_timestep_embedding(int(t), out)
+    return out
+
+
+def host_rel_buckets(n):
+    L = lib()
+    return np.array([[L.tts_host_rel_bucket(i, c) for c in range(n)] for i in range(n)], np.int32)
+
+
+def host_pad_codes(codes):
+    codes = np.ascontiguousarray(codes, np.int32)
+    out = np.empty(502, np.int32)
+    rc = lib().tts_host_pad_codes(codes, len(codes), out)
+    if rc:
+        raise TtsError("tts_host_pad_codes failed (%d)" % rc)
+    return out
+
+
+def host_trimmed_rows(codes502):
+    return lib().tts_host_trimmed_rows(np.ascontiguousarray(codes502, np.int32))
 
 
 def write_wav(path, samples, rate=24000):

@@ -444,6 +444,32 @@ void DiffSchedule::build(int n_steps) {
 
 } // namespace tts
 
+// ---- host-logic probes: the host-side pieces of the stage drivers, callable without a GPU (tests/test_host_parity.py) ----
+extern "C" int tts_host_schedule(int n_steps, int32_t *timestep_map, float *max_log, float *min_log, float *cfk, float *sqrt_recip,
+                                 float *sqrt_recipm1, float *coef1, float *coef2) {
+  if (n_steps < 2) return TTS_ERR_ARG;
+  tts::DiffSchedule s;
+  s.build(n_steps);
+  for (int t = 0; t < n_steps; t++) {
+    timestep_map[t] = s.timestep_map[t];
+    max_log[t] = s.max_log[t]; min_log[t] = s.min_log[t]; cfk[t] = s.cfk[t];
+    sqrt_recip[t] = s.sqrt_recip[t]; sqrt_recipm1[t] = s.sqrt_recipm1[t];
+    coef1[t] = s.coef1[t]; coef2[t] = s.coef2[t];
+  }
+  return TTS_OK;
+}
+extern "C" void tts_host_timestep_embedding(int t, float *out1024) { tts::timestep_embedding(t, out1024); }
+extern "C" int tts_host_rel_bucket(int query, int key) { return tts::rel_bucket(query, key); }
+extern "C" int tts_host_pad_codes(const int32_t *codes, int n, int32_t *out502) {
+  if (n < 0 || n > 500) return TTS_ERR_ARG;
+  std::vector<int> v(codes, codes + n);
+  tts::pad_codes(v);
+  if (v.size() != 502) return TTS_ERR_LIMIT;
+  std::copy(v.begin(), v.end(), out502);
+  return TTS_OK;
+}
+extern "C" int tts_host_trimmed_rows(const int32_t *codes502) { return tts::trimmed_latent_rows(codes502); }
+
 // writeWav, main.cpp:4821-4868
 extern "C" int tts_write_wav(const char *path, const float *samples, int64_t n, int sample_rate) {
   FILE *f = fopen(path, "wb");
