@@ -35,6 +35,9 @@ int fail(tts_ctx *ctx, int code, const char *fmt, ...) {
 int read_weight_file(const char *path, WeightFile &out, std::string &err) {
   FILE *f = fopen(path, "rb");
   if (!f) { err = std::string("failed to open '") + path + "'"; return TTS_ERR_IO; }
+  fseek(f, 0, SEEK_END);
+  const long long file_size = ftell(f);
+  fseek(f, 0, SEEK_SET);
   uint32_t magic = 0;
   if (fread(&magic, 4, 1, f) != 1 || magic != 0x67676d6cu) {
     fclose(f);
@@ -60,6 +63,13 @@ int read_weight_file(const char *path, WeightFile &out, std::string &err) {
     }
     std::string name(name_len, '\0');
     if (fread(&name[0], 1, name_len, f) != (size_t)name_len) { fclose(f); err = "truncated name"; return TTS_ERR_IO; }
+    // a corrupt shape must not turn into a giant allocation (no exception may cross the C ABI)
+    unsigned long long want = 4;
+    for (int i = 0; i < n_dims; i++) {
+      want *= (unsigned long long)t.ne[i];
+      if (want > (unsigned long long)file_size) break;
+    }
+    if (want > (unsigned long long)(file_size - ftell(f))) { fclose(f); err = "tensor '" + name + "' truncated"; return TTS_ERR_IO; }
     t.data.resize((size_t)t.nelem());
     if (fread(t.data.data(), sizeof(float), t.data.size(), f) != t.data.size()) {
       fclose(f);
