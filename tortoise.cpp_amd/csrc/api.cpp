@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <chrono>
 #include <fstream>
+#include <new>
 
 namespace tts {
 int ar_begin(tts_ctx *, const int32_t *, int, const float *, int, int);
@@ -24,6 +25,20 @@ hipEvent_t tts::prof_event(tts_ctx *c) {
   hipEvent_t e = nullptr;
   (void)hipEventCreate(&e);
   return e;
+}
+
+// No exception crosses the C ABI: allocation failures and anything unexpected become a status + tts_last_error text.
+template <class F>
+static int guarded(tts_ctx *c, F body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    return fail(c, TTS_ERR_LIMIT, "out of host memory");
+  } catch (const std::exception &e) {
+    return fail(c, TTS_ERR_STATE, "internal error: %s", e.what());
+  } catch (...) {
+    return fail(c, TTS_ERR_STATE, "internal error");
+  }
 }
 
 extern "C" {
@@ -98,9 +113,9 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
     (void)hipSetDevice((c)->device);                                                           \
   } while (0)
 
-int tts_load_ar(tts_ctx *c, const char *path) { NEED_CTX(c); return ar_load(c, path); }
-int tts_load_diffusion(tts_ctx *c, const char *path) { NEED_CTX(c); return diff_load(c, path); }
-int tts_load_vocoder(tts_ctx *c, const char *path) { NEED_CTX(c); return voc_load(c, path); }
+int tts_load_ar(tts_ctx *c, const char *path) { NEED_CTX(c); return guarded(c, [&] { return ar_load(c, path); }); }
+int tts_load_diffusion(tts_ctx *c, const char *path) { NEED_CTX(c); return guarded(c, [&] { return diff_load(c, path); }); }
+int tts_load_vocoder(tts_ctx *c, const char *path) { NEED_CTX(c); return guarded(c, [&] { return voc_load(c, path); }); }
 int tts_ar_layers(const tts_ctx *c) { return c ? ar_layers(c) : 0; }
 int tts_diffusion_layers(const tts_ctx *c) { return c ? diff_layers(c) : 0; }
 
@@ -142,26 +157,27 @@ int tts_tokenize(tts_ctx *c, const char *message, int32_t *out, int cap) {
 
 int tts_ar_begin(tts_ctx *c, const int32_t *ids, int n, const float *voice, int B, int max_steps) {
   NEED_CTX(c);
-  return ar_begin(c, ids, n, voice, B, max_steps);
+  return guarded(c, [&] { return ar_begin(c, ids, n, voice, B, max_steps); });
 }
-int tts_ar_prefill(tts_ctx *c, float *logits) { NEED_CTX(c); return ar_prefill(c, logits); }
-int tts_ar_step(tts_ctx *c, const int32_t *prev, int i, float *logits) { NEED_CTX(c); return ar_step(c, prev, i, logits); }
+int tts_ar_prefill(tts_ctx *c, float *logits) { NEED_CTX(c); return guarded(c, [&] { return ar_prefill(c, logits); }); }
+int tts_ar_step(tts_ctx *c, const int32_t *prev, int i, float *logits) {
+  NEED_CTX(c);
+  return guarded(c, [&] { return ar_step(c, prev, i, logits); });
+}
 int tts_ar_latents(tts_ctx *c, const int32_t *codes, int nb, int n_mel, float *out) {
   NEED_CTX(c);
-  return ar_latents(c, codes, nb, n_mel, out);
+  return guarded(c, [&] { return ar_latents(c, codes, nb, n_mel, out); });
 }
 int tts_sample(tts_ctx *c, const float *logits, const int32_t *ids, int ids_per_cand, int B, int32_t *out) {
   if (!c || !logits || !ids || !out || B < 1 || ids_per_cand < 1) return TTS_ERR_ARG;
   for (int i = 0; i < B * ids_per_cand; i++)
     if (ids[i] < 0 || ids[i] >= TTS_VOCAB_MEL) return fail(c, TTS_ERR_ARG, "penalty id out of range");
-  sample_candidates(c, logits, ids, ids_per_cand, B, out);
-  return TTS_OK;
+  return guarded(c, [&] { sample_candidates(c, logits, ids, ids_per_cand, B, out); return (int)TTS_OK; });
 }
 
 // autoregressive(), main.cpp:5042-5367.
-int tts_autoregressive(tts_ctx *c, const int32_t *text_ids, int n_text, const float *voice, int B, int max_steps,
-                       unsigned flags, int32_t *codes_out, int32_t *rows_out, float *latents_out, int32_t *steps_out) {
-  NEED_CTX(c);
+static int autoregressive_impl(tts_ctx *c, const int32_t *text_ids, int n_text, const float *voice, int B, int max_steps,
+                               unsigned flags, int32_t *codes_out, int32_t *rows_out, float *latents_out, int32_t *steps_out) {
   static const bool timing = getenv("TTS_TIMING") != nullptr; // developer aid: host-side breakdown of the stage on stderr
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_begin = now(), t_sample = 0, t_step = 0;
@@ -238,20 +254,28 @@ int tts_autoregressive(tts_ctx *c, const int32_t *text_ids, int n_text, const fl
   return TTS_OK;
 }
 
+int tts_autoregressive(tts_ctx *c, const int32_t *text_ids, int n_text, const float *voice, int B, int max_steps,
+                       unsigned flags, int32_t *codes_out, int32_t *rows_out, float *latents_out, int32_t *steps_out) {
+  NEED_CTX(c);
+  return guarded(c, [&] {
+    return autoregressive_impl(c, text_ids, n_text, voice, B, max_steps, flags, codes_out, rows_out, latents_out, steps_out);
+  });
+}
+
 int tts_diffusion_frames(int L) { return L * 4 * 24000 / 22050; }
 int tts_diffusion_forward(tts_ctx *c, const float *latents, int L, const float *x_t, int timestep, int cond_free, float *out) {
   NEED_CTX(c);
-  return diff_forward(c, latents, L, x_t, timestep, cond_free, out);
+  return guarded(c, [&] { return diff_forward(c, latents, L, x_t, timestep, cond_free, out); });
 }
 int tts_diffusion(tts_ctx *c, const float *latents, const int32_t *rows, int B, int n_steps, const float *noise,
                   int noise_mode, float *mel_out) {
   NEED_CTX(c);
-  return diff_sample(c, latents, rows, B, n_steps, noise, noise_mode, mel_out);
+  return guarded(c, [&] { return diff_sample(c, latents, rows, B, n_steps, noise, noise_mode, mel_out); });
 }
 int tts_vocoder_samples(int T) { return (T + 10) * 256 - 6; }
 int tts_vocoder(tts_ctx *c, const float *mel, const int32_t *frames, int B, const float *noise, int noise_mode, float *audio) {
   NEED_CTX(c);
-  return voc_run(c, mel, frames, B, noise, noise_mode, audio);
+  return guarded(c, [&] { return voc_run(c, mel, frames, B, noise, noise_mode, audio); });
 }
 
 static void prof_resolve(tts_ctx *c) {
