@@ -135,8 +135,9 @@ int tts_rng_load_state(tts_ctx *c, const char *path) {
   c->normal_distribution.reset();
   return fin ? TTS_OK : fail(c, TTS_ERR_FORMAT, "bad RNG state file '%s'", path);
 }
-float tts_rng_uniform(tts_ctx *c) { return c->distribution(c->generator); }
+float tts_rng_uniform(tts_ctx *c) { return c ? c->distribution(c->generator) : 0.f; }
 void tts_rng_normal(tts_ctx *c, float *out, int64_t n) { // sample_normal_noise, main.cpp:4695-4701
+  if (!c || !out) return;
   for (int64_t i = 0; i < n; i++) out[i] = c->normal_distribution(c->generator);
 }
 
