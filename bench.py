@@ -53,9 +53,9 @@ def cpu_baseline(model_dir, voice, toks, S, L_bench, n_diff_steps, quick):
     t_all = time.time()
     # --- AR: prefill + a few decode steps at B=1
     ar = O.AR(O.Model(os.path.join(model_dir, "ggml-model.bin")))
-    ar.start(toks, voice, 1, n + 2 + 16)
+    nstep = 48 if not quick else 4
+    ar.start(toks, voice, 1, n + 2 + nstep + 1)
     t0 = time.time(); ar.prefill(); t_prefill = time.time() - t0
-    nstep = 16 if not quick else 4
     t0 = time.time()
     for i in range(nstep):
         ar.step(np.array([100 + i], np.int32), i)
@@ -70,11 +70,15 @@ def cpu_baseline(model_dir, voice, toks, S, L_bench, n_diff_steps, quick):
     Ts = od.T_of(Ls)
     lat = np.random.RandomState(0).randn(Ls, 1024).astype(np.float32)
     x = np.random.RandomState(1).randn(100, Ts).astype(np.float32)
-    t0 = time.time(); ce = od.code_embedding(lat, Ts); od.forward(ce, x, 2025); od.forward(None, x, 2025)
-    t_pair = time.time() - t0
+    t0 = time.time(); ce = od.code_embedding(lat, Ts); t_cond = time.time() - t0
+    npair = 3 if not quick else 1                                 # cond + uncond forward at three timesteps
+    t0 = time.time()
+    for ts in (3999, 2025, 51)[:npair]:
+        od.forward(ce, x, ts); od.forward(None, x, ts)
+    t_pair = (time.time() - t0) / npair
     fl = lambda T: 249307136.0 * T + 53248.0 * T * T              # per forward
     Tb = od.T_of(L_bench)
-    t_diff = n_diff_steps * t_pair * fl(Tb) / fl(Ts)
+    t_diff = t_cond + n_diff_steps * t_pair * fl(Tb) / fl(Ts)     # conditioner once per utterance
     del od
     # --- vocoder at the same T
     ov = O.Vocoder(O.Model(os.path.join(model_dir, "ggml-vocoder-model.bin")))
@@ -85,10 +89,10 @@ def cpu_baseline(model_dir, voice, toks, S, L_bench, n_diff_steps, quick):
     return {
         "value": round(audio_s / (t_ar + t_diff + t_voc), 5), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
         "sample": "oracle (f32 C++/OpenMP restatement of the ggml graphs; the reference itself cannot be built: ggml "
-                  "submodule absent). Measured B=1: prefill(P=%d) %.2fs, %d decode steps %.3fs/step, diffusion conditioner+cond+uncond "
-                  "forward at L=%d/T=%d %.2fs, vocoder T=%d %.2fs (%.0fs total); extrapolated per candidate to S=%d steps, L=%d/T=%d, "
+                  "submodule absent). Measured B=1: prefill(P=%d) %.2fs, %d decode steps %.3fs/step, diffusion cond+uncond "
+                  "forward pair (mean of %d timesteps) at L=%d/T=%d %.2fs, vocoder T=%d %.2fs (%.0fs total); extrapolated per candidate to S=%d steps, L=%d/T=%d, "
                   "%d diffusion steps (repetition counts; SURVEY 8d work formulae where a sample is smaller than the workload): AR %.1fs + diffusion %.1fs + vocoder %.1fs for %.2fs of audio"
-                  % (n + 2, t_prefill, nstep, t_step, Ls, Ts, t_pair, Ts, t_voc_s, time.time() - t_all, S, L_bench, Tb, n_diff_steps,
+                  % (n + 2, t_prefill, nstep, t_step, npair, Ls, Ts, t_pair, Ts, t_voc_s, time.time() - t_all, S, L_bench, Tb, n_diff_steps,
                      t_ar, t_diff, t_voc, audio_s),
     }
 

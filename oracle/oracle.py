@@ -232,6 +232,8 @@ class AR:
 
     def start(self, tokens, voice, B, max_pos):
         self.B = B
+        self._P, self._max_pos = len(tokens) + 2, max_pos
+        assert max_pos >= self._P, "cache smaller than the prompt"
         lib().orc_ar_start(self.h, np.ascontiguousarray(tokens, np.int32), len(tokens),
                            np.ascontiguousarray(voice, np.float32), B, max_pos)
 
@@ -241,6 +243,7 @@ class AR:
         return out
 
     def step(self, toks, i):
+        assert self._P + i < self._max_pos, "step %d beyond the cache given to start()" % i  # the C side does not check
         out = np.empty((self.B, self.V), np.float32)
         lib().orc_ar_step(self.h, np.ascontiguousarray(toks, np.int32), i, out.reshape(-1))
         return out
