@@ -373,7 +373,11 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
   // rounds, so there is no 2.3 -> 3 round quantisation to win back. The instantiation is kept for the A/B switch.
   static const char *force_mi = getenv("TTS_GEMM_MI");
   const int NTt = g.N >> 7;
-  const int mi = (force_mi && atoi(force_mi) == 5) ? 5 : 4;
+  // Small problems (a single utterance: M = 1 792 rows -> 14 x 8 tiles of 128 rows on 256 CUs): 64-row tiles put twice as
+  // many workgroups on the chip. TTS_GEMM_MI=4 keeps the 128-row tile everywhere (A/B switch).
+  const int mt4 = (g.M + 127) / 128;
+  int mi = (mt4 * NTt < 256) ? 2 : 4;
+  if (force_mi) { const int f = atoi(force_mi); if (f == 5 || f == 4 || f == 2) mi = f; }
   const int bm = 32 * mi, MTt = (g.M + bm - 1) / bm, grid1 = 8 * ((MTt >> 3) + ((MTt & 7) ? 1 : 0)) * NTt;
   // k = 3 convolution (three row-shifted segments of one activation buffer, tap-major weights): shared-slab kernel
   static const bool no_conv3 = getenv("TTS_GEMM_NOCONV3") != nullptr; // A/B switch for tools/gemm_bench
@@ -397,6 +401,7 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
     else gemm_f16_glds_kernel<GEMM_OUT_QKV, MI_, 4><<<grid1, 256, 0, s>>>(gg);                                           \
   } while (0)
   if (mi == 5) TTS_LAUNCH_MI(5);
+  else if (mi == 2) TTS_LAUNCH_MI(2);
   else TTS_LAUNCH_MI(4);
 #undef TTS_LAUNCH_MI
   return hipGetLastError();
