@@ -374,9 +374,11 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
   static const char *force_mi = getenv("TTS_GEMM_MI");
   const int NTt = g.N >> 7;
   // Small problems (a single utterance: M = 1 792 rows -> 14 x 8 tiles of 128 rows on 256 CUs): 64-row tiles put twice as
-  // many workgroups on the chip. TTS_GEMM_MI=4 keeps the 128-row tile everywhere (A/B switch).
+  // many workgroups on the chip. Threshold measured at one candidate (diffusion stage): 256 tiles 183 ms, 512 tiles 174 ms,
+  // 1024 tiles 175 ms; 16 candidates are above all of them. TTS_GEMM_MI=4 keeps the 128-row tile everywhere (A/B switch).
   const int mt4 = (g.M + 127) / 128;
-  int mi = (mt4 * NTt < 256) ? 2 : 4;
+  static const int mi2_tiles = getenv("TTS_GEMM_MI2_TILES") ? atoi(getenv("TTS_GEMM_MI2_TILES")) : 512;
+  int mi = (mt4 * NTt < mi2_tiles) ? 2 : 4;
   if (force_mi) { const int f = atoi(force_mi); if (f == 5 || f == 4 || f == 2) mi = f; }
   const int bm = 32 * mi, MTt = (g.M + bm - 1) / bm, grid1 = 8 * ((MTt >> 3) + ((MTt & 7) ? 1 : 0)) * NTt;
   // k = 3 convolution (three row-shifted segments of one activation buffer, tap-major weights): shared-slab kernel
