@@ -56,7 +56,11 @@ const char *tts_last_error(const tts_ctx *ctx);
  * do not depend on it: the RNG is consumed in candidate order before the per-candidate scans run),
  * "share_uncond" (1 default: in tts_diffusion the conditioning_timestep_integrator layers of the unconditioned branch,
  * whose input does not depend on the candidate, are evaluated once per distinct sequence length instead of once per
- * candidate; 0 = once per candidate. Same arithmetic per row either way). */
+ * candidate; 0 = once per candidate. Same arithmetic per row either way),
+ * "rng_shard_offset" / "rng_shard_total" (0 / 0 default = unsharded): candidate-parallel multi-GPU runs. This context
+ * holds candidates [offset, offset + n_candidates) of a batch of `total`: the sampler skips the uniforms of the other
+ * ranks' candidates (the used uniform of (step s, candidate c) is output 2 (s total + c) + 1 of the mt19937 stream), and
+ * TTS_NOISE_DEVICE streams are keyed by the global candidate id — so G ranks x B/G candidates reproduce one rank x B. */
 int tts_set_option(tts_ctx *ctx, const char *key, double value);
 
 /* ---- weight files (drop-in format: magic 0x67676d6c + name-keyed F32 records) ------------- */
@@ -109,7 +113,11 @@ int tts_sample(tts_ctx *ctx, const float *logits, const int32_t *penalty_ids, in
  *   flags: TTS_AR_MASK_STOP -> stop token never sampled, exactly max_steps codes (bench workload).
  *   codes_out [B][502]; rows_out [B] trimmed latent rows; latents_out: the trimmed latents of all
  *   candidates back to back (capacity B*500*1024 floats); steps_out: sampling iterations run. */
-enum { TTS_AR_MASK_STOP = 1 };
+/*          TTS_AR_RETIRE (n_candidates > 1; throughput mode) -> a candidate retires at its first 8193 and
+ *          the loop ends when all have retired (the reference ends only when all B samples of ONE step are 8193,
+ *          main.cpp:5214-5222); reaching max_steps pads and returns TTS_OK. No sequence differs from strict mode:
+ *          sequences freeze at the first 8193 (5210-5213) and the uniforms are consumed identically. */
+enum { TTS_AR_MASK_STOP = 1, TTS_AR_RETIRE = 2 };
 int tts_autoregressive(tts_ctx *ctx, const int32_t *text_ids, int n_text, const float *voice1024,
                        int n_candidates, int max_steps, unsigned flags, int32_t *codes_out,
                        int32_t *rows_out, float *latents_out, int32_t *steps_out);

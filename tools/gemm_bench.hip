@@ -1,5 +1,5 @@
 // Developer tool: times gemm_f16_kernel variants on the diffusion shapes and checks them against a naive
-// kernel.  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tortoise.cpp_amd/csrc tools/gemm_bench.hip -o /tmp/gemm_bench
+// kernel.  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tortoise.cpp_amd/csrc -I tools tools/gemm_bench.hip -o /tmp/gemm_bench
 #include "gemm_f16.h"
 #include <cstdio>
 #include <cstdlib>

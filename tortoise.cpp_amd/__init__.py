@@ -17,6 +17,7 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "tortoise_mi355x.h")
 VOCAB_MEL = 8194
 DMODEL = 1024
 AR_MASK_STOP = 1
+AR_RETIRE = 2
 NOISE_REFERENCE, NOISE_DEVICE = 0, 1
 
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
@@ -178,7 +179,7 @@ class Engine:
         self._ck(self.L.tts_sample(self.h, logits.reshape(-1), ids.reshape(-1), ids.shape[1], logits.shape[0], out))
         return out
 
-    def autoregressive(self, tokens, voice, B, max_steps, mask_stop=False, want_latents=True):
+    def autoregressive(self, tokens, voice, B, max_steps, mask_stop=False, want_latents=True, retire=False):
         """Returns (codes [B,502], rows [B], list of trimmed latents [rows_c,1024], steps)."""
         codes = np.empty((B, 502), np.int32)
         rows = np.empty(B, np.int32)
@@ -186,7 +187,7 @@ class Engine:
         lat = np.empty((B * 500, DMODEL), np.float32) if want_latents else None
         self._ck(self.L.tts_autoregressive(self.h, np.ascontiguousarray(tokens, np.int32), len(tokens),
                                            np.ascontiguousarray(voice, np.float32), B, max_steps,
-                                           AR_MASK_STOP if mask_stop else 0, codes.reshape(-1), rows, _ptr(lat), steps))
+                                           (AR_MASK_STOP if mask_stop else 0) | (AR_RETIRE if retire else 0), codes.reshape(-1), rows, _ptr(lat), steps))
         lats = None
         if want_latents:
             lats, off = [], 0

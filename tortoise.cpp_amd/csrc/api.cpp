@@ -102,6 +102,8 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
   }
   else if (k == "share_uncond") c->share_uncond = value != 0;
   else if (k == "prof_stride") c->prof_stride = value < 1 ? 1 : (int)value;
+  else if (k == "rng_shard_offset") { if (value < 0) return fail(c, TTS_ERR_ARG, "rng_shard_offset < 0"); c->rng_shard_offset = (int)value; }
+  else if (k == "rng_shard_total") { if (value < 0) return fail(c, TTS_ERR_ARG, "rng_shard_total < 0"); c->rng_shard_total = (int)value; }
   else return fail(c, TTS_ERR_ARG, "unknown option '%s'", key);
   return TTS_OK;
 }
@@ -142,18 +144,23 @@ void tts_rng_normal(tts_ctx *c, float *out, int64_t n) { // sample_normal_noise,
 }
 
 int tts_tokenizer_load(tts_ctx *c, const char *path) {
-  if (!c) return TTS_ERR_ARG;
-  std::unique_ptr<Tokenizer> t(new Tokenizer());
-  if (!t->load(path)) return fail(c, TTS_ERR_IO, "Failed to open %s", path);
-  delete c->tok;
-  c->tok = t.release();
-  return (int)c->tok->vocab.size();
+  if (!c || !path) return TTS_ERR_ARG;
+  return guarded(c, [&] {
+    std::unique_ptr<Tokenizer> t(new Tokenizer());
+    if (!t->load(path)) return fail(c, TTS_ERR_IO, "Failed to open %s (missing, truncated or malformed)", path);
+    delete c->tok;
+    c->tok = t.release();
+    return (int)c->tok->vocab.size();
+  });
 }
 int tts_tokenize(tts_ctx *c, const char *message, int32_t *out, int cap) {
   if (!c || !c->tok) return c ? fail(c, TTS_ERR_STATE, "tokenizer not loaded") : TTS_ERR_ARG;
-  std::vector<int> ids = c->tok->encode(message);
-  for (int i = 0; i < (int)ids.size() && i < cap; i++) out[i] = ids[i];
-  return (int)ids.size();
+  if (!message || !out || cap < 0) return fail(c, TTS_ERR_ARG, "tts_tokenize: bad argument");
+  return guarded(c, [&] {
+    std::vector<int> ids = c->tok->encode(message);
+    for (int i = 0; i < (int)ids.size() && i < cap; i++) out[i] = ids[i];
+    return (int)ids.size();
+  });
 }
 
 int tts_ar_begin(tts_ctx *c, const int32_t *ids, int n, const float *voice, int B, int max_steps) {
@@ -173,6 +180,8 @@ int tts_sample(tts_ctx *c, const float *logits, const int32_t *ids, int ids_per_
   if (!c || !logits || !ids || !out || B < 1 || ids_per_cand < 1) return TTS_ERR_ARG;
   for (int i = 0; i < B * ids_per_cand; i++)
     if (ids[i] < 0 || ids[i] >= TTS_VOCAB_MEL) return fail(c, TTS_ERR_ARG, "penalty id out of range");
+  if (c->rng_shard_total > 0 && c->rng_shard_offset + B > c->rng_shard_total)
+    return fail(c, TTS_ERR_ARG, "candidates [%d, %d) exceed rng_shard_total %d", c->rng_shard_offset, c->rng_shard_offset + B, c->rng_shard_total);
   return guarded(c, [&] { sample_candidates(c, logits, ids, ids_per_cand, B, out); return (int)TTS_OK; });
 }
 
@@ -200,6 +209,16 @@ static int autoregressive_impl(tts_ctx *c, const int32_t *text_ids, int n_text, 
   int ids_per_cand = P;
   std::vector<std::vector<int>> seq(B);
   std::vector<int32_t> samples(B);
+  // Stop rule. Reference (strict, always for B == 1): the loop ends only in an iteration where ALL B samples are 8193
+  // (main.cpp:5214-5222), a candidate's sequence freezes at its first 8193 (5210-5213). TTS_AR_RETIRE (throughput mode,
+  // SURVEY 8e): a candidate retires at its first 8193 — from then on its input token is forced to 8193 and its samples are
+  // ignored — the loop ends when every candidate has retired, and reaching max_steps pads and returns instead of failing.
+  // The uniforms are consumed exactly as in strict mode (two per candidate and step, candidate order), so every
+  // sequence is the one strict mode would have produced.
+  const bool retire = (flags & TTS_AR_RETIRE) && B > 1;
+  if (c->rng_shard_total > 0 && c->rng_shard_offset + B > c->rng_shard_total)
+    return fail(c, TTS_ERR_ARG, "candidates [%d, %d) exceed rng_shard_total %d", c->rng_shard_offset, c->rng_shard_offset + B, c->rng_shard_total);
+  std::vector<char> done(B, 0);
   int i = 0;
   for (;;) {
     if (flags & TTS_AR_MASK_STOP)
@@ -209,15 +228,16 @@ static int autoregressive_impl(tts_ctx *c, const int32_t *text_ids, int n_text, 
     t_sample += now() - t0;
     int stops = 0;
     for (int b = 0; b < B; b++) {
+      if (retire && done[b]) { samples[b] = 8193; stops++; continue; }
       if (!(seq[b].size() > 0 && seq[b].back() == 8193)) seq[b].push_back(samples[b]);
-      if (samples[b] == 8193) stops++;
+      if (samples[b] == 8193) { stops++; done[b] = 1; }
     }
     ids.assign(samples.begin(), samples.end());
     ids_per_cand = 1;
     i++;
     if (stops == B) break;
     if (i >= max_steps) {
-      if (flags & TTS_AR_MASK_STOP) break;
+      if ((flags & TTS_AR_MASK_STOP) || retire) break;
       return fail(c, TTS_ERR_LIMIT, "no stop token within %d steps", max_steps);
     }
     t0 = now();

@@ -78,6 +78,9 @@ struct tts_ctx {
   tts::SamplerPool *sampler_pool = nullptr; // worker threads for the per-candidate sampler scans (host_logic.cpp)
   int sampler_threads = -1;                 // -1: min(7, hardware threads - 1); option "sampler_threads"
   bool share_uncond = true;                 // option "share_uncond": see DiffState::share_integ (diffusion.hip)
+  // candidate-parallel sharding: this context runs candidates [rng_shard_offset, +B) of a batch of rng_shard_total
+  // (0 = unsharded). The sampler skips the other ranks' uniforms; device noise streams are keyed by the global candidate id.
+  int rng_shard_offset = 0, rng_shard_total = 0;
   // profiling: per kernel family, HIP event pairs recorded on the ctx stream around every launch and
   // resolved lazily (no host sync inside the timed region)
   bool prof_on = false;

@@ -512,7 +512,7 @@ __global__ __launch_bounds__(128) void ddpm_update_kernel(const float *__restric
                                                           const int *__restrict__ row_t, const int *__restrict__ seq_len,
                                                           const int *__restrict__ seq_start, int ncand, StepScalars sc,
                                                           const float *__restrict__ noise /* same layout as x, or null */,
-                                                          uint64_t seed, uint32_t step) {
+                                                          uint64_t seed, uint32_t step, uint32_t stream0 /* global id of candidate 0 */) {
   const int r = blockIdx.x, s = row_seq[r], ch = threadIdx.x;
   if (s < 0 || s >= ncand || ch >= 100) return;
   const int T = seq_len[s], t = row_t[r];
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(128) void ddpm_update_kernel(const float *__restric
   const float mean = sc.coef1 * x0 + sc.coef2 * xv;
   float outv = mean;
   if (!sc.is_last) {
-    const float nz = noise ? noise[xi] : philox_normal(seed, (uint32_t)s, step, (uint32_t)(ch * T + t));
+    const float nz = noise ? noise[xi] : philox_normal(seed, stream0 + (uint32_t)s, step, (uint32_t)(ch * T + t));
     outv = (float)((double)mean + exp(0.5 * (double)model_log_variance) * (double)nz);
   }
   x[xi] = outv;
@@ -1248,7 +1248,7 @@ int diff_sample(tts_ctx *ctx, const float *latents, const int32_t *rows, int B, 
   } else {
     for (int c = 0; c < B; c++) {
       int64_t n = (int64_t)100 * lay.len[c];
-      philox_fill_kernel<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(st->xbuf.as<float>() + xoff[c], n, ctx->seed_value, (uint32_t)c, 0xFFFFFFFFu);
+      philox_fill_kernel<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(st->xbuf.as<float>() + xoff[c], n, ctx->seed_value, (uint32_t)(ctx->rng_shard_offset + c), 0xFFFFFFFFu);
     }
   }
   if (timing) (void)hipStreamSynchronize(ctx->stream);
@@ -1266,7 +1266,7 @@ int diff_sample(tts_ctx *ctx, const float *latents, const int32_t *rows, int B, 
     ddpm_update_kernel<<<lay.rows, 128, 0, ctx->stream>>>(
         st->net.as<float>(), st->xbuf.as<float>(), st->xoff.as<int64_t>(), lay.d_row_seq.as<int>(), lay.d_row_t.as<int>(),
         lay.d_len.as<int>(), lay.d_start.as<int>(), B, sc, host_noise ? st->noise.as<float>() + (size_t)(idx + 1) * total : nullptr,
-        ctx->seed_value, (uint32_t)idx);
+        ctx->seed_value, (uint32_t)idx, (uint32_t)ctx->rng_shard_offset);
     TTS_HIP(ctx, hipGetLastError());
   }
   const auto t_issued = now();

@@ -15,7 +15,8 @@
 //   gemm_f16_glds_kernel   any segment structure; one LDS stage, 4 workgroups per CU overlap each other
 //   gemm_f16_conv3_kernel  the k=3 convolution: one activation slab shared by the three taps, weight tiles
 //                          double-buffered
-// launch_gemm_f16 picks between them. Measured-and-rejected variants: gemm_f16_experiments.h (bench only).
+// launch_gemm_f16 picks between them. Measured-and-rejected variants: tools/gemm_f16_experiments.h (only tools/gemm_bench.hip
+// defines TTS_GEMM_VARIANT and adds -I tools).
 #pragma once
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
@@ -350,7 +351,7 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_kernel(GemmArgs 
   gemm_epilogue<MODE, MI>(g, acc, m0, n0, wm, wn, fr, fq);
 }
 
-#ifdef TTS_GEMM_VARIANT
+#ifdef TTS_GEMM_VARIANT // tools/gemm_bench.hip only (compiled with -I tools)
 #include "gemm_f16_experiments.h"
 #endif
 
@@ -365,7 +366,7 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
     while (!no_chunk && NT > 8 && cn > 1 && (cn % 2 == 0) && (size_t)cn * 128 * ktot * 2 > (size_t)2560 * 1024) cn /= 2;
     gg.cn = cn;
   }
-#ifdef TTS_GEMM_VARIANT // tools/gemm_bench.hip: measured-and-rejected variants live in gemm_f16_experiments.h
+#ifdef TTS_GEMM_VARIANT // tools/gemm_bench.hip: measured-and-rejected variants live in tools/gemm_f16_experiments.h
   if (TTS_GEMM_VARIANT != 1) return launch_gemm_experiment(g, s);
 #endif
   // Tile height: 128 rows. 160-row tiles (MI = 5: 1416 instead of 1768 workgroups on 768 slots) were measured 4-6 %

@@ -124,16 +124,19 @@ bool Tokenizer::load(const char *path) {
     }
     if (ch != '"') { cur += ch; continue; }
     if (st == IN_STRVAL) { commit(); continue; }
-    // closing quote of a key: expect [spaces] ':' [spaces] value
+    // closing quote of a key: expect [spaces] ':' [spaces] value. Every scan is bounded: a truncated or malformed file
+    // is a load failure (status + last_error), never a read past the buffer.
     ++i;
-    while (js[i] == ' ') ++i;
+    while (i < n && js[i] == ' ') ++i;
     ++i;
-    while (js[i] == ' ') ++i;
+    while (i < n && js[i] == ' ') ++i;
+    if (i >= n) return false;
     if (js[i] == '"') { st = IN_STRVAL; continue; }
-    while (js[i] != ',' && js[i] != '}') val += js[i++]; // (std::string[] past-the-end reads '\0')
+    while (i < n && js[i] != ',' && js[i] != '}') val += js[i++];
+    if (i >= n) return false; // value runs into the end of the file
     commit();
   }
-  return true;
+  return st == OUTSIDE; // a key or string value still open at EOF: truncated file
 }
 
 // gpt_split_words + greedy longest match (common.cpp:268-339); main.cpp:6559-6567 wraps the
@@ -300,47 +303,63 @@ struct SamplerPool {
   std::vector<std::thread> th;
   std::mutex m;
   std::condition_variable cv;
-  std::atomic<uint64_t> gen{0};
-  std::atomic<int> next{0}, remaining{0}, n_items{0}; // a straggler's last fetch_add may land in the next job: all atomics
+  // (job generation << 32) | next item. Items are claimed by compare-exchange on the whole word, so a worker that is
+  // still leaving job g can neither claim an item of job g+1 nor disturb its counters: its exchange fails as soon as the
+  // generation has moved on. `remaining` and `n_items` are published BEFORE the ticket (release) and only read after a
+  // ticket load (acquire) that showed the matching generation.
+  std::atomic<uint64_t> ticket{0};
+  std::atomic<int> remaining{0}, n_items{0};
   std::function<void(int)> fn;
-  bool stop = false;
+  std::atomic<bool> stop{false};
   explicit SamplerPool(int n) {
     for (int i = 0; i < n; i++) th.emplace_back([this] { loop(); });
   }
   ~SamplerPool() {
-    { std::lock_guard<std::mutex> lk(m); stop = true; gen++; }
+    { std::lock_guard<std::mutex> lk(m); stop.store(true); ticket.fetch_add(1ull << 32, std::memory_order_release); }
     cv.notify_all();
     for (auto &t : th) t.join();
   }
-  void drain() {
-    int i;
-    while ((i = next.fetch_add(1)) < n_items) { fn(i); remaining.fetch_sub(1); }
+  static uint32_t gen_of(uint64_t t) { return (uint32_t)(t >> 32); }
+  void drain(uint32_t g) {
+    for (;;) {
+      uint64_t t = ticket.load(std::memory_order_acquire);
+      if (gen_of(t) != g) return;                 // job g is over (or was never ours)
+      const int i = (int)(uint32_t)t;
+      if (i >= n_items.load(std::memory_order_relaxed)) return;
+      if (!ticket.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel)) continue;
+      fn(i);                                      // job g cannot complete before this item does: fn is still job g's
+      remaining.fetch_sub(1, std::memory_order_release);
+    }
   }
   void loop() {
-    uint64_t seen = 0;
+    uint32_t seen = 0;
     for (;;) {
       // spin up to 2 ms for the next job, then block
       auto t0 = std::chrono::steady_clock::now();
-      while (gen.load(std::memory_order_acquire) == seen) {
+      while (gen_of(ticket.load(std::memory_order_acquire)) == seen) {
         if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2000)) {
           std::unique_lock<std::mutex> lk(m);
-          cv.wait(lk, [&] { return gen.load() != seen; });
+          cv.wait(lk, [&] { return gen_of(ticket.load(std::memory_order_acquire)) != seen; });
           break;
         }
       }
-      seen = gen.load(std::memory_order_acquire);
-      if (stop) return;
-      drain();
+      seen = gen_of(ticket.load(std::memory_order_acquire));
+      if (stop.load()) return;
+      drain(seen);
     }
   }
   void run(int n, std::function<void(int)> f) {
+    uint32_t g;
     {
       std::lock_guard<std::mutex> lk(m);
-      fn = std::move(f); n_items = n; next = 0; remaining = n;
-      gen.fetch_add(1, std::memory_order_release);
+      fn = std::move(f);
+      n_items.store(n, std::memory_order_relaxed);
+      remaining.store(n, std::memory_order_relaxed);
+      g = gen_of(ticket.load(std::memory_order_relaxed)) + 1;
+      ticket.store((uint64_t)g << 32, std::memory_order_release); // publishes fn / n_items / remaining, next item = 0
     }
     cv.notify_all();
-    drain();
+    drain(g);
     while (remaining.load(std::memory_order_acquire) > 0) std::this_thread::yield();
   }
 };
@@ -349,13 +368,19 @@ void sampler_pool_free(SamplerPool *p) { delete p; }
 void sample_candidates(tts_ctx *ctx, const float *logits, const int32_t *ids, int ids_per_cand, int B,
                        int32_t *out) {
   const int V = TTS_VOCAB_MEL;
-  // the RNG is consumed in candidate order exactly as the reference does; the scans then run in parallel
+  // the RNG is consumed in candidate order exactly as the reference does; the scans then run in parallel.
+  // Sharded batch (options "rng_shard_offset" / "rng_shard_total"): this context holds candidates
+  // [offset, offset + B) of a batch of `total`; the used uniform of (step s, global candidate c) is output 2 (s total + c) + 1
+  // of the one mt19937 stream, so the draws of the other ranks' candidates are skipped (each uniform is one 32-bit output).
+  const int total = ctx->rng_shard_total > 0 ? ctx->rng_shard_total : B, c0 = ctx->rng_shard_total > 0 ? ctx->rng_shard_offset : 0;
   std::vector<float> samples(B);
+  if (c0 > 0) ctx->generator.discard(2ull * c0);
   for (int c = 0; c < B; c++) {
     float sample = ctx->distribution(ctx->generator); // first draw discarded (main.cpp:4708-4709)
     sample = ctx->distribution(ctx->generator);
     samples[c] = sample;
   }
+  if (total - c0 - B > 0) ctx->generator.discard(2ull * (total - c0 - B));
   auto one = [&](int c) { out[c] = sample_one(logits + (size_t)c * V, ids + (size_t)c * ids_per_cand, ids_per_cand, samples[c]); };
   if (B < 4 || ctx->sampler_threads == 0) { for (int c = 0; c < B; c++) one(c); return; }
   if (!ctx->sampler_pool) {
