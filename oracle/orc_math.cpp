@@ -217,3 +217,21 @@ void conv1d_f16(const float *x, int T, int Cin, const float *w, int K, int Cout,
 }
 
 } // namespace orc
+
+// ---- op-level probes (tests/test_oracle_vs_torch.py: every op against torch's) -------------------------------------
+using namespace orc;
+extern "C" {
+void orc_op_conv1d_f16(const float *x, int T, int Cin, const float *w, int K, int Cout, const float *bias, int pad, int dil,
+                       float *y) { conv1d_f16(x, T, Cin, w, K, Cout, bias, pad, dil, y); }
+void orc_op_groupnorm(const float *x, int T, int C, int G, float eps, const float *g, const float *b, float *y) {
+  groupnorm_tc(x, T, C, G, eps, g, b, y);
+}
+void orc_op_layernorm(float *x, int rows, int C, float eps, const float *g, const float *b) { layernorm_rows(x, rows, C, eps, g, b); }
+void orc_op_unary(int which, float *x, int64_t n) { // 0 gelu (tanh form), 1 silu
+  for (int64_t i = 0; i < n; i++) x[i] = which == 0 ? gelu_f(x[i]) : silu_f(x[i]);
+}
+void orc_op_softmax(float *x, int n) { softmax_row(x, n); }
+void orc_op_gemm_kn(int M, int N, int K, const float *A, const float *Bt, const float *bias, float *C) {
+  gemm_kn(M, N, K, A, K, Bt, N, C, N, bias);
+}
+}

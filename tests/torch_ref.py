@@ -1,0 +1,260 @@
+"""TEST INFRASTRUCTURE — an independent PyTorch (CPU, fp32) assembly of the three network stages from torch's own ops
+(F.conv1d, F.group_norm, F.layer_norm, F.conv_transpose1d, F.pad(reflect), Tensor.unfold, F.interpolate, F.gelu(tanh),
+F.silu, softmax), reading the reference-format weight files with synth_weights.read_ggml (PyTorch dim order).
+
+Purpose ("pin what can be pinned offline"): the oracle (oracle/orc_*.cpp) restates the reference's ggml graphs
+with hand-written loops; this module restates the same graphs with PyTorch semantics, which is what the ggml graphs were
+transcribed from (tortoise-tts' DiffusionTts / UnivNet / GPT-2). tests/test_oracle_vs_torch.py compares the two on synthetic
+weights: op semantics (conv1d-as-fp16-im2col, GroupNorm, conv_transpose_1d, reflect pad, unfold/LVC, nearest upscale,
+tanh-GELU) and the wiring of every block are then torch-pinned; what stays unverified is only what neither side can know
+offline (ggml-fork constants: GroupNorm eps, fp16 activation tables — both exposed as switches).
+
+Reference line numbers are /root/reference/main.cpp. The fp16 rounding points are the reference's: conv1d rounds weights and
+the im2col'd input to fp16 and accumulates in f32; the AR stack rounds QKV to fp16 (main.cpp:2789-2790).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+torch.set_grad_enabled(False)
+
+
+def h16(x):
+    """fp16 round trip (ggml F32->F16->F32); keeps the working dtype (f32, or f64 for the triangulation runs)."""
+    return x.float().half().to(x.dtype)
+
+
+def conv1d_f16(x, w, b, padding=0, dilation=1):
+    """x [Cin, T], w [Cout, Cin, K] -> [Cout, Tout]; fp16-rounded operands, f32 accumulate."""
+    return F.conv1d(h16(x)[None], h16(w), b, padding=padding, dilation=dilation)[0]
+
+
+def gn32(x, g, b, eps):
+    """x [C, T] -> GroupNorm(32) over (C/32, T) per group (ggml_group_norm on [T,1,C])."""
+    return F.group_norm(x[None], 32, g, b, eps)[0]
+
+
+class Weights:
+    def __init__(self, path, dtype=torch.float32):
+        import tortoise_cpp_amd_loader
+        tortoise_cpp_amd_loader.load()
+        from tortoise_cpp_amd import synth_weights  # the container reader (format: main.cpp:811-888)
+        self.dtype = dtype
+        self.t = {k: torch.from_numpy(v).to(dtype) for k, v in synth_weights.read_ggml(path).items()}
+
+    def tensor(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.dtype)
+
+    def __getitem__(self, k):
+        return self.t[k]
+
+    def has(self, k):
+        return k in self.t
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# diffusion (diffusion_graph, main.cpp:3066-4044)
+# ------------------------------------------------------------------------------------------------------------------
+class TorchDiffusion:
+    def __init__(self, path, buckets, gn_eps=1e-6, dtype=torch.float32):
+        """dtype float64: the same graph (same fp16 rounding points) evaluated in double — the yardstick for how far two f32
+        evaluations with different summation orders may legitimately be apart. buckets(n) -> int array [n, n] of T5 relative-position buckets, index [query][key] (main.cpp:4722-4749; pinned against
+        the reference's own code in tests/test_host_parity.py — passed in so this file stays free of oracle imports)."""
+        self.w = Weights(path, dtype)
+        self.buckets = buckets
+        self.eps = gn_eps
+        w = self.w
+        self.n_lc = 0
+        while w.has("latent_conditioner.%d.norm.weight" % (self.n_lc + 1)):
+            self.n_lc += 1
+        self.n_integ = 0
+        while w.has("conditioning_timestep_integrator.%d.resblk.in_layers.0.weight" % self.n_integ):
+            self.n_integ += 1
+        self.n_main = 0
+        while w.has("layers.%d.resblk.in_layers.0.weight" % self.n_main):
+            self.n_main += 1
+        self.n_tail = 0
+        while w.has("layers.%d.in_layers.0.weight" % (self.n_main + self.n_tail)):
+            self.n_tail += 1
+
+    def attention(self, x, p):
+        """AttentionBlock (main.cpp:3184-3288): x [C, T]."""
+        w = self.w
+        C, T = x.shape
+        h = gn32(x, w[p + ".norm.weight"], w[p + ".norm.bias"], self.eps)
+        qkv = conv1d_f16(h, w[p + ".qkv.weight"].reshape(3 * C, C, 1), w[p + ".qkv.bias"])  # [3C, T]
+        q, k, v = qkv.reshape(16, 192, T).split(64, dim=1)  # channel = head*192 + {q | k | v}
+        rel = w[p + ".relative_pos_embeddings.relative_attention_bias.weight"]  # [32 buckets, 16 heads]
+        bk = torch.from_numpy(np.asarray(self.buckets(T), np.int64))  # [query, key]
+        bias = rel[bk].permute(2, 0, 1) * 8.0  # [head, query, key]
+        att = torch.einsum("hdi,hdj->hij", q, k) * (1.0 / 8.0) + bias
+        att = torch.softmax(att, dim=-1)
+        a = torch.einsum("hij,hdj->hdi", att, v).reshape(C, T)
+        o = F.conv1d(a[None], w[p + ".proj_out.weight"].reshape(C, C, 1), w[p + ".proj_out.bias"])[0]  # F32 linear
+        return x + o
+
+    def resblock(self, x, p, emb):
+        """ResBlock (main.cpp:3659-3782): x [C, T], emb [1024] (time embedding after the MLP, not yet activated)."""
+        w = self.w
+        C = x.shape[0]
+        h = F.silu(gn32(x, w[p + ".in_layers.0.weight"], w[p + ".in_layers.0.bias"], self.eps))
+        h = conv1d_f16(h, w[p + ".in_layers.2.weight"].reshape(C, C, 1), w[p + ".in_layers.2.bias"])
+        ss = F.linear(F.silu(emb), w[p + ".emb_layers.1.weight"], w[p + ".emb_layers.1.bias"])  # [2048] = scale | shift
+        scale, shift = ss[:C], ss[C:]
+        h = gn32(h, w[p + ".out_layers.0.weight"], w[p + ".out_layers.0.bias"], self.eps)
+        h = F.silu(h * (scale[:, None] + 1.0) + shift[:, None])
+        h = conv1d_f16(h, w[p + ".out_layers.3.weight"], w[p + ".out_layers.3.bias"], padding=1)
+        return x + h
+
+    @staticmethod
+    def upscale_index(L, T):
+        """ggml_upscale_ext nearest: src = (int)(dst / ((float)T / L)) in f32 (main.cpp:3321 via SURVEY 3.7)."""
+        sf = np.float32(T) / np.float32(L)
+        idx = (np.arange(T, dtype=np.float32) / sf).astype(np.int64)
+        return np.minimum(idx, L - 1)
+
+    def code_embedding(self, latents, T):
+        """latents [L, 1024] -> [T, 1024] (main.cpp:3156-3321)."""
+        w = self.w
+        x = w.tensor(latents).T.contiguous()  # [C, L]
+        C, L = x.shape
+        x = conv1d_f16(x, w["latent_conditioner.0.weight"], w["latent_conditioner.0.bias"], padding=1)
+        for i in range(self.n_lc):
+            x = self.attention(x, "latent_conditioner.%d" % (i + 1))
+        x = gn32(x, w["code_norm.weight"], w["code_norm.bias"], self.eps)
+        cl = w["diffusion_conditioning_latent"].reshape(-1)
+        x = x * (cl[:C, None] + 1.0) + cl[C:, None]
+        idx = torch.from_numpy(self.upscale_index(L, T))
+        return x[:, idx].T.contiguous().float().numpy()
+
+    def time_embedding(self, te):
+        w = self.w
+        e = F.linear(w.tensor(te), w["time_embed.0.weight"], w["time_embed.0.bias"])
+        return F.linear(F.silu(e), w["time_embed.2.weight"], w["time_embed.2.bias"])
+
+    def forward(self, code_emb, x_t, te):
+        """code_emb [T,1024] or None; x_t [100,T]; te = sinusoidal timestep embedding [1024] (host math, pinned separately).
+        Returns [200, T]."""
+        w = self.w
+        x_t = w.tensor(x_t)
+        T = x_t.shape[1]
+        emb = self.time_embedding(te)
+        if code_emb is None:
+            ce = w["unconditioned_embedding"].reshape(-1, 1).repeat(1, T)
+        else:
+            ce = w.tensor(code_emb).T.contiguous()
+        for i in range(self.n_integ):
+            p = "conditioning_timestep_integrator.%d" % i
+            ce = self.resblock(ce, p + ".resblk", emb)
+            ce = self.attention(ce, p + ".attn")
+        xi = conv1d_f16(x_t, w["inp_block.weight"], w["inp_block.bias"], padding=1)
+        x = conv1d_f16(torch.cat([xi, ce], 0), w["integrating_conv.weight"].reshape(1024, 2048, 1), w["integrating_conv.bias"])
+        for i in range(self.n_main):
+            x = self.resblock(x, "layers.%d.resblk" % i, emb)
+            x = self.attention(x, "layers.%d.attn" % i)
+        for i in range(self.n_tail):
+            x = self.resblock(x, "layers.%d" % (self.n_main + i), emb)
+        h = F.silu(gn32(x, w["out.0.weight"], w["out.0.bias"], self.eps))
+        return conv1d_f16(h, w["out.2.weight"], w["out.2.bias"], padding=1).float().numpy()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# vocoder (vocoder_graph, main.cpp:4068-4483)
+# ------------------------------------------------------------------------------------------------------------------
+class TorchVocoder:
+    def __init__(self, path, dtype=torch.float32):
+        self.w = Weights(path, dtype)
+
+    def forward(self, mel_denorm, noise):
+        """mel_denorm [100, T] (already denormalised), noise [64, T+10] -> audio [(T+10)*256 - 6]."""
+        w = self.w
+        lk = lambda v: F.leaky_relu(v, 0.2)
+        mel = w.tensor(mel_denorm)
+        z = w.tensor(noise)
+        T = mel.shape[1]
+        Tm = T + 10
+        pm = torch.cat([mel, w.tensor(np.full((100, 10), -11.5129, np.float32))], 1)  # 10 silent frames (main.cpp:6051-6054)
+        x = conv1d_f16(F.pad(z[None], (3, 3), mode="reflect")[0], w["conv_pre.weight"], w["conv_pre.bias"])  # [32, Tm]
+        for i, (s, hop) in enumerate(zip((8, 8, 4), (8, 64, 256))):
+            rs = "res_stack.%d" % i
+            # leaky -> ConvTranspose1d(32, 32, 2s, stride s, padding s/2): F32 (main.cpp:4145-4167)
+            x = F.conv_transpose1d(lk(x)[None], w[rs + ".convt_pre.1.weight"], w[rs + ".convt_pre.1.bias"], stride=s, padding=s // 2)[0]
+            kp = rs + ".kernel_predictor"
+            c = lk(conv1d_f16(pm, w[kp + ".input_conv.0.weight"], w[kp + ".input_conv.0.bias"], padding=2))
+            for r in range(3):
+                rp = kp + ".residual_convs.%d" % r
+                c1 = lk(conv1d_f16(c, w[rp + ".1.weight"], w[rp + ".1.bias"], padding=1))
+                c2 = lk(conv1d_f16(c1, w[rp + ".3.weight"], w[rp + ".3.bias"], padding=1))
+                c = c + c2
+            kern = conv1d_f16(c, w[kp + ".kernel_conv.weight"], w[kp + ".kernel_conv.bias"], padding=1)  # [24576, Tm]
+            kb = conv1d_f16(c, w[kp + ".bias_conv.weight"], w[kp + ".bias_conv.bias"], padding=1)  # [256, Tm]
+            kern = kern.reshape(4, 32, 64, 3, Tm)  # [layer, in, out, tap, frame] (channel = ((c*32+i)*64+o)*3+k, main.cpp:4323, 4371)
+            kb = kb.reshape(4, 64, Tm)
+            for cidx, d in enumerate((1, 3, 9, 27)):
+                cb = rs + ".conv_blocks.%d.1" % cidx
+                y = lk(conv1d_f16(lk(x), w[cb + ".weight"], w[cb + ".bias"], padding=d, dilation=d))  # [32, len]
+                # location-variable convolution through unfold (main.cpp:4337-4456): windows of hop + 2 samples per frame, 3 taps
+                yp = F.pad(y, (1, 1))
+                win = yp.unfold(1, hop + 2, hop)  # [32, Tm, hop + 2]
+                win = win.unfold(2, 3, 1)  # [32, Tm, hop, 3]
+                o = torch.einsum("ilsk,iokl->ols", win, kern[cidx]) + kb[cidx][:, :, None]  # [64, Tm, hop]
+                o = o.reshape(64, Tm * hop)
+                x = x + torch.sigmoid(o[:32]) * torch.tanh(o[32:])
+        return conv1d_f16(lk(x), w["conv_post.1.weight"].reshape(1, 32, 7), w["conv_post.1.bias"])[0].float().numpy()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# autoregressive GPT-2 (main.cpp:2053-3040)
+# ------------------------------------------------------------------------------------------------------------------
+class TorchAR:
+    def __init__(self, path, dtype=torch.float32):
+        self.w = Weights(path, dtype)
+        self.n_layers = 0
+        while self.w.has("inference_model.transformer.h.%d.ln_1.weight" % self.n_layers):
+            self.n_layers += 1
+
+    def stack(self, x):
+        """x [S, 1024]: full causal pass, QKV rounded to fp16 (main.cpp:2718-2983)."""
+        w = self.w
+        S = x.shape[0]
+        mask = torch.full((S, S), float("-inf"), dtype=x.dtype).triu(1)
+        for l in range(self.n_layers):
+            p = "inference_model.transformer.h.%d" % l
+            h = F.layer_norm(x, (1024,), w[p + ".ln_1.weight"], w[p + ".ln_1.bias"], 1e-5)
+            qkv = h16(h @ w[p + ".attn.c_attn.weight"] + w[p + ".attn.c_attn.bias"])  # HF Conv1D: weight [in, out]
+            q, k, v = [t.reshape(S, 16, 64).transpose(0, 1) for t in qkv.split(1024, dim=1)]
+            att = torch.softmax(q @ k.transpose(1, 2) * (1.0 / 8.0) + mask, dim=-1)
+            a = (att @ v).transpose(0, 1).reshape(S, 1024)
+            x = x + (a @ w[p + ".attn.c_proj.weight"] + w[p + ".attn.c_proj.bias"])
+            h = F.layer_norm(x, (1024,), w[p + ".ln_2.weight"], w[p + ".ln_2.bias"], 1e-5)
+            f = F.gelu(h @ w[p + ".mlp.c_fc.weight"] + w[p + ".mlp.c_fc.bias"], approximate="tanh")
+            x = x + (f @ w[p + ".mlp.c_proj.weight"] + w[p + ".mlp.c_proj.bias"])
+        return x
+
+    def final_norms(self, x):
+        w = self.w
+        x = F.layer_norm(x, (1024,), w["inference_model.transformer.ln_f.weight"], w["inference_model.transformer.ln_f.bias"], 1e-5)
+        return F.layer_norm(x, (1024,), w["inference_model.lm_head.0.weight"], w["inference_model.lm_head.0.bias"], 1e-5)
+
+    def inputs(self, tokens, voice, mel_ids, mel_pos):
+        w = self.w
+        tok = torch.from_numpy(np.asarray(tokens, np.int64))
+        rows = [w.tensor(voice)[None],
+                w["text_embedding.weight"][tok] + w["text_pos_embedding.emb.weight"][: len(tok)]]
+        mel = torch.from_numpy(np.asarray(mel_ids, np.int64))
+        pos = torch.from_numpy(np.asarray(mel_pos, np.int64))
+        rows.append(w["mel_embedding.weight"][mel] + w["mel_pos_embedding.emb.weight"][pos])
+        return torch.cat(rows, 0)
+
+    def logits_after(self, tokens, voice, mel_ids, mel_pos):
+        """Logits at the last position of [voice | text | mel_ids at mel positions mel_pos] — a cache-free evaluation of what the
+        prefill (mel_ids = [8192], pos [0]) and decode step i (positions 0, 2, 3, ..., i + 2: the reference's quirk,
+        main.cpp:5244) produce through the KV cache."""
+        w = self.w
+        x = self.final_norms(self.stack(self.inputs(tokens, voice, mel_ids, mel_pos))[-1:])
+        return F.linear(x, w["inference_model.lm_head.1.weight"], w["inference_model.lm_head.1.bias"])[0].float().numpy()
+
+    def latents(self, tokens, voice, codes, n_mel):
+        """Latent pass (main.cpp:2053-2519): mel positions 0 .. n_mel-1; returns the n_mel mel rows after both LayerNorms."""
+        x = self.inputs(tokens, voice, codes[:n_mel], np.arange(n_mel))
+        return self.final_norms(self.stack(x))[1 + len(tokens):].float().numpy()
