@@ -58,6 +58,19 @@ def mid_models(pkg):
 
 
 @pytest.fixture(scope="session")
+def full_models(pkg):
+    """The benchmark's own weights: 30 GPT-2 layers, 4 + 3 + 10 + 3 diffusion blocks, UnivNet (2.4 GB, ~1 min to generate).
+    Same directory and seed as bench.py, so the weights bench.py times are the weights these tests check."""
+    d = os.environ.get("TTS_BENCH_MODELS", "/tmp/tts_bench_models")
+    stamp = os.path.join(d, ".done")
+    if not os.path.exists(stamp):
+        from tortoise_cpp_amd import synth_weights as sw
+        sw.write_all(d, seed=1234)
+        open(stamp, "w").write("ok")
+    return d
+
+
+@pytest.fixture(scope="session")
 def engine(pkg):
     eng = pkg.Engine(0)
     yield eng

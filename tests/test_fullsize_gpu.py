@@ -1,0 +1,196 @@
+"""GPU parity at the size the benchmark runs: full-depth synthetic weights — 30 GPT-2 layers, 4 latent-
+conditioner + 3 integrator + 10 main + 3 tail diffusion blocks, UnivNet — the very files bench.py times (conftest.full_models),
+against the oracle through the C ABI. Error compounds with depth (30 fp16-QKV rounding points, 13 AttentionBlocks with fp16 P.V),
+so the reduced-depth tests in test_ar_gpu.py / test_diffusion_gpu.py do not cover this.
+
+Gates: AR logits 1e-4 relative (f32 on both sides), latents and mel/audio 1e-3 relative (north star), the sampling loop the
+reference's own gate abs 0.01 (main.cpp:6223). configs[1] = test_config1_end_to_end, configs[2] = test_config2_batch16."""
+import numpy as np
+import pytest
+
+from conftest import DEFAULT_TOKENS
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def bench_prompt():
+    return np.array([255] + [3 + (7 * j) % 250 for j in range(64)] + [0], np.int32)  # the synthetic 64-token prompt
+
+
+@pytest.fixture(scope="module")
+def full_engine(pkg, full_models):
+    eng = pkg.Engine(0)
+    eng.load(full_models)
+    yield eng
+    eng.close()
+
+
+def test_ar_full_depth(full_engine, oracle, full_models, voice):
+    """30 layers: prompt pass (P = 68, the bench prompt), 8 decode steps at B = 16 (one full candidate tile, as in bench.py), a 40-row
+    latent pass."""
+    eng = full_engine
+    ar = oracle.AR(oracle.Model(full_models + "/ggml-model.bin"))
+    assert eng.ar_layers == ar.n_layers == 30
+    toks, B = bench_prompt(), 16
+    eng.ar_begin(toks, voice, B, 16)
+    ar.start(toks, voice, B, len(toks) + 2 + 17)
+    errs = [rel_err(eng.ar_prefill(), ar.prefill())]
+    rs = np.random.RandomState(1)
+    for i in range(8):
+        prev = rs.randint(0, 8192, B).astype(np.int32)
+        errs.append(rel_err(eng.ar_step(prev, i), ar.step(prev, i)))
+    print("full-depth AR logits rel err: prefill %.1e, steps %s" % (errs[0], " ".join("%.1e" % e for e in errs[1:])))
+    assert max(errs) < 1e-4, errs
+    codes = rs.randint(0, 8192, (2, 502)).astype(np.int32)
+    codes[:, 0] = 8192
+    lg, lo = eng.ar_latents(codes, 40), ar.latents(codes, 40)
+    e = rel_err(lg, lo)
+    print("full-depth latents (40 rows) rel err %.1e" % e)
+    assert lg.shape == lo.shape == (2, 40, 1024) and e < 1e-3
+
+
+@pytest.mark.parametrize("L", [43, 200])  # T = 187 (the reference fixture's size) and T = 870 (the benchmark's)
+def test_diffusion_forward_full_depth(full_engine, oracle, full_models, L):
+    eng = full_engine
+    od = oracle.Diffusion(oracle.Model(full_models + "/ggml-diffusion-model.bin"))
+    lat = np.random.RandomState(L).randn(L, 1024).astype(np.float32)
+    T = eng.frames(L)
+    x_t = np.random.RandomState(7).randn(100, T).astype(np.float32)
+    ce = od.code_embedding(lat, T)
+    for cond_free, timestep in ((False, 3999), (True, 3999), (False, 557)):
+        got = eng.diffusion_forward(lat, x_t, timestep, cond_free)
+        want = od.forward(None if cond_free else ce, x_t, timestep)
+        e = rel_err(got, want)
+        print("full-depth diffusion forward T=%d t=%d cond_free=%s: rel err %.2e" % (T, timestep, cond_free, e))
+        assert got.shape == want.shape == (200, T) and e < 1e-3, e
+
+
+def test_vocoder_full(full_engine, oracle, full_models):
+    eng = full_engine
+    ov = oracle.Vocoder(oracle.Model(full_models + "/ggml-vocoder-model.bin"))
+    T = 187
+    rs = np.random.RandomState(3)
+    mel = np.clip(rs.randn(100, T) * 0.5, -1, 1).astype(np.float32)
+    nz = rs.randn(64, T + 10).astype(np.float32)
+    au, ao = eng.vocoder([mel], noise=[nz])[0], ov.run(mel, noise=nz)
+    e = rel_err(au, ao)
+    print("vocoder T=187 rel err %.2e" % e)
+    assert au.shape == ao.shape and e < 1e-3
+
+
+@pytest.mark.parametrize("models,L", [("small", 12), ("mid", 12)])
+def test_sampling_loop_80_steps(engine, oracle, small_models, mid_models, models, L):
+    """tts_diffusion over the full 80-step schedule against the oracle's diffusion() with the same explicit noise — the
+    reference's own gate: max abs 0.01 on the mel (main.cpp:6223); mean reported."""
+    d = small_models if models == "small" else mid_models
+    engine.load(diffusion=d + "/ggml-diffusion-model.bin")
+    od = oracle.Diffusion(oracle.Model(d + "/ggml-diffusion-model.bin"))
+    lat = np.random.RandomState(L).randn(L, 1024).astype(np.float32)
+    T = engine.frames(L)
+    noise = np.random.RandomState(5).randn(81, 100 * T).astype(np.float32)
+    mel = engine.diffusion([lat], n_steps=80, noise=[noise])[0]
+    want = od.sample(lat, n_steps=80, noise=noise)
+    err = np.abs(mel - want)
+    print("80-step loop (%s weights, T=%d): max abs %.2e mean %.2e" % (models, T, err.max(), err.mean()))
+    assert np.abs(want).max() <= 1.5 and err.max() <= 0.01, (err.max(), err.mean())
+
+
+def test_config1_end_to_end(full_engine, oracle, full_models, voice):
+    """configs[1]: the default message, mol.bin voice, --seed 0, ONE candidate, 80 diffusion steps, full-size weights, every stage
+    against the oracle with the RNG stream in lock-step (AR uniforms -> x_T -> 80 noise vectors -> vocoder noise, the reference's
+    order). The stop token is masked (random weights do not produce one): 40 codes -> L = 48, T = 208."""
+    eng = full_engine
+    toks, S, seed = DEFAULT_TOKENS, 40, 0
+    eng.seed(seed)
+    codes, rows, lats, steps = eng.autoregressive(toks, voice, 1, S, mask_stop=True)
+    ar = oracle.AR(oracle.Model(full_models + "/ggml-model.bin"))
+    rng = oracle.Rng(seed)
+    rc, codes_o, steps_o, _ = ar.generate(toks, voice, 1, rng, S, mask_stop=True)
+    assert rc == 0 and steps == steps_o == S
+    if not (codes == codes_o).all():  # a split must be explained by sub-tolerance logits at the first divergent step
+        j = int(np.argwhere(codes[0] != codes_o[0])[0][0])
+        ar.start(toks, voice, 1, len(toks) + 2 + S + 1)
+        eng.ar_begin(toks, voice, 1, S)
+        lo, lg = ar.prefill(), eng.ar_prefill()
+        for i in range(j - 1):
+            lo, lg = ar.step(codes_o[:, 1 + i], i), eng.ar_step(codes_o[:, 1 + i], i)
+        assert rel_err(lg, lo) < 1e-4
+        pytest.skip("AR trajectories split at step %d with logits within %.1e (fp16-QKV rounding flip): the lock-step comparison of "
+                    "the later stages does not apply to this seed" % (j - 1, rel_err(lg, lo)))
+    L = int(rows[0])
+    lat_o = ar.latents(codes_o, L + 1)[0, :L]
+    e_lat = rel_err(lats[0], lat_o)
+    del ar
+    # diffusion: reference noise order from the shared stream; the oracle runs on ITS latents (end-to-end comparison)
+    mel = eng.diffusion([lats[0]], n_steps=80)[0]
+    od = oracle.Diffusion(oracle.Model(full_models + "/ggml-diffusion-model.bin"))
+    mel_o = od.sample(lat_o, n_steps=80, rng=rng)
+    del od
+    dm = np.abs(mel - mel_o)
+    au = eng.vocoder([mel])[0]
+    ov = oracle.Vocoder(oracle.Model(full_models + "/ggml-vocoder-model.bin"))
+    au_o = ov.run(mel_o, rng=rng)
+    da = np.abs(au - au_o)
+    assert eng.rng_uniform() == rng.uniform()  # every stage consumed the stream exactly like the reference
+    # vocoder gate proper: same mel, same explicit noise on both sides (the end-to-end audio difference above also carries the
+    # mel difference through a network that amplifies it; it is reported, the reference gates each stage on its own fixture)
+    nz = np.random.RandomState(4).randn(64, mel_o.shape[1] + 10).astype(np.float32)
+    e_voc = rel_err(eng.vocoder([mel_o], noise=[nz])[0], ov.run(mel_o, noise=nz))
+    print("configs[1] end to end: ids identical (%d codes), latents rel %.1e, mel max abs %.2e mean %.2e, vocoder on the oracle's mel rel %.2e; "
+          "end-to-end audio max abs %.2e of range %.2f" % (S, e_lat, dm.max(), dm.mean(), e_voc, da.max(), np.abs(au_o).max()))
+    assert e_lat < 1e-3
+    assert dm.max() <= 0.01  # the reference's gate on target_mel (main.cpp:6223)
+    assert e_voc < 1e-3
+
+
+def test_config2_batch16(full_engine, oracle, full_models, voice, pkg):
+    """configs[2] at the benchmark's own shapes: 16 candidates of the 64-token prompt, batched through all three stages exactly as
+    bench.py does (device noise), with full-size weights. Checked against the oracle where the oracle can follow: AR ids of every
+    candidate (teacher-forced check of one late decode step at B = 16, context 68 + 24), the latents of candidates 0 and 15, one
+    batched network evaluation inside the sampling loop (first step, all 32 sequences: x_T is reproduced on the host from the device
+    generator's output) and the vocoder on the batch's own mel for candidates 0 and 15."""
+    eng = full_engine
+    toks, B, S = bench_prompt(), 16, 24
+    eng.seed(77)
+    codes, rows, lats, steps = eng.autoregressive(toks, voice, B, S, mask_stop=True)
+    assert steps == S and (rows == rows[0]).all()
+    ar = oracle.AR(oracle.Model(full_models + "/ggml-model.bin"))
+    # teacher-forced: the oracle replays the device's ids; logits of the last step within 1e-4 for all 16 candidates
+    ar.start(toks, voice, B, len(toks) + 2 + S + 1)
+    eng.ar_begin(toks, voice, B, S)
+    lo, lg = ar.prefill(), eng.ar_prefill()
+    worst = rel_err(lg, lo)
+    for i in range(S - 1):
+        lo, lg = ar.step(codes[:, 1 + i], i), eng.ar_step(codes[:, 1 + i], i)
+        worst = max(worst, rel_err(lg, lo))
+    print("configs[2] AR B=16: worst logits rel err over %d steps %.1e" % (S, worst))
+    assert worst < 1e-4
+    L = int(rows[0])
+    lat_o = ar.latents(codes[[0, 15]], L + 1)
+    for k, c in enumerate((0, 15)):
+        assert rel_err(lats[c], lat_o[k, :L]) < 1e-3
+    del ar
+    # diffusion + vocoder as one batch of 16 (32 sequences with the unconditioned copies), 4 steps, device noise
+    mels = eng.diffusion(lats, n_steps=4, noise_mode=pkg.NOISE_DEVICE)
+    assert all(np.isfinite(m).all() and np.abs(m).max() <= 1.5 for m in mels)
+    # the same batch, explicit noise, against the oracle for two candidates: 4 coarse steps (gate as the 6-step test: 2e-2 max)
+    T = eng.frames(L)
+    rs = np.random.RandomState(9)
+    noise = [rs.randn(5, 100 * T).astype(np.float32) for _ in range(B)]
+    mels = eng.diffusion(lats, n_steps=4, noise=noise)
+    od = oracle.Diffusion(oracle.Model(full_models + "/ggml-diffusion-model.bin"))
+    for c in (0, 15):
+        want = od.sample(lats[c], n_steps=4, noise=noise[c])
+        err = np.abs(mels[c] - want)
+        print("configs[2] batched sampling loop cand %d: max %.2e mean %.2e" % (c, err.max(), err.mean()))
+        assert err.max() < 2e-2 and err.mean() < 5e-4
+    del od
+    nz = [rs.randn(64, T + 10).astype(np.float32) for _ in range(B)]
+    aus = eng.vocoder(mels, noise=nz)
+    ov = oracle.Vocoder(oracle.Model(full_models + "/ggml-vocoder-model.bin"))
+    for c in (0, 15):
+        assert rel_err(aus[c], ov.run(mels[c], noise=nz[c])) < 1e-3
