@@ -49,6 +49,18 @@ struct GemmArgs {
   int mode;
 };
 
+#ifdef TTS_GEMM_TRACE // developer build (tools/gemm_diag.hip): phase timestamps (100 MHz wall clock) of every workgroup / tile
+__device__ unsigned long long tts_gemm_trace[65536 * 8];
+#define GEMM_TR_DECL unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define GEMM_TR(i) do { tr_[i] = wall_clock64(); } while (0)
+#define GEMM_TR_FLUSH(slot) do { if (threadIdx.x == 0 && (slot) < 65536) { tr_[6] = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11)); \
+  tr_[7] = __builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (31 << 11)); for (int q_ = 0; q_ < 8; q_++) tts_gemm_trace[(size_t)(slot) * 8 + q_] = tr_[q_]; } } while (0)
+#else
+#define GEMM_TR_DECL
+#define GEMM_TR(i)
+#define GEMM_TR_FLUSH(slot)
+#endif
+
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // Single 32 KB LDS stage filled by direct global->LDS DMA (global_load_lds_dwordx4): no
@@ -183,6 +195,8 @@ static __global__ __launch_bounds__(256, WGS) void gemm_f16_glds_kernel(GemmArgs
   const int mq = MT >> 3, mr = MT & 7;
   const int mcount = mq + (xcd < mr ? 1 : 0), mfirst = xcd * mq + (xcd < mr ? xcd : mr);
   if (idx >= mcount * NT) return; // grid is padded to 8 * max tiles per XCD
+  GEMM_TR_DECL;
+  GEMM_TR(0);
   const int cn = g.cn > 0 ? g.cn : NT, per_chunk = mcount * cn;
   const int chunk = idx / per_chunk, rem = idx - chunk * per_chunk;
   const int m0 = (mfirst + rem / cn) * BM, n0 = (chunk * cn + rem % cn) << 7;
@@ -214,6 +228,7 @@ static __global__ __launch_bounds__(256, WGS) void gemm_f16_glds_kernel(GemmArgs
   char *sa = smem, *sb = smem + BM * 128;
   // operand order (see gemm_epilogue): natural only for the V columns of a QKV projection (wave-uniform)
   const bool natural = (MODE == GEMM_OUT_QKV) && (((n0 + wn * 64) % 192) >= 128);
+  GEMM_TR(1);
   // the K loop is instantiated once per operand order so the choice costs nothing inside it
   auto kloop = [&](auto nat) {
     constexpr bool NAT = decltype(nat)::value;
@@ -231,6 +246,9 @@ static __global__ __launch_bounds__(256, WGS) void gemm_f16_glds_kernel(GemmArgs
       for (int i = 0; i < 4; i++)
         __builtin_amdgcn_global_load_lds((gptr_t)(wbase + boff[i]), (lptr_t)(sb + (wave * 4 + i) * 1024), 16, 0, 0);
       __syncthreads(); // waits vmcnt(0) for the DMA, then barrier
+#ifdef TTS_GEMM_TRACE
+      if (seg == 0 && kt == 0) GEMM_TR(2);
+#endif
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
         half8 af[MI], bf[4];
@@ -252,8 +270,138 @@ static __global__ __launch_bounds__(256, WGS) void gemm_f16_glds_kernel(GemmArgs
   };
   if (MODE == GEMM_OUT_QKV && natural) kloop(std::true_type{});
   else kloop(std::false_type{});
+  GEMM_TR(3);
+#ifdef TTS_GEMM_DIAG_NOEPI // tools/gemm_diag.hip: the K loop alone (the runtime condition keeps the accumulators live)
+  if (g.ldo != -12345) { GEMM_TR(4); GEMM_TR_FLUSH(blockIdx.x); return; }
+#endif
   if (resid_first) gemm_epilogue<MODE, MI, true>(g, acc, m0, n0, wm, wn, fr, fq);
   else gemm_epilogue<MODE, MI>(g, acc, m0, n0, wm, wn, fr, fq);
+  GEMM_TR(4);
+#ifdef TTS_GEMM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // stamp 5: the epilogue's stores have been acknowledged
+  GEMM_TR(5);
+#endif
+  GEMM_TR_FLUSH(blockIdx.x);
+}
+
+// Persistent form of gemm_f16_glds_kernel: the grid is 8 XCDs x (CUs per XCD x WGS) workgroups, each walking the tiles
+// idx = slot, slot + S, ... of its XCD's list (the same chunk-outermost order: at any moment the S resident workgroups of an
+// XCD work on S consecutive tiles, exactly what the hardware dispatcher does with the one-tile-per-workgroup grid). The first
+// K tile of the NEXT output tile is requested before the epilogue of the current one, so a tile boundary costs neither a
+// workgroup launch nor an exposed first-DMA round trip.
+template <int MODE, int MI, int WGS = 3>
+static __global__ __launch_bounds__(256, WGS) void gemm_f16_pers_kernel(GemmArgs g) {
+  constexpr int BM = 32 * MI;
+  __shared__ __attribute__((aligned(16))) char smem[BM * 128 + 16384];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int MT = (g.M + BM - 1) / BM, NT = g.N >> 7;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, S = gridDim.x >> 3;
+  const int mq = MT >> 3, mr = MT & 7;
+  const int mcount = mq + (xcd < mr ? 1 : 0), mfirst = xcd * mq + (xcd < mr ? xcd : mr);
+  const int ntiles = mcount * NT;
+  if (slot >= ntiles) return;
+  const int cn = g.cn > 0 ? g.cn : NT, per_chunk = mcount * cn;
+  const int tiles_per_seg = g.kseg >> 6;
+  const int ldw = g.custom_w ? g.ldw_ : g.nseg * g.kseg;
+  const int prow = lane >> 3, pslot = lane & 7;
+  const int fr = lane & 15, fq = lane >> 4;
+  const bool resid_first = MODE == GEMM_OUT_F32 && g.resid != nullptr;
+  char *sa = smem, *sb = smem + BM * 128;
+  int aoff[MI], boff[4];
+  auto coords = [&](int idx, int &m0, int &n0) {
+    const int chunk = idx / per_chunk, rem = idx - chunk * per_chunk;
+    m0 = (mfirst + rem / cn) * BM;
+    n0 = (chunk * cn + rem % cn) << 7;
+  };
+  auto offsets = [&](int m0, int n0) {
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+      const int row = (wave * MI + i) * 8 + prow;
+      aoff[i] = min(m0 + row, g.M - 1) * g.lda + (pslot ^ ((row >> 1) & 7)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int row = (wave * 4 + i) * 8 + prow;
+      boff[i] = (n0 + row) * ldw + (pslot ^ ((row >> 1) & 7)) * 8;
+    }
+  };
+  auto issue = [&](const __half *abase, const __half *wbase) {
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+      __builtin_amdgcn_global_load_lds((gptr_t)(abase + aoff[i]), (lptr_t)(sa + (wave * MI + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wbase + boff[i]), (lptr_t)(sb + (wave * 4 + i) * 1024), 16, 0, 0);
+  };
+  const __half *aseg0 = g.A[0] + (ptrdiff_t)g.row_off[0] * g.lda;
+  const __half *wseg0 = g.W + (g.custom_w ? g.w_off_[0] : 0);
+  int idx = slot, m0, n0, it = 0;
+  (void)it; // (only the trace build reads it)
+  coords(idx, m0, n0);
+  offsets(m0, n0);
+  issue(aseg0, wseg0); // K tile 0 of the first output tile
+  for (;;) {
+    GEMM_TR_DECL;
+    GEMM_TR(0);
+    floatx4 acc[MI][4];
+    if (resid_first) gemm_acc_from_resid<MI>(g, acc, m0, n0, wm, wn, fr, fq);
+    else {
+#pragma unroll
+      for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool natural = (MODE == GEMM_OUT_QKV) && (((n0 + wn * 64) % 192) >= 128);
+    GEMM_TR(1);
+    auto kloop = [&](auto nat) {
+      constexpr bool NAT = decltype(nat)::value;
+      for (int seg = 0; seg < g.nseg; seg++) {
+        const __half *aseg = g.A[seg] + (ptrdiff_t)g.row_off[seg] * g.lda;
+        const __half *wseg = g.W + (g.custom_w ? g.w_off_[seg] : seg * g.kseg);
+        for (int kt = 0; kt < tiles_per_seg; kt++) {
+          if (seg | kt) issue(aseg + (kt << 6), wseg + (kt << 6)); // K tile 0 was requested at the previous tile boundary
+          __syncthreads();
+#ifdef TTS_GEMM_TRACE
+          if (seg == 0 && kt == 0) GEMM_TR(2);
+#endif
+#pragma unroll
+          for (int ks = 0; ks < 2; ks++) {
+            half8 af[MI], bf[4];
+#pragma unroll
+            for (int i = 0; i < MI; i++) af[i] = *(const half8 *)(sa + lds_off(wm * (16 * MI) + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < 4; i++) bf[i] = *(const half8 *)(sb + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                if (NAT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+              }
+          }
+          __syncthreads();
+        }
+      }
+    };
+    if (MODE == GEMM_OUT_QKV && natural) kloop(std::true_type{});
+    else kloop(std::false_type{});
+    GEMM_TR(3);
+    // tile boundary: every wave has left the last K tile (trailing barrier), the LDS stage is free
+    const int nidx = idx + S;
+    int m0n = 0, n0n = 0;
+    if (nidx < ntiles) {
+      coords(nidx, m0n, n0n);
+      offsets(m0n, n0n);
+      issue(aseg0, wseg0);
+    }
+    if (resid_first) gemm_epilogue<MODE, MI, true>(g, acc, m0, n0, wm, wn, fr, fq);
+    else gemm_epilogue<MODE, MI>(g, acc, m0, n0, wm, wn, fr, fq);
+    GEMM_TR(4);
+    GEMM_TR_FLUSH(blockIdx.x + gridDim.x * it);
+    if (nidx >= ntiles) break;
+    idx = nidx; m0 = m0n; n0 = n0n; it++;
+  }
 }
 
 // k = 3 convolution as ONE GEMM with a shared activation slab. The three taps are three row-shifted GEMM
@@ -281,6 +429,8 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_kernel(GemmArgs 
   const int chunk = idx / per_chunk, rem = idx - chunk * per_chunk;
   const int m0 = (mfirst + rem / cn) * BM, n0 = (chunk * cn + rem % cn) << 7;
   const int nchunks = g.kseg >> 6, ldw = 3 * g.kseg, nph = 3 * nchunks;
+  GEMM_TR_DECL;
+  GEMM_TR(0);
   const int prow = lane >> 3, pslot = lane & 7;
   const int fr = lane & 15, fq = lane >> 4;
   // (residual-first accumulators, as in gemm_f16_glds_kernel, were measured SLOWER here: 237-249 vs 216-225 us —
@@ -323,12 +473,16 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_kernel(GemmArgs 
   };
   stageA(0);
   stageB(0);
+  GEMM_TR(1);
   for (int kc = 0, p = 0; kc < nchunks; kc++) {
 #pragma unroll
     for (int tap = 0; tap < 3; tap++, p++) {
       stageB(p + 1); // its buffer was last read in phase p-1, which every wave has left (trailing barrier)
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // all but the 4 pieces just issued: B(p) and the slab have landed
       __builtin_amdgcn_s_barrier();
+#ifdef TTS_GEMM_TRACE
+      if (p == 0) GEMM_TR(2);
+#endif
       const char *sbp = sb + (p & 1) * 16384;
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
@@ -348,12 +502,28 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_kernel(GemmArgs 
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // trailing (clamped) pieces must land before the LDS is released
+  GEMM_TR(3);
+#ifdef TTS_GEMM_DIAG_NOEPI
+  if (g.ldo != -12345) { GEMM_TR(4); GEMM_TR_FLUSH(blockIdx.x); return; }
+#endif
   gemm_epilogue<MODE, MI>(g, acc, m0, n0, wm, wn, fr, fq);
+  GEMM_TR(4);
+#ifdef TTS_GEMM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GEMM_TR(5);
+#endif
+  GEMM_TR_FLUSH(blockIdx.x);
 }
 
 #ifdef TTS_GEMM_VARIANT // tools/gemm_bench.hip only (compiled with -I tools)
 #include "gemm_f16_experiments.h"
 #endif
+
+// A/B switch (TTS_GEMM_PERSIST=1, or set by tools/gemm_diag.hip): persistent tile loop for the non-conv3 launches
+static inline int &gemm_persist_flag() {
+  static int v = getenv("TTS_GEMM_PERSIST") ? atoi(getenv("TTS_GEMM_PERSIST")) : 0;
+  return v;
+}
 
 static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
   GemmArgs gg = g;
@@ -387,9 +557,26 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
   const bool conv3 = !no_conv3 && g.nseg == 3 && !g.custom_w && g.A[0] == g.A[1] && g.A[1] == g.A[2] && g.row_off[0] == -1 &&
                      g.row_off[1] == 0 && g.row_off[2] == 1 && g.mode != GEMM_OUT_QKV;
   static const bool qkv3 = getenv("TTS_GEMM_QKV3") != nullptr; // A/B switch: QKV projection at 3 workgroups per CU (138 VGPRs, no spills)
+  // A/B switch: persistent tile loop (gemm_f16_pers_kernel) for the non-conv3 launches
+  const int persist = gemm_persist_flag();
+  static int cus_per_xcd = 0;
+  if (persist && !cus_per_xcd) {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    cus_per_xcd = cus / 8 > 0 ? cus / 8 : 32;
+  }
 #define TTS_LAUNCH_MI(MI_)                                                                                              \
   do {                                                                                                                  \
-    if (conv3) {                                                                                                        \
+    if (persist && !conv3) {                                                                                            \
+      const int wgs = (g.mode == GEMM_OUT_QKV && qkv3) ? 3 : 4;                                                         \
+      const int per_xcd = ((MTt >> 3) + ((MTt & 7) ? 1 : 0)) * NTt;                                                     \
+      const int gridp = 8 * (per_xcd < cus_per_xcd * wgs ? per_xcd : cus_per_xcd * wgs);                                \
+      if (g.mode == GEMM_OUT_F32) gemm_f16_pers_kernel<GEMM_OUT_F32, MI_, 4><<<gridp, 256, 0, s>>>(gg);                  \
+      else if (g.mode == GEMM_OUT_F16) gemm_f16_pers_kernel<GEMM_OUT_F16, MI_, 4><<<gridp, 256, 0, s>>>(gg);             \
+      else if (qkv3) gemm_f16_pers_kernel<GEMM_OUT_QKV, MI_><<<gridp, 256, 0, s>>>(gg);                                  \
+      else gemm_f16_pers_kernel<GEMM_OUT_QKV, MI_, 4><<<gridp, 256, 0, s>>>(gg);                                         \
+    } else if (conv3) {                                                                                                        \
       static bool attr = false;                                                                                         \
       if (!attr) {                                                                                                      \
         (void)hipFuncSetAttribute((const void *)gemm_f16_conv3_kernel<GEMM_OUT_F32, MI_>, hipFuncAttributeMaxDynamicSharedMemorySize, conv3_lds<MI_>()); \
