@@ -3,18 +3,29 @@
 
 Metric (BASELINE.json): audio-seconds/sec end-to-end, 16 AR candidates x 80 diffusion steps per GPU.
 One "step" = one full pass over one batch: tts_autoregressive (prefill + 192 sampled codes + latent pass)
--> tts_diffusion (80 steps, cond+uncond) -> tts_vocoder for 16 candidates, weights resident in HBM,
+-> tts_diffusion (80 steps, cond+uncond) -> tts_vocoder for every candidate, weights resident in HBM,
 synthetic 64-token prompt, stock mol.bin voice, full-size synthetic weights in the reference file format
-(the trained weights are not available offline).  N>1: one process per GPU (torchrun), every rank runs
-its own 16 candidates (weak scaling); RCCL broadcasts the prompt/voice and gathers the audio on rank 0.
+(the trained weights are not available offline).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the fp16 MFMA GEMM of the diffusion
-stage, timed with HIP events on the engine's stream inside the timed region) and `cpu_baseline`
-(the oracle = CPU restatement of the reference path, timed on a bounded sample and extrapolated).
+Workloads (--config, SURVEY 8d numbering; the name in BASELINE.json is given in the JSON line):
+  3 (default) = BASELINE configs[2]: 16 candidates per GPU, 80 steps; N > 1: every rank its own 16 (weak scaling)
+  4           = BASELINE configs[3]: ONE batch of 64 candidates sharded 64/N per GPU, 80 steps (strong scaling); the RNG stream
+                partition (options rng_shard_offset / rng_shard_total) makes N x 64/N reproduce the ids of 1 x 64
+  5           = BASELINE configs[4]: 8 distinct prompts x 16 candidates, 200 diffusion steps, prompts dealt round-robin to ranks
+                (strong scaling)
+Multi-GPU: one process per GPU. `python bench.py --gpus N` launches itself under torch.distributed.run when it is not already
+running under it (WORLD_SIZE unset); RCCL (backend "nccl") broadcasts the prompt ids / voice latent from rank 0 and gathers
+the audio on rank 0. No collective sits inside the data path: candidates never interact.
+
+Prints ONE JSON line (rank 0): `roofline` = the dominant kernel family (fp16 MFMA GEMMs of the diffusion stage, HIP-event timed on the
+engine's stream inside the timed region), `roofline_decode` = the HBM-bound decode step (one event pair per hipGraph replay),
+`cpu_baseline` = the oracle (CPU restatement of the reference path) on a bounded sample at 4 threads and at all host cores.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,11 +36,13 @@ sys.path.insert(0, ROOT)
 import tortoise_cpp_amd_loader  # noqa: E402
 
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
+HBM_PEAK_GBS = 8000.0                # same guide: 8 TB/s spec (6.29 TB/s measured copy)
 
 
-def synthetic_prompt():
-    # ids 255, (3 + 7j mod 250) for j < 64, 0  -> n = 66 text ids, P = 68 prompt positions
-    return np.array([255] + [3 + (7 * j) % 250 for j in range(64)] + [0], np.int32)
+def synthetic_prompt(p=0):
+    # ids 255, (3 + 7j mod 250) for j < 64, 0  -> n = 66 text ids, P = 68 prompt positions; p > 0: the distinct
+    # prompts of config 5 (same length, shifted ids)
+    return np.array([255] + [3 + (7 * j + 11 * p) % 250 for j in range(64)] + [0], np.int32)
 
 
 def ensure_models(path, quick, rank_is_writer):
@@ -43,17 +56,24 @@ def ensure_models(path, quick, rank_is_writer):
         open(stamp, "w").write("ok")
 
 
-def cpu_baseline(model_dir, voice, toks, S, L_bench, n_diff_steps, quick):
-    """Oracle (CPU restatement) on a bounded sample of the same workload, extrapolated with the
+def _omp_set_threads(n):
+    import ctypes
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+        return True
+    except OSError:
+        return False
+
+
+def cpu_baseline_once(model_dir, voice, toks, S, L_bench, n_diff_steps, quick, threads):
+    """Oracle (CPU restatement) on a bounded sample of the same workload at `threads` OpenMP threads, extrapolated with the
     algorithmic-work formulae of SURVEY §8d to one candidate of the bench workload."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    cores = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    _omp_set_threads(threads)
     n = len(toks)
     t_all = time.time()
-    # --- AR: prefill + a few decode steps at B=1
     ar = O.AR(O.Model(os.path.join(model_dir, "ggml-model.bin")))
-    nstep = 48 if not quick else 4
+    nstep = 24 if not quick else 4
     ar.start(toks, voice, 1, n + 2 + nstep + 1)
     t0 = time.time(); ar.prefill(); t_prefill = time.time() - t0
     t0 = time.time()
@@ -63,38 +83,62 @@ def cpu_baseline(model_dir, voice, toks, S, L_bench, n_diff_steps, quick):
     row_s = t_prefill / (n + 2)                                   # seconds per transformer row (dense part)
     t_ar = t_prefill + S * t_step + (n + 1 + L_bench) * row_s     # + latent pass over the needed prefix
     del ar
-    # --- diffusion: conditioner + one cond and one uncond forward at the bench's own size (L=200, T=870): only the
-    # number of repetitions (80 steps) is extrapolated
+    # diffusion: conditioner + cond and uncond forward at the bench's own size (L=200, T=870): only the number of repetitions
+    # (diffusion steps) is extrapolated
     od = O.Diffusion(O.Model(os.path.join(model_dir, "ggml-diffusion-model.bin")))
     Ls = L_bench if not quick else 12
     Ts = od.T_of(Ls)
     lat = np.random.RandomState(0).randn(Ls, 1024).astype(np.float32)
     x = np.random.RandomState(1).randn(100, Ts).astype(np.float32)
     t0 = time.time(); ce = od.code_embedding(lat, Ts); t_cond = time.time() - t0
-    npair = 3 if not quick else 1                                 # cond + uncond forward at three timesteps
+    npair = 2 if not quick else 1
     t0 = time.time()
-    for ts in (3999, 2025, 51)[:npair]:
+    for ts in (3999, 51)[:npair]:
         od.forward(ce, x, ts); od.forward(None, x, ts)
     t_pair = (time.time() - t0) / npair
     fl = lambda T: 249307136.0 * T + 53248.0 * T * T              # per forward
     Tb = od.T_of(L_bench)
     t_diff = t_cond + n_diff_steps * t_pair * fl(Tb) / fl(Ts)     # conditioner once per utterance
     del od
-    # --- vocoder at the same T
     ov = O.Vocoder(O.Model(os.path.join(model_dir, "ggml-vocoder-model.bin")))
     mel = np.clip(np.random.RandomState(2).randn(100, Ts) * 0.5, -1, 1).astype(np.float32)
     t0 = time.time(); ov.run(mel, rng=O.Rng(0)); t_voc_s = time.time() - t0
     t_voc = t_voc_s * (Tb + 10) / (Ts + 10)
-    audio_s = ((Tb + 10) * 256 - 6) / 24000.0
+    audio_s = Tb * 256 / 24000.0                                  # the 10 silent pad frames are not counted
+    return {"value": round(audio_s / (t_ar + t_diff + t_voc), 5), "threads": threads,
+            "measured_s": {"prefill_P%d" % (n + 2): round(t_prefill, 3), "decode_step": round(t_step, 4), "diffusion_pair_T%d" % Ts: round(t_pair, 3),
+                           "conditioner": round(t_cond, 3), "vocoder_T%d" % Ts: round(t_voc_s, 3), "sample_total": round(time.time() - t_all, 1)},
+            "extrapolated_s_per_candidate": {"ar": round(t_ar, 1), "diffusion": round(t_diff, 1), "vocoder": round(t_voc, 2)}, "audio_s": round(audio_s, 3)}
+
+
+def cpu_baseline(model_dir, voice, toks, S, L_bench, n_diff_steps, quick):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    nproc = os.cpu_count() or 1
+    runs = [cpu_baseline_once(model_dir, voice, toks, S, L_bench, n_diff_steps, quick, th) for th in sorted({min(4, nproc), nproc})]
+    best = max(runs, key=lambda r: r["value"])
     return {
-        "value": round(audio_s / (t_ar + t_diff + t_voc), 5), "unit": "audio-seconds/sec", "cores": cores, "kind": "port",
-        "sample": "oracle (f32 C++/OpenMP restatement of the ggml graphs; the reference itself cannot be built: ggml "
-                  "submodule absent). Measured B=1: prefill(P=%d) %.2fs, %d decode steps %.3fs/step, diffusion cond+uncond "
-                  "forward pair (mean of %d timesteps) at L=%d/T=%d %.2fs, vocoder T=%d %.2fs (%.0fs total); extrapolated per candidate to S=%d steps, L=%d/T=%d, "
-                  "%d diffusion steps (repetition counts; SURVEY 8d work formulae where a sample is smaller than the workload): AR %.1fs + diffusion %.1fs + vocoder %.1fs for %.2fs of audio"
-                  % (n + 2, t_prefill, nstep, t_step, npair, Ls, Ts, t_pair, Ts, t_voc_s, time.time() - t_all, S, L_bench, Tb, n_diff_steps,
-                     t_ar, t_diff, t_voc, audio_s),
+        "value": best["value"], "unit": "audio-seconds/sec", "cores": best["threads"], "kind": "port", "host_nproc": nproc,
+        "runs": runs,
+        "sample": "oracle (f32 C++/OpenMP restatement of the ggml graphs; the reference itself cannot be built: ggml submodule absent), "
+                  "B=1, at 4 OpenMP threads (ggml's default, what ./tortoise would use) and at all %d host cores; `value`/`cores` = the "
+                  "faster of the two. Measured per run: prompt pass, 24 decode steps, latent conditioner + two cond+uncond forward pairs at "
+                  "the workload's own L=%d/T, the vocoder at the same T; extrapolated by repetition counts only (S=%d decode steps, %d "
+                  "diffusion steps) to one candidate. Audio seconds = T*256/24000 (SURVEY 8d)" % (nproc, L_bench, S, n_diff_steps),
     }
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` outside torchrun: re-exec under torch.distributed.run, one rank per GPU (RCCL over xGMI)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: required for RCCL on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -102,144 +146,244 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--candidates", type=int, default=16, help="AR candidates per GPU")
-    ap.add_argument("--diff-steps", type=int, default=80)
+    ap.add_argument("--config", type=int, default=3, choices=[3, 4, 5], help="workload, SURVEY 8d numbering (3 = BASELINE configs[2], the metric's)")
+    ap.add_argument("--candidates", type=int, default=None, help="AR candidates per GPU (config 3) / in total (config 4) / per prompt (config 5)")
+    ap.add_argument("--diff-steps", type=int, default=None)
     ap.add_argument("--decode-steps", type=int, default=192, help="sampled codes per candidate (stop token masked) -> L=200, T=870")
     ap.add_argument("--quick", action="store_true", help="tiny layer counts (plumbing check only; NOT the benchmark)")
     ap.add_argument("--prof-stride", type=int, default=13, help="every Nth GEMM launch is bracketed by a HIP event pair (roofline timing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-share-uncond", action="store_true", help="evaluate the unconditioned integrator layers once per candidate")
+    ap.add_argument("--no-share-uncond", action="store_true", help="headline pass with the unconditioned integrator layers evaluated per candidate")
+    ap.add_argument("--no-ab", action="store_true", help="skip the extra pass that measures the other share_uncond setting")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU plumbing test with --dry-engine)")
+    ap.add_argument("--dry-engine", action="store_true", help="no device work: host-only contexts, fake stage outputs (tests of the launch / collective plumbing)")
     ap.add_argument("--models", default=None)
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     dist = None
+    dev = None
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
-    assert a.gpus == world, "--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (a.gpus, world)
+        if a.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dev = torch.device("cuda", local_rank)
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dev = torch.device("cpu")
+            dist.init_process_group(a.backend)
+
+    # ---- workload ---------------------------------------------------------------------------------------------------
+    n_diff = a.diff_steps or (200 if a.config == 5 else 80)
+    if a.config == 3:
+        B = a.candidates or 16                      # per GPU
+        my_prompts, cand0, cand_total, scaling = [0], 0, 0, "weak"
+        name = "configs[2]"
+    elif a.config == 4:
+        total = a.candidates or 64
+        if total % world:
+            sys.exit("config 4: %d candidates do not divide over %d GPUs" % (total, world))
+        B = total // world
+        my_prompts, cand0, cand_total, scaling = [0], rank * B, total, "strong"
+        name = "configs[3]"
+    else:
+        B = a.candidates or 16
+        my_prompts, cand0, cand_total, scaling = [p for p in range(8) if p % world == rank], 0, 0, "strong"
+        name = "configs[4]"
 
     pkg = tortoise_cpp_amd_loader.load()
     model_dir = a.models or ("/tmp/tts_bench_models_quick" if a.quick else "/tmp/tts_bench_models")
-    ensure_models(model_dir, a.quick, local_rank == 0)
+    if not a.dry_engine:
+        ensure_models(model_dir, a.quick, local_rank == 0)
     if dist:
         dist.barrier()
 
-    eng = pkg.Engine(local_rank)  # raises without the HIP library/device: there is no fallback path
-    if world > 1:  # N processes share the host: leave each rank's sampler pool its share of the cores
-        eng.set_option("sampler_threads", max(0, min(7, (os.cpu_count() or 8) // world - 2)))
-    eng.load(model_dir)
-    if a.no_share_uncond:
-        eng.set_option("share_uncond", 0)
-    B, S = a.candidates, a.decode_steps
-    toks = synthetic_prompt()
+    S = a.decode_steps
     voice = np.fromfile(os.path.join(ROOT, "models", "mol.bin"), np.float32)
-    if dist:  # prompt + conditioning come from rank 0 (RCCL broadcast), results are gathered on rank 0
+    prompts = {p: synthetic_prompt(p) for p in range(8)}
+    if dist:  # prompt ids + conditioning come from rank 0 (broadcast), results are gathered on rank 0
         import torch
-        tt = torch.from_numpy(toks.copy()).cuda()
-        tv = torch.from_numpy(voice.copy()).cuda()
+        tt = torch.from_numpy(np.stack([prompts[p] for p in range(8)])).to(dev)
+        tv = torch.from_numpy(voice.copy()).to(dev)
+        if rank != 0:
+            tt.zero_(); tv.zero_()
         dist.broadcast(tt, 0)
         dist.broadcast(tv, 0)
-        toks, voice = tt.cpu().numpy(), tv.cpu().numpy()
+        voice = tv.cpu().numpy()
+        prompts = {p: tt[p].cpu().numpy() for p in range(8)}
+
+    if a.dry_engine:
+        eng = pkg.Engine.__new__(pkg.Engine)
+        eng.L = pkg.lib()
+        eng.h = eng.L.tts_create(-1)
+    else:
+        eng = pkg.Engine(local_rank)  # raises without the HIP library/device: there is no fallback path
+        if world > 1:  # N processes share the host: leave each rank's sampler pool its share of the cores
+            eng.set_option("sampler_threads", max(0, min(7, (os.cpu_count() or 8) // world - 2)))
+        eng.load(model_dir)
+    if cand_total:
+        eng.set_option("rng_shard_offset", cand0)
+        eng.set_option("rng_shard_total", cand_total)
 
     stage_ms = {"ar": 0.0, "diffusion": 0.0, "vocoder": 0.0}
+    shape = {}
 
-    def one_pass(it):
-        eng.seed(1000 * it + rank)  # distinct candidates per rank and per pass
-        t_a = time.time()
-        codes, rows, lats, steps = eng.autoregressive(toks, voice, B, S, mask_stop=True)
-        t_b = time.time()
-        mels = eng.diffusion(lats, n_steps=a.diff_steps, noise_mode=pkg.NOISE_DEVICE)
-        t_c = time.time()
-        audio = eng.vocoder(mels, noise_mode=pkg.NOISE_DEVICE)
-        t_d = time.time()
-        if it >= 0:
-            stage_ms["ar"] += 1e3 * (t_b - t_a); stage_ms["diffusion"] += 1e3 * (t_c - t_b); stage_ms["vocoder"] += 1e3 * (t_d - t_c)
+    def one_pass(it, record=True):
+        audio_s, n_audio = 0.0, 0
+        chunks = []
+        for p in my_prompts:
+            # config 3: distinct candidates per rank and per pass; configs 4/5: one seed for the whole (sharded) batch
+            eng.seed(1000 * it + (rank if a.config == 3 else 17 * p))
+            if a.dry_engine:  # plumbing only: the host sampler on fixed logits stands in for the three stages
+                logits = np.random.RandomState(7).randn(B, 8194).astype(np.float32) * 3
+                ids = eng.sample(logits, np.tile(np.array([1] * 17 + [8192], np.int32), (B, 1)))
+                audio = [np.full(100 + int(i) % 7, float(i), np.float32) for i in ids]
+                rows, Ts = np.full(B, 200), [870] * B
+                shape.update(L=200, T=870, ids=[int(i) for i in ids])
+                print("DRY_IDS rank %d prompt %d pass %d: %s" % (rank, p, it, " ".join(str(int(i)) for i in ids)), file=sys.stderr)
+            else:
+                t_a = time.time()
+                codes, rows, lats, steps = eng.autoregressive(prompts[p], voice, B, S, mask_stop=True)
+                t_b = time.time()
+                mels = eng.diffusion(lats, n_steps=n_diff, noise_mode=pkg.NOISE_DEVICE)
+                t_c = time.time()
+                audio = eng.vocoder(mels, noise_mode=pkg.NOISE_DEVICE)
+                t_d = time.time()
+                if record:
+                    stage_ms["ar"] += 1e3 * (t_b - t_a); stage_ms["diffusion"] += 1e3 * (t_c - t_b); stage_ms["vocoder"] += 1e3 * (t_d - t_c)
+                Ts = [m.shape[1] for m in mels]
+                shape.update(L=int(rows[0]), T=int(Ts[0]))
+            audio_s += sum(t * 256 for t in Ts) / 24000.0  # T*256/24000 per candidate (the 10 pad frames are not counted)
+            n_audio += sum(len(x) for x in audio)
+            chunks += audio
         if dist:
             import torch
-            flat = torch.from_numpy(np.concatenate(audio)).cuda()
-            sizes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
-            dist.all_gather(sizes, torch.tensor([flat.numel()], dtype=torch.int64, device="cuda"))
+            flat = torch.from_numpy(np.concatenate(chunks) if chunks else np.zeros(0, np.float32)).to(dev)
+            sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(sizes, torch.tensor([flat.numel()], dtype=torch.int64, device=dev))
             mx = int(max(s.item() for s in sizes))
-            pad = torch.zeros(mx, device="cuda")
+            pad = torch.zeros(mx, device=dev)
             pad[:flat.numel()] = flat
-            outs = [torch.zeros(mx, device="cuda") for _ in range(world)] if rank == 0 else None
+            outs = [torch.zeros(mx, device=dev) for _ in range(world)] if rank == 0 else None
             dist.gather(pad, outs, dst=0)
-        return sum(len(x) for x in audio) / 24000.0, rows, [m.shape[1] for m in mels]
+            if rank == 0:
+                shape["gathered_samples"] = int(sum(int(s.item()) for s in sizes))
+        return audio_s, n_audio
 
     def sync():
         if dist:
-            import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if a.backend == "nccl":
+                import torch
+                torch.cuda.synchronize()
         # every engine call is synchronous (ends with hipStreamSynchronize on its stream)
 
+    def timed(steps, share):
+        if not a.dry_engine:
+            eng.set_option("share_uncond", 1 if share else 0)
+        for k in stage_ms:
+            stage_ms[k] = 0.0
+        sync()
+        t0 = time.time()
+        audio_s = 0.0
+        for k in range(steps):
+            audio_s += one_pass(k)[0]
+        sync()
+        dt = time.time() - t0
+        if dist:
+            import torch
+            t = torch.tensor([dt, 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0].item())
+            s = torch.tensor([audio_s], dtype=torch.float64, device=dev)
+            dist.all_reduce(s, op=dist.ReduceOp.SUM)
+            audio_s = float(s.item())
+        return audio_s, dt, {k: round(v / steps, 1) for k, v in stage_ms.items()}
+
+    share = not a.no_share_uncond
     for w in range(a.warmup):
-        one_pass(-1 - w)
-    eng.set_option("prof_only:diff_gemm", 1)
-    # every 13th GEMM launch is bracketed by a HIP event pair (60 launches per diffusion step, 13 is coprime: every launch
-    # position is sampled equally often over the 80 steps). An event pair drains the pipeline around its launch: bracketing
-    # all ~9 600 launches of the timed region cost 5 % of the pass, every 7th 0.5 %, every 29th nothing measurable.
-    eng.set_option("prof_stride", a.prof_stride)
-    eng.prof_reset(True)
-    sync()
-    t0 = time.time()
-    audio_s = 0.0
-    for k in range(a.steps):
-        s, rows, Ts = one_pass(k)
-        audio_s += s
-    sync()
-    dt = time.time() - t0
-    g_ms, g_n, g_flops = eng.prof_get("diff_gemm")
-    eng.prof_reset(False)
-    if dist:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        s = torch.tensor([audio_s], dtype=torch.float64, device="cuda")
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        audio_s = float(s.item())
+        one_pass(-1 - w, record=False)
+    if not a.dry_engine:
+        # every 13th GEMM launch is bracketed by a HIP event pair (60 launches per diffusion step, 13 is coprime: every launch position is
+        # sampled equally often). An event pair drains the pipeline around its launch: bracketing all ~9 600 launches of the timed region
+        # cost 5 % of the pass, every 7th 0.5 %, every 29th nothing measurable. The decode step is ONE hipGraph replay per event pair.
+        eng.set_option("prof_only:diff_gemm", 1)
+        eng.set_option("prof_only:ar_decode_step", 1)
+        eng.set_option("prof_stride", a.prof_stride)
+        eng.prof_reset(True)
+    audio_s, dt, stages = timed(a.steps, share)
+    g_ms = g_n = g_flops = d_ms = d_n = d_bytes = 0.0
+    if not a.dry_engine:
+        g_ms, g_n, g_flops = eng.prof_get("diff_gemm")
+        d_ms, d_n, d_bytes = eng.prof_get("ar_decode_step")
+        eng.prof_reset(False)
+    # the other share_uncond setting, one pass, outside the timed region (both numbers belong in the line: the sharing only exists
+    # because the masked stop token gives every candidate the same length)
+    other = None
+    if not a.no_ab and not a.dry_engine:
+        o_audio, o_dt, o_stages = timed(1, not share)
+        other = {"uncond_integrator_shared": not share, "value": round(o_audio / o_dt, 3), "ms_per_step": round(1000.0 * o_dt, 2),
+                 "stage_ms_per_step": o_stages}
     if rank != 0:
         if dist:
             dist.destroy_process_group()
         return
     achieved = g_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
-    # HBM bytes per GEMM launch from the committed PMC profile (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes,
-    # calibration in the file's note); null when the profile is absent. bench.py does not run rocprofv3 itself.
-    traffic = None
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm_traffic.json")))["kernels"]
-        gk = [v for k, v in prof.items() if "gemm_f16" in k]
-        traffic = int(sum(v["dispatches"] * v["hbm_bytes_per_launch"] for v in gk) / max(1, sum(v["dispatches"] for v in gk)))
-    except Exception:
-        pass
+    dec_gbs = d_bytes / (d_ms * 1e-3) / 1e9 if d_ms > 0 else 0.0
+    # HBM bytes per GEMM launch from the committed PMC profile (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, calibration in the
+    # file's note); null when the profile is absent. bench.py does not run rocprofv3 itself.
+    traffic, traffic_src = None, None
+    for prof_name in ("r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))["kernels"]
+            gk = [v for k, v in prof.items() if "gemm_f16" in k]
+            traffic = int(sum(v["dispatches"] * v["hbm_bytes_per_launch"] for v in gk) / max(1, sum(v["dispatches"] for v in gk)))
+            traffic_src = "profiles/" + prof_name
+            break
+        except Exception:
+            pass
+    L, T = shape.get("L", 0), shape.get("T", 0)
+    n_prompts = len(my_prompts) if a.config != 5 else 8
     out = {
         "metric": "audio-seconds/sec end-to-end (AR+diffusion+vocoder), 16 cands x 80 steps",
         "value": round(audio_s / dt, 3), "unit": "audio-seconds/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(1000.0 * dt / a.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(1000.0 * dt / a.steps, 2), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "f16 MFMA inputs / f32 accumulate (diffusion, vocoder convs); f32 weights, f16 KV (AR)", "data": "synthetic",
-        "config": {"workload": "configs[2]: synthetic 64-token prompt (n=66), mol.bin voice, %d AR candidates/GPU x %d sampled codes "
-                               "(L=%d latent rows, T=%d mel frames, %.2f s audio each), %d diffusion steps (cond+uncond batched), "
-                               "UnivNet vocoder; full-size synthetic weights%s" % (B, S, int(rows[0]), int(Ts[0]),
-                                                                                  ((Ts[0] + 10) * 256 - 6) / 24000.0, a.diff_steps,
-                                                                                  " [QUICK: reduced layer counts]" if a.quick else ""),
-                   "candidates_per_gpu": B, "diffusion_steps": a.diff_steps, "decode_steps": S, "parallelism": "candidate-parallel x%d" % world,
+        "config": {"workload": "%s: synthetic 64-token prompt%s (n=66), mol.bin voice, %d AR candidates %s x %d sampled codes (stop token masked: "
+                               "L=%d latent rows, T=%d mel frames), %d diffusion steps (cond+uncond batched), UnivNet vocoder; full-size synthetic "
+                               "weights%s" % (name, "s (8 distinct)" if a.config == 5 else "", B if a.config != 4 else cand_total,
+                                              {3: "per GPU", 4: "in one batch sharded over the GPUs", 5: "per prompt"}[a.config], S, L, T, n_diff,
+                                              " [QUICK: reduced layer counts]" if a.quick else ""),
+                   "candidates_per_gpu": B * (len(my_prompts) if a.config == 5 else 1), "prompts": n_prompts, "diffusion_steps": n_diff, "decode_steps": S,
+                   "parallelism": "candidate-parallel x%d (one process per GPU, replicated weights, RCCL broadcast of prompt/voice + gather of audio)" % world,
                    # the unconditioned branch's integrator layers (input independent of the candidate) are evaluated once per distinct
                    # sequence length; with the stop token masked all candidates have one length (option share_uncond)
-                   "uncond_integrator_shared": not a.no_share_uncond},
-        "stage_ms_per_step": {k: round(v / a.steps, 1) for k, v in stage_ms.items()},
-        "roofline": {"kernel": "gemm_f16_glds_kernel + gemm_f16_conv3_kernel (diffusion convs/projections)", "bound": "mfma", "achieved": round(achieved, 1),
-                     "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
-                     "traffic": traffic, "launches_timed": int(g_n), "launch_sampling": "every %dth launch of the family is bracketed by HIP events" % a.prof_stride, "avg_launch_us": round(1000.0 * g_ms / max(g_n, 1), 2),
-                     "algorithmic_gflop_per_launch": round(g_flops / max(g_n, 1) / 1e9, 2)},
+                   "uncond_integrator_shared": share,
+                   "audio_seconds": "T*256/24000 per candidate = %.3f s (SURVEY 8d; the vocoder also emits 10 silent pad frames: %.3f s of samples)"
+                                    % (T * 256 / 24000.0, ((T + 10) * 256 - 6) / 24000.0)},
+        "stage_ms_per_step": stages,
+        "other_share_uncond_setting": other,
+        "roofline": {"kernel": "gemm_f16_glds_kernel / gemm_f16_pers_kernel + gemm_f16_conv3_kernel (diffusion convs/projections)", "bound": "mfma",
+                     "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
+                     "traffic": traffic, "traffic_source": traffic_src, "launches_timed": int(g_n),
+                     "launch_sampling": "every %dth launch of the family is bracketed by HIP events" % a.prof_stride,
+                     "avg_launch_us": round(1000.0 * g_ms / max(g_n, 1), 2), "algorithmic_gflop_per_launch": round(g_flops / max(g_n, 1) / 1e9, 2)},
+        "roofline_decode": {"kernel": "AR decode step (one hipGraph replay: 151 kernels streaming every weight once)", "bound": "hbm",
+                            "achieved": round(dec_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dec_gbs / HBM_PEAK_GBS, 4),
+                            "traffic": None, "steps_timed": int(d_n), "avg_step_us": round(1000.0 * d_ms / max(d_n, 1), 1),
+                            "algorithmic_mb_per_step": round(d_bytes / max(d_n, 1) / 1e6, 1)},
     }
-    if world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(model_dir, voice, toks, S, int(rows[0]), a.diff_steps, a.quick)
+    if a.dry_engine:
+        out["dry_engine"] = {"ids": shape.get("ids"), "gathered_samples": shape.get("gathered_samples")}
+    if world == 1 and not a.no_cpu_baseline and not a.dry_engine:
+        out["cpu_baseline"] = cpu_baseline(model_dir, voice, prompts[0], S, L, n_diff, a.quick)
     print(json.dumps(out))
     if dist:
         dist.destroy_process_group()

@@ -49,7 +49,7 @@ void tts_destroy(tts_ctx *ctx);
 const char *tts_last_error(const tts_ctx *ctx);
 /* Options (all have reference defaults): "gn_eps" (1e-6; ggml's GroupNorm epsilon),
  * "ggml_lut" (0/1: emulate ggml-CPU fp16 lookup tables for GELU/SiLU),
- * "prof_only:<family>" (1: restrict profiling to one kernel family, 0: all),
+ * "prof_only:<family>" (1: add the family to the list of profiled families, 0: clear the list = all families),
  * "prof_stride" (1 default: every launch of a profiled family is bracketed by an event pair; N: every Nth launch —
  * an event pair drains the pipeline around the launch, so bracketing all 9 600 GEMM launches of a pass costs ~5 %),
  * "sampler_threads" (-1 default = min(7, hardware threads - 1); 0 = sample on the calling thread; the token ids
@@ -174,7 +174,8 @@ int tts_host_trimmed_rows(const int32_t *codes502);
 /* ---- measurement hooks (bench.py; not part of the reference seam) -------------------------- */
 /* Accumulated device time (ms; HIP event pairs recorded on the ctx stream around every launch, resolved
  * lazily so the timed region is not synchronised) and launch count of the named kernel family since the
- * last reset: "ar_gemv", "ar_attention", "diff_gemm", "diff_attn", "diff_gn_apply", "voc_lvc", ... */
+ * last reset: "ar_gemv", "ar_attention", "ar_decode_step" (one whole decode-step graph replay; work = bytes streamed), "diff_gemm",
+ * "diff_attn", "diff_gn_apply", "voc_lvc", ... */
 int tts_prof_reset(tts_ctx *ctx, int enable);
 /* work_out: summed algorithmic work of those launches — FLOPs for the MFMA-bound families (diff_gemm,
  * diff_attn, voc_kernel_gemm), bytes for the HBM-bound ones (ar_gemv: weight bytes streamed). */

@@ -9,7 +9,8 @@ import os
 import subprocess
 import numpy as np
 
-# the oracle's loops are small; a 256-thread OpenMP team on the GPU box's host is slower than 16
+# Default team size for the TESTS only (the oracle's loops are small; a 256-thread OpenMP team on the GPU box's host is slower than 16).
+# bench.py's cpu_baseline does not rely on this: it sets the team size explicitly (4 threads and all host cores) and reports both.
 os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
 
 HERE = os.path.dirname(os.path.abspath(__file__))

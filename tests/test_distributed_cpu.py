@@ -7,12 +7,14 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = r'''
 import os, sys
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 sys.path.insert(0, %(root)r)
@@ -70,3 +72,83 @@ def test_two_rank_gloo_sharding(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "DIST_OK" in r.stdout
+
+
+def _host_engine(pkg):
+    eng = pkg.Engine.__new__(pkg.Engine)
+    eng.L = pkg.lib()
+    eng.h = eng.L.tts_create(-1)
+    return eng
+
+
+def test_rng_stream_partition_reproduces_unsharded_ids(pkg):
+    """the used uniform of (step s, candidate c) is output 2 (s B + c) + 1 of the one mt19937 stream. With the options
+    rng_shard_offset / rng_shard_total a rank that holds candidates [c0, c0 + b) skips the other ranks' draws, so G ranks x B/G
+    candidates sample exactly the ids one rank x B samples — for every split, step after step."""
+    B, steps = 12, 7
+    rs = np.random.RandomState(3)
+    logits = [rs.randn(B, 8194).astype(np.float32) * 3 for _ in range(steps)]
+    prev = rs.randint(0, 8192, (B, 1)).astype(np.int32)
+    ref = _host_engine(pkg)
+    ref.seed(99)
+    want = np.stack([ref.sample(lg, prev) for lg in logits])
+    tail = ref.rng_uniform()
+    for G in (2, 3, 4, 12):
+        b = B // G
+        got = np.zeros_like(want)
+        for r in range(G):
+            e = _host_engine(pkg)
+            e.set_option("rng_shard_offset", r * b)
+            e.set_option("rng_shard_total", B)
+            e.seed(99)
+            for s in range(steps):
+                got[s, r * b:(r + 1) * b] = e.sample(logits[s][r * b:(r + 1) * b], prev[r * b:(r + 1) * b])
+            assert e.rng_uniform() == tail  # every rank leaves the stream where the unsharded run leaves it
+            e.close()
+        assert (got == want).all(), G
+    # a shard that does not fit its batch is an argument error, not a silent mis-draw
+    e = _host_engine(pkg)
+    e.set_option("rng_shard_offset", 8)
+    e.set_option("rng_shard_total", 10)
+    with pytest.raises(pkg.TtsError):
+        e.sample(logits[0][:4], prev[:4])
+    e.close()
+    ref.close()
+
+
+def test_bench_self_launches_its_ranks(pkg):
+    """`python bench.py --gpus 2` (no torchrun around it) spawns its own two ranks, runs the broadcast / per-rank work / audio gather /
+    max-over-ranks timing and prints ONE JSON line with n_gpus = 2. Device work is replaced by the host sampler (--dry-engine,
+    gloo): config 4 shards ONE batch of 6 candidates 3 + 3 with the RNG stream partition, and the two ranks' ids must be the ids an
+    unsharded context samples."""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "4", "--candidates", "6", "--backend", "gloo",
+           "--dry-engine", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    import json
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["workload"].startswith("configs[3]")
+    ids = {}
+    for l in r.stderr.splitlines():
+        if "DRY_IDS rank" in l and "pass 0" in l:
+            ids[int(l.split("rank ")[1].split()[0])] = [int(x) for x in l.split(": ")[1].split()]
+    assert sorted(ids) == [0, 1] and len(ids[0]) == len(ids[1]) == 3
+    ref = _host_engine(pkg)
+    ref.seed(0)  # bench.py: seed 1000 * pass + 17 * prompt
+    logits = np.random.RandomState(7).randn(6, 8194).astype(np.float32) * 3
+    want = ref.sample(logits, np.tile(np.array([1] * 17 + [8192], np.int32), (6, 1)))
+    ref.close()
+    # every rank draws on the same 3 rows of logits (its own slice of the fake stage is rows 0..2): compare with those rows
+    want0 = _host_engine(pkg); want0.seed(0)
+    lg3 = logits[:3]
+    e0 = _host_engine(pkg); e0.set_option("rng_shard_total", 6); e0.seed(0)
+    e1 = _host_engine(pkg); e1.set_option("rng_shard_offset", 3); e1.set_option("rng_shard_total", 6); e1.seed(0)
+    pen = np.tile(np.array([1] * 17 + [8192], np.int32), (3, 1))
+    assert ids[0] == e0.sample(lg3, pen).tolist() and ids[1] == e1.sample(lg3, pen).tolist()
+    for e in (want0, e0, e1):
+        e.close()
+    assert out["dry_engine"]["gathered_samples"] > 0

@@ -95,7 +95,10 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
   std::string k(key);
   if (k == "gn_eps") c->gn_eps = (float)value;
   else if (k == "ggml_lut") c->ggml_lut = value != 0;
-  else if (k.rfind("prof_only:", 0) == 0) c->prof_filter = value != 0 ? k.substr(10) : std::string();
+  else if (k.rfind("prof_only:", 0) == 0) { // value 1: add the family to the list of profiled families; 0: back to "all"
+    if (value != 0) c->prof_filter.push_back(k.substr(10));
+    else c->prof_filter.clear();
+  }
   else if (k == "sampler_threads") { // worker threads for the per-candidate sampler scans (0 = run them on the caller)
     if (c->sampler_pool) { sampler_pool_free(c->sampler_pool); c->sampler_pool = nullptr; }
     c->sampler_threads = value < 0 ? -1 : (int)value;

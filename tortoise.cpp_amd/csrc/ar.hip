@@ -1334,7 +1334,9 @@ int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out
   st->h_toks[st->B + 1] = step_i + 2; // mel position id (main.cpp:5244)
   static const bool no_graph = getenv("TTS_NO_GRAPH") != nullptr; // e.g. under rocprofv3, which crashes on graph replays here
   // event records are not captured: the step runs eagerly while one of its own kernel families ("ar_*") is profiled
-  const bool prof_ar = ctx->prof_on && (ctx->prof_filter.empty() || ctx->prof_filter.rfind("ar_", 0) == 0);
+  // ("ar_decode_step" brackets the whole graph replay and keeps the graph)
+  bool prof_ar = ctx->prof_on && ctx->prof_filter.empty();
+  for (const std::string &f : ctx->prof_filter) prof_ar |= ctx->prof_on && f.rfind("ar_", 0) == 0 && f != "ar_decode_step";
   if (prof_ar || no_graph) {
     CHECK(enqueue_decode_step(ctx, st));
   } else {
@@ -1349,6 +1351,10 @@ int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out
       TTS_HIP(ctx, e);
       TTS_HIP(ctx, hipGraphInstantiate(&st->graph_exec, st->graph, nullptr, nullptr, 0));
     }
+    // HBM-bound step: every weight once (f32: 12 d^2 per layer + the padded head) + the fp16 K/V rows read + logits
+    const double step_bytes = 4.0 * ((double)st->n_layers * 12.0 * D * D + (double)D * V) +
+                              (double)st->B * st->n_layers * 2.0 * (st->P + step_i + 1) * D * 2.0 + (double)st->B * V * 4.0;
+    ProfScope ps(ctx, "ar_decode_step", step_bytes);
     TTS_HIP(ctx, hipGraphLaunch(st->graph_exec, ctx->stream));
   }
   TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -84,7 +84,7 @@ struct tts_ctx {
   // profiling: per kernel family, HIP event pairs recorded on the ctx stream around every launch and
   // resolved lazily (no host sync inside the timed region)
   bool prof_on = false;
-  std::string prof_filter; // empty = every family
+  std::vector<std::string> prof_filter; // empty = every family; "prof_only:<family>" = 1 adds one, = 0 clears the list
   int prof_stride = 1;     // option "prof_stride": every Nth launch of a family is bracketed (an event pair drains the pipeline)
   std::map<std::string, tts::ProfEntry> prof;
   std::vector<hipEvent_t> ev_pool;
@@ -109,7 +109,10 @@ struct ProfScope {
   tts_ctx *c; const char *fam; hipEvent_t a = nullptr;
   // work: algorithmic FLOPs (MFMA-bound families) or bytes (HBM-bound families) of this launch
   ProfScope(tts_ctx *ctx, const char *family, double work = 0) : c(ctx), fam(family) {
-    if (c->prof_on && (c->prof_filter.empty() || c->prof_filter == fam)) {
+    bool want = c->prof_on && c->prof_filter.empty();
+    if (c->prof_on && !want)
+      for (const std::string &f : c->prof_filter) want |= (f == fam);
+    if (want) {
       ProfEntry &e = c->prof[fam];
       if (e.seen++ % c->prof_stride == 0) { // work and time are accumulated over the bracketed launches only
         a = prof_event(c);
