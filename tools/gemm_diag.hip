@@ -1,4 +1,4 @@
-// Developer tool: where does a diffusion GEMM launch spend its time?  Times the product kernels (and the persistent A/B variant) on
+// Developer tool: where does a diffusion GEMM launch spend its time?  Times the one-tile-per-workgroup kernels and the balanced persistent kernels on
 // the benchmark's shapes and, in the trace build, prints per-workgroup phase statistics from in-kernel wall-clock stamps
 // (gemm_f16.h, TTS_GEMM_TRACE): setup | first K tile (DMA round trip) | rest of the K loop | epilogue issue | store drain, plus the
 // dispatch timeline (workgroup starts per 5 us).
@@ -65,8 +65,7 @@ int main(int argc, char **argv) {
   for (const Shape &sh : shapes) {
     for (int pers = 0; pers < npers; pers++) {
 #ifndef TTS_GEMM_VARIANT
-      gemm_persist_flag() = pers;
-      if (pers && sh.nseg == 3) continue; // the conv3 kernel has no persistent form
+      gemm_balanced_flag() = pers;
 #endif
       GemmArgs g{};
       const int lda = sh.K;
@@ -78,13 +77,17 @@ int main(int argc, char **argv) {
       CK(hipStreamSynchronize(s));
       char chk[64] = "-";
 #ifndef TTS_GEMM_DIAG_NOEPI
-      if (sh.mode == GEMM_OUT_F32) { // first 256 rows against a naive kernel
+      if (sh.mode == GEMM_OUT_F32) { // three bands of 256 rows (start, an XCD boundary of the row partition, end) against a naive kernel
         const int MC = 256, ldw = sh.nseg * sh.K;
-        naive_kernel<<<dim3((sh.N + 255) / 256, MC), 256, 0, s>>>(dA + lda, lda, dW, ldw, sh.nseg, sh.K, MC, sh.N, sh.resid ? dRes : nullptr, dR);
-        std::vector<float> c((size_t)MC * sh.N), r((size_t)MC * sh.N);
-        CK(hipMemcpy(c.data(), dC, c.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(r.data(), dR, r.size() * 4, hipMemcpyDeviceToHost));
         double maxd = 0, maxr = 0;
-        for (size_t i = 0; i < c.size(); i++) { maxd = fmax(maxd, fabs(c[i] - r[i])); maxr = fmax(maxr, fabs(r[i])); }
+        const int bands[3] = {0, (sh.M / 8 / 32) * 32 - 128, sh.M - MC};
+        for (int b0 : bands) {
+          naive_kernel<<<dim3((sh.N + 255) / 256, MC), 256, 0, s>>>(dA + lda + (size_t)b0 * lda, lda, dW, ldw, sh.nseg, sh.K, MC, sh.N,
+                                                                   sh.resid ? dRes + (size_t)b0 * sh.N : nullptr, dR);
+          std::vector<float> c((size_t)MC * sh.N), r((size_t)MC * sh.N);
+          CK(hipMemcpy(c.data(), dC + (size_t)b0 * sh.N, c.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(r.data(), dR, r.size() * 4, hipMemcpyDeviceToHost));
+          for (size_t i = 0; i < c.size(); i++) { maxd = fmax(maxd, fabs(c[i] - r[i])); maxr = fmax(maxr, fabs(r[i])); }
+        }
         snprintf(chk, sizeof chk, "maxdiff %.2g / %.2g", maxd, maxr);
       }
 #endif
@@ -95,7 +98,7 @@ int main(int argc, char **argv) {
       CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       const double fl = 2.0 * sh.M * sh.N * (double)sh.K * sh.nseg, us = 1000.0 * ms / iters;
-      printf("%-36s %-10s %9.1f %9.1f %s\n", sh.name, pers ? "persistent" : "product", us, fl / (us * 1e-6) / 1e12, chk);
+      printf("%-36s %-10s %9.1f %9.1f %s\n", sh.name, pers ? "balanced" : "classic", us, fl / (us * 1e-6) / 1e12, chk);
 #ifdef TTS_GEMM_TRACE
       { // one more launch with a clean trace buffer
         static std::vector<unsigned long long> tr(65536 * 8);
