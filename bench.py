@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-share-uncond", action="store_true", help="headline pass with the unconditioned integrator layers evaluated per candidate")
     ap.add_argument("--no-ab", action="store_true", help="skip the extra pass that measures the other share_uncond setting")
+    ap.add_argument("--no-diff-graph", action="store_true", help="A/B: launch every diffusion step eagerly instead of replaying the captured step graph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU plumbing test with --dry-engine)")
     ap.add_argument("--dry-engine", action="store_true", help="no device work: host-only contexts, fake stage outputs (tests of the launch / collective plumbing)")
     ap.add_argument("--models", default=None)
@@ -228,6 +229,8 @@ def main():
         if world > 1:  # N processes share the host: leave each rank's sampler pool its share of the cores
             eng.set_option("sampler_threads", max(0, min(7, (os.cpu_count() or 8) // world - 2)))
         eng.load(model_dir)
+    if a.no_diff_graph and not a.dry_engine:
+        eng.set_option("diff_graph", 0)
     if cand_total:
         eng.set_option("rng_shard_offset", cand0)
         eng.set_option("rng_shard_total", cand_total)

@@ -57,6 +57,9 @@ const char *tts_last_error(const tts_ctx *ctx);
  * "share_uncond" (1 default: in tts_diffusion the conditioning_timestep_integrator layers of the unconditioned branch,
  * whose input does not depend on the candidate, are evaluated once per distinct sequence length instead of once per
  * candidate; 0 = once per candidate. Same arithmetic per row either way),
+ * "diff_graph" (1 default: tts_diffusion captures ONE sampling step — ~125 kernels, every per-step value read through a device-side step
+ * counter — into a hipGraph and replays it; 0: every step is launched kernel by kernel), "prof_eager_every" (8: while a diff_* family is
+ * being profiled every 8th step runs eagerly with its event pairs, the rest replay the graph),
  * "rng_shard_offset" / "rng_shard_total" (0 / 0 default = unsharded): candidate-parallel multi-GPU runs. This context
  * holds candidates [offset, offset + n_candidates) of a batch of `total`: the sampler skips the uniforms of the other
  * ranks' candidates (the used uniform of (step s, candidate c) is output 2 (s total + c) + 1 of the mt19937 stream), and

@@ -55,18 +55,18 @@ int main(int argc, char **argv) {
   CK(hipMemset(dBias, 0, 3072 * 4)); CK(hipMemset(dSeq, 0, Mmax * 4));
   hipStream_t s; CK(hipStreamCreate(&s));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const int npers =
-#ifdef TTS_GEMM_VARIANT
-      1;
-#else
-      2;
-#endif
+  // variants: classic, then the round stagger sweep (delay us, div)
+  struct Var { const char *name; int bal; float us; int div; };
+  const std::vector<Var> vars = {{"classic", 0, 0.f, 1},      {"stag6/1", 0, 6.f, 1},   {"stag10/1", 0, 10.f, 1}, {"stag14/1", 0, 14.f, 1},
+                                 {"stag20/1", 0, 20.f, 1},    {"stag30/1", 0, 30.f, 1}, {"stag10/32", 0, 10.f, 32}, {"stag20/32", 0, 20.f, 32},
+                                 {"stag30/32", 0, 30.f, 32},  {"stag14/4", 0, 14.f, 4}, {"stag20/2", 0, 20.f, 2}};
+  const int npers = (int)vars.size();
   printf("%-36s %-10s %9s %9s %s\n", "shape", "kernel", "us/launch", "TF/s", "check");
   for (const Shape &sh : shapes) {
     for (int pers = 0; pers < npers; pers++) {
-#ifndef TTS_GEMM_VARIANT
-      gemm_balanced_flag() = pers;
-#endif
+      gemm_balanced_flag() = vars[pers].bal;
+      gemm_stagger_us() = vars[pers].us;
+      gemm_stagger_div() = vars[pers].div;
       GemmArgs g{};
       const int lda = sh.K;
       for (int i = 0; i < 3; i++) { g.A[i] = dA + lda; g.row_off[i] = sh.nseg == 3 ? i - 1 : 0; }
@@ -98,7 +98,7 @@ int main(int argc, char **argv) {
       CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       const double fl = 2.0 * sh.M * sh.N * (double)sh.K * sh.nseg, us = 1000.0 * ms / iters;
-      printf("%-36s %-10s %9.1f %9.1f %s\n", sh.name, pers ? "balanced" : "classic", us, fl / (us * 1e-6) / 1e12, chk);
+      printf("%-36s %-10s %9.1f %9.1f %s\n", sh.name, vars[pers].name, us, fl / (us * 1e-6) / 1e12, chk);
 #ifdef TTS_GEMM_TRACE
       { // one more launch with a clean trace buffer
         static std::vector<unsigned long long> tr(65536 * 8);
@@ -130,6 +130,14 @@ int main(int argc, char **argv) {
         }
         std::vector<int> hist((size_t)((tmax - tmin) / 500) + 1, 0);
         for (auto t : starts) hist[(size_t)((t - tmin) / 500)]++;
+        if (pers == 0 && &sh == &shapes[0]) { // where do consecutive workgroups of one XCD land? (HW_ID: cu_id [11:8], se_id [15:13]; XCC_ID [3:0])
+          printf("    placement of blockIdx 0, 8, 16, ... (XCD 0 by construction): (xcc se cu simd):");
+          for (int i = 0; i < 48; i++) {
+            const unsigned hw = (unsigned)tr[(size_t)i * 8 * 8 + 6], xc = (unsigned)tr[(size_t)i * 8 * 8 + 7];
+            printf(" %u.%u.%u.%u", xc & 15, (hw >> 13) & 7, (hw >> 8) & 15, (hw >> 4) & 3);
+          }
+          printf("\n");
+        }
         printf("    tile starts per 5 us:");
         for (int h : hist) printf(" %d", h);
         printf("\n");

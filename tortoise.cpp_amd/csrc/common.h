@@ -86,6 +86,9 @@ struct tts_ctx {
   bool prof_on = false;
   std::vector<std::string> prof_filter; // empty = every family; "prof_only:<family>" = 1 adds one, = 0 clears the list
   int prof_stride = 1;     // option "prof_stride": every Nth launch of a family is bracketed (an event pair drains the pipeline)
+  bool capturing = false;  // a hipGraph is being captured on the stream: ProfScope records nothing (event records would become graph nodes)
+  int diff_graph = 1;      // option "diff_graph": the diffusion step is captured once per call and replayed (0: every step launched eagerly)
+  int prof_eager_every = 8; // while a diff_* family is profiled, every Nth diffusion step runs eagerly with its event pairs; the others replay the graph
   std::map<std::string, tts::ProfEntry> prof;
   std::vector<hipEvent_t> ev_pool;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -109,8 +112,8 @@ struct ProfScope {
   tts_ctx *c; const char *fam; hipEvent_t a = nullptr;
   // work: algorithmic FLOPs (MFMA-bound families) or bytes (HBM-bound families) of this launch
   ProfScope(tts_ctx *ctx, const char *family, double work = 0) : c(ctx), fam(family) {
-    bool want = c->prof_on && c->prof_filter.empty();
-    if (c->prof_on && !want)
+    bool want = c->prof_on && !c->capturing && c->prof_filter.empty();
+    if (c->prof_on && !c->capturing && !want)
       for (const std::string &f : c->prof_filter) want |= (f == fam);
     if (want) {
       ProfEntry &e = c->prof[fam];

@@ -507,14 +507,31 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint32_t stream, u
 // Ancestral sampling step (main.cpp:5970-6030) for every candidate, in place on x [cand][100][T].
 // net: [rows][256] f32 (channels 0..99 eps, 100..199 variance logits). grid: cond rows; block 128.
 struct StepScalars { float max_log, min_log, cfk, sqrt_recip, sqrt_recipm1, coef1, coef2; int is_last; };
+// Everything of a sampling step that the reference keeps in host variables lives in a device table indexed by a device-side step
+// counter, so that ONE captured hipGraph of the step can be replayed for every step (main.cpp:5723-6033 rebuilds and re-uploads
+// its graph 160 times): the schedule scalars, the noise block of the step, the generator key.
+struct StepEntry { StepScalars sc; int has_noise; long long noise_off; unsigned philox_step; unsigned pad; };
+
+// Copies this step's [n_res][scale | shift] block to the fixed address the GroupNorm kernels read. grid: any, block 256.
+__global__ __launch_bounds__(256) void step_begin_kernel(const float *__restrict__ ss_all, size_t ss_stride, const int *__restrict__ ctr,
+                                                         float *__restrict__ ss_cur) {
+  const float4 *src = (const float4 *)(ss_all + (size_t)(*ctr) * ss_stride);
+  float4 *dst = (float4 *)ss_cur;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < ss_stride / 4; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ void step_advance_kernel(int *ctr) { *ctr += 1; }
 __global__ __launch_bounds__(128) void ddpm_update_kernel(const float *__restrict__ net, float *__restrict__ x,
                                                           const int64_t *__restrict__ x_off, const int *__restrict__ row_seq,
                                                           const int *__restrict__ row_t, const int *__restrict__ seq_len,
-                                                          const int *__restrict__ seq_start, int ncand, StepScalars sc,
-                                                          const float *__restrict__ noise /* same layout as x, or null */,
-                                                          uint64_t seed, uint32_t step, uint32_t stream0 /* global id of candidate 0 */) {
+                                                          const int *__restrict__ seq_start, int ncand, const StepEntry *__restrict__ tab,
+                                                          const int *__restrict__ ctr, const float *__restrict__ noise_base /* or null */,
+                                                          uint64_t seed, uint32_t stream0 /* global id of candidate 0 */) {
   const int r = blockIdx.x, s = row_seq[r], ch = threadIdx.x;
   if (s < 0 || s >= ncand || ch >= 100) return;
+  const StepEntry e = tab[*ctr];
+  const StepScalars sc = e.sc;
+  const float *noise = e.has_noise ? noise_base + e.noise_off : nullptr; // same layout as x
+  const uint32_t step = e.philox_step;
   const int T = seq_len[s], t = row_t[r];
   const size_t xi = x_off[s] + (size_t)ch * T + t;
   const float eps_c = net[(size_t)r * 256 + ch], var_c = net[(size_t)r * 256 + 100 + ch];
@@ -629,8 +646,16 @@ struct DiffState {
   bool share_integ = false;
   DevBuf ce_src, iseq_src;
   DevBuf h0; // in_layers of the first integrator ResBlock applied to the code embedding: the same at every step
+  DevBuf step_tab, step_ctr, ss_cur; // StepEntry[n_steps] | int step counter | this step's scale/shift block (fixed address)
+  hipGraph_t step_graph = nullptr;
+  hipGraphExec_t step_exec = nullptr;
+  void drop_step_graph() {
+    if (step_exec) (void)hipGraphExecDestroy(step_exec);
+    if (step_graph) (void)hipGraphDestroy(step_graph);
+    step_exec = nullptr; step_graph = nullptr;
+  }
   DevBuf code_emb, ce, ce16, xt16, inp16, net, temb, e1, emb, ss_all, xbuf, xoff, noise, seq_src, lat_in16, out_ct;
-  ~DiffState() { for (void *p : owned) (void)hipFree(p); }
+  ~DiffState() { drop_step_graph(); for (void *p : owned) (void)hipFree(p); }
   int n_res() const { return n_integ + n_main + n_tail; }
 };
 
@@ -1254,20 +1279,67 @@ int diff_sample(tts_ctx *ctx, const float *latents, const int32_t *rows, int B, 
   if (timing) (void)hipStreamSynchronize(ctx->stream);
   const auto t_pre = now();
   const size_t ss_stride = (size_t)st->n_res() * 2 * C;
+  // per-step table + device step counter (see StepEntry)
+  std::vector<StepEntry> tab(n_steps);
   for (int idx = 0; idx < n_steps; idx++) {
     const int t = n_steps - 1 - idx;
+    tab[idx].sc = StepScalars{sched.max_log[t], sched.min_log[t], sched.cfk[t], sched.sqrt_recip[t], sched.sqrt_recipm1[t],
+                              sched.coef1[t], sched.coef2[t], t == 0 ? 1 : 0};
+    tab[idx].has_noise = host_noise ? 1 : 0;
+    tab[idx].noise_off = (long long)(idx + 1) * total;
+    tab[idx].philox_step = (unsigned)idx;
+    tab[idx].pad = 0;
+  }
+  TTS_HIP(ctx, st->step_tab.reserve(tab.size() * sizeof(StepEntry)));
+  TTS_HIP(ctx, st->step_ctr.reserve(64));
+  TTS_HIP(ctx, st->ss_cur.reserve(ss_stride * 4));
+  TTS_HIP(ctx, hipMemcpyAsync(st->step_tab.p, tab.data(), tab.size() * sizeof(StepEntry), hipMemcpyHostToDevice, ctx->stream));
+  TTS_HIP(ctx, hipMemsetAsync(st->step_ctr.p, 0, 64, ctx->stream));
+  TTS_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `tab` is a host vector: the copy must have read it before it goes out of scope
+  // One sampling step, identical for every step (all per-step values are read through the device counter): launched eagerly or
+  // captured once and replayed.
+  auto enqueue_step = [&]() -> int {
+    step_begin_kernel<<<16, 256, 0, ctx->stream>>>(st->ss_all.as<float>(), ss_stride, st->step_ctr.as<int>(), st->ss_cur.as<float>());
     xt_to_rows_kernel<<<lay.rows, 128, 0, ctx->stream>>>(st->xbuf.as<float>(), st->xoff.as<int64_t>(), lay.d_row_seq.as<int>(),
                                                          lay.d_row_t.as<int>(), lay.d_len.as<int>(), lay.d_start.as<int>(), B, 1,
                                                          st->xt16.as<__half>() + XTC);
-    CHECK(network_forward(ctx, st, st->ss_all.as<float>() + (size_t)idx * ss_stride));
-    StepScalars sc{sched.max_log[t], sched.min_log[t], sched.cfk[t], sched.sqrt_recip[t], sched.sqrt_recipm1[t],
-                   sched.coef1[t], sched.coef2[t], t == 0 ? 1 : 0};
-    ProfScope ps(ctx, "diff_update");
-    ddpm_update_kernel<<<lay.rows, 128, 0, ctx->stream>>>(
-        st->net.as<float>(), st->xbuf.as<float>(), st->xoff.as<int64_t>(), lay.d_row_seq.as<int>(), lay.d_row_t.as<int>(),
-        lay.d_len.as<int>(), lay.d_start.as<int>(), B, sc, host_noise ? st->noise.as<float>() + (size_t)(idx + 1) * total : nullptr,
-        ctx->seed_value, (uint32_t)idx, (uint32_t)ctx->rng_shard_offset);
+    CHECK(network_forward(ctx, st, st->ss_cur.as<float>()));
+    {
+      ProfScope ps(ctx, "diff_update");
+      ddpm_update_kernel<<<lay.rows, 128, 0, ctx->stream>>>(
+          st->net.as<float>(), st->xbuf.as<float>(), st->xoff.as<int64_t>(), lay.d_row_seq.as<int>(), lay.d_row_t.as<int>(),
+          lay.d_len.as<int>(), lay.d_start.as<int>(), B, st->step_tab.as<StepEntry>(), st->step_ctr.as<int>(),
+          host_noise ? st->noise.as<float>() : nullptr, ctx->seed_value, (uint32_t)ctx->rng_shard_offset);
+    }
+    step_advance_kernel<<<1, 1, 0, ctx->stream>>>(st->step_ctr.as<int>());
     TTS_HIP(ctx, hipGetLastError());
+    return TTS_OK;
+  };
+  // Event records cannot ride in the replayed graph: while a diff_* family is profiled every prof_eager_every-th step is launched
+  // eagerly (with its event pairs), the others replay the graph; "diff_graph" = 0 (or TTS_NO_GRAPH, e.g. under rocprofv3) launches
+  // every step eagerly.
+  static const bool no_graph_env = getenv("TTS_NO_GRAPH") != nullptr;
+  bool prof_diff = ctx->prof_on && ctx->prof_filter.empty();
+  for (const std::string &f : ctx->prof_filter) prof_diff |= ctx->prof_on && f.rfind("diff_", 0) == 0;
+  const bool use_graph = ctx->diff_graph && !no_graph_env && n_steps > 2;
+  double t_capture = 0;
+  if (use_graph) {
+    const auto tc0 = now();
+    st->drop_step_graph(); // layouts and buffers belong to this call
+    ctx->capturing = true;
+    hipError_t eb = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+    int rc = eb == hipSuccess ? enqueue_step() : TTS_OK;
+    hipError_t ee = eb == hipSuccess ? hipStreamEndCapture(ctx->stream, &st->step_graph) : eb;
+    ctx->capturing = false;
+    if (rc) return rc;
+    TTS_HIP(ctx, ee);
+    TTS_HIP(ctx, hipGraphInstantiate(&st->step_exec, st->step_graph, nullptr, nullptr, 0));
+    t_capture = ms(tc0, now());
+  }
+  for (int idx = 0; idx < n_steps; idx++) {
+    const bool eager = !use_graph || (prof_diff && idx % ctx->prof_eager_every == 0);
+    if (eager) CHECK(enqueue_step());
+    else TTS_HIP(ctx, hipGraphLaunch(st->step_exec, ctx->stream));
   }
   const auto t_issued = now();
   if (timing) (void)hipStreamSynchronize(ctx->stream);
@@ -1275,8 +1347,8 @@ int diff_sample(tts_ctx *ctx, const float *latents, const int32_t *rows, int B, 
   TTS_HIP(ctx, hipMemcpyAsync(mel_out, st->xbuf.p, total * 4, hipMemcpyDeviceToHost, ctx->stream));
   TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (timing)
-    fprintf(stderr, "[tts timing] diffusion: setup %.1f ms, time MLP + noise %.1f, %d steps %.1f (issued in %.1f), mel copy %.1f\n",
-            ms(t_begin, t_setup), ms(t_setup, t_pre), n_steps, ms(t_pre, t_loop), ms(t_pre, t_issued), ms(t_loop, now()));
+    fprintf(stderr, "[tts timing] diffusion: setup %.1f ms, time MLP + noise %.1f, %d steps %.1f (issued in %.1f, graph capture + instantiate %.1f), mel copy %.1f\n",
+            ms(t_begin, t_setup), ms(t_setup, t_pre), n_steps, ms(t_pre, t_loop), ms(t_pre, t_issued), t_capture, ms(t_loop, now()));
   return TTS_OK;
 }
 

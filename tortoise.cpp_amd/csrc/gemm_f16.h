@@ -47,7 +47,18 @@ struct GemmArgs {
   __half *outH; int ldh;
   __half *outVt; int ldvt; // QKV: V channels transposed [h*64+d][row]
   int mode;
+  // Round stagger (set by launch_gemm_f16): of the workgroups resident in the first round (index inside the XCD < stagger_slots) those
+  // with an odd (index / stagger_div) start stagger_ticks (100 MHz wall clock) late. All tiles take the same time, so the two
+  // populations stay half a tile apart for the whole launch: one's epilogue burst (HBM-bound, matrix pipe idle) falls into the other's K loop.
+  int stagger_ticks, stagger_slots, stagger_div;
 };
+
+__device__ __forceinline__ void gemm_round_stagger(const GemmArgs &g, int idx_in_xcd) {
+  if (g.stagger_ticks > 0 && idx_in_xcd < g.stagger_slots && ((idx_in_xcd / g.stagger_div) & 1)) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)g.stagger_ticks) __builtin_amdgcn_s_sleep(16);
+  }
+}
 
 #ifdef TTS_GEMM_TRACE // developer build (tools/gemm_diag.hip): phase timestamps (100 MHz wall clock) of every workgroup / tile
 __device__ unsigned long long tts_gemm_trace[65536 * 8];
@@ -196,6 +207,7 @@ static __global__ __launch_bounds__(256, WGS) void gemm_f16_glds_kernel(GemmArgs
   const int mq = MT >> 3, mr = MT & 7;
   const int mcount = mq + (xcd < mr ? 1 : 0), mfirst = xcd * mq + (xcd < mr ? xcd : mr);
   if (idx >= mcount * NT) return; // grid is padded to 8 * max tiles per XCD
+  gemm_round_stagger(g, idx);
   GEMM_TR_DECL;
   GEMM_TR(0);
   const int cn = g.cn > 0 ? g.cn : NT, per_chunk = mcount * cn;
@@ -306,6 +318,7 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_kernel(GemmArgs 
   const int mq = MT >> 3, mr = MT & 7;
   const int mcount = mq + (xcd < mr ? 1 : 0), mfirst = xcd * mq + (xcd < mr ? xcd : mr);
   if (idx >= mcount * NT) return;
+  gemm_round_stagger(g, idx);
   const int cn = g.cn > 0 ? g.cn : NT, per_chunk = mcount * cn;
   const int chunk = idx / per_chunk, rem = idx - chunk * per_chunk;
   const int m0 = (mfirst + rem / cn) * BM, n0 = (chunk * cn + rem % cn) << 7;
@@ -662,6 +675,15 @@ static inline int &gemm_balanced_flag() {
   static int v = getenv("TTS_GEMM_BAL") ? atoi(getenv("TTS_GEMM_BAL")) : 0;
   return v;
 }
+static inline float &gemm_stagger_us() {
+  static float v = getenv("TTS_GEMM_STAGGER_US") ? (float)atof(getenv("TTS_GEMM_STAGGER_US")) : -1.f; // < 0: per-mode default
+  return v;
+}
+static inline int &gemm_stagger_div() {
+  static int v = getenv("TTS_GEMM_STAGGER_DIV") ? atoi(getenv("TTS_GEMM_STAGGER_DIV")) : 0; // 0: default (32)
+  return v;
+}
+
 static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
   GemmArgs gg = g;
   {
@@ -697,12 +719,26 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
   // the kernel needs only 128 VGPRs; with (256, 4) 1024 are, and M = 28 032 x N = 1024 is 1752 tiles: 2 rounds instead of 3)
   static const bool wgs3 = getenv("TTS_GEMM_WGS3") != nullptr;
   static const bool qkv3 = getenv("TTS_GEMM_QKV3") != nullptr; // A/B switch: QKV projection at 3 workgroups per CU (138 VGPRs, no spills)
+  // A/B switches for the round stagger: TTS_GEMM_STAGGER_US (delay in microseconds for every mode; 0 = off; unset = per-mode default),
+  // TTS_GEMM_STAGGER_DIV (1: alternate workgroups, N: alternate groups of N consecutive workgroups of an XCD)
   static int cus_per_xcd = 0;
   if (!cus_per_xcd) {
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     cus_per_xcd = cus / 8 > 0 ? cus / 8 : 32;
+  }
+  {
+    // default: the QKV projection only (fp16 outputs, 5.1 rounds at B = 16): alternate groups of 32 workgroups of an XCD start 16 us apart —
+    // measured 241.6 -> 221.6 us per launch (tools/gemm_diag: stag20/32). The f32-output GEMMs measured slower with any stagger (their first
+    // round is already the whole launch's critical path: 1.7 - 2.3 rounds).
+    const float us = gemm_stagger_us() >= 0 ? gemm_stagger_us() : (g.mode == GEMM_OUT_QKV ? 16.f : 0.f);
+    const int wgs_res = conv3 ? 3 : (g.mode == GEMM_OUT_QKV && qkv3) ? 3 : (g.mode == GEMM_OUT_F16 || (g.mode == GEMM_OUT_F32 && wgs3)) ? 3 : 4;
+    gg.stagger_ticks = us > 0 ? (int)(us * 100.0f) : 0;
+    gg.stagger_slots = cus_per_xcd * wgs_res;
+    gg.stagger_div = gemm_stagger_div() > 0 ? gemm_stagger_div() : 32;
+    // only launches with more tiles than resident slots have rounds to stagger
+    if (grid1 / 8 <= gg.stagger_slots) gg.stagger_ticks = 0;
   }
   if (gemm_balanced_flag() && !force_mi) {
     // S workgroups per XCD = G row groups x cn n-tiles; cn: the largest divisor of NT that divides S and keeps the n-chunk's weights
