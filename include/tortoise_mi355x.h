@@ -81,6 +81,8 @@ int tts_diffusion_layers(const tts_ctx *ctx);
 void tts_seed(tts_ctx *ctx, uint32_t seed);
 /* libstdc++ text state ("fin >> generator", main.cpp:6260-6262, 6475-6477) */
 int tts_rng_load_state(tts_ctx *ctx, const char *path);
+/* "fout << generator": hands the engine state back to a host program that keeps its own std::mt19937 */
+int tts_rng_save_state(tts_ctx *ctx, const char *path);
 float tts_rng_uniform(tts_ctx *ctx);
 void tts_rng_normal(tts_ctx *ctx, float *out, int64_t n);
 
@@ -153,6 +155,15 @@ int tts_vocoder_samples(int mel_frames); /* (T+10)*256-6, main.cpp:6051, 4459-44
  * audio_out per candidate tts_vocoder_samples(T_c) floats back to back. */
 int tts_vocoder(tts_ctx *ctx, const float *mel, const int32_t *frames, int n_candidates,
                 const float *noise, int noise_mode, float *audio_out);
+
+/* Streaming form for ONE candidate (first-audio latency; the reference has only the whole-utterance call): the samples of
+ * frames [frame0, frame0 + n_frames) of the padded sequence (T + 10 frames; sample index = frame * 256, the sequence has (T+10)*256-6
+ * samples). mel [100][T] and noise [64][T+10] are the WHOLE utterance's (draw the noise once with tts_rng_normal(ctx, buf, 64*(T+10)):
+ * that is vocoder()'s draw, main.cpp:6058-6059); only a window with a fixed halo is evaluated. Concatenating the chunks of any
+ * partition of [0, T+10) reproduces tts_vocoder's samples (same arithmetic per sample; tests/test_vocoder_gpu.py).
+ * audio_out: capacity n_frames*256 floats; *n_samples_out: samples written. */
+int tts_vocoder_chunk(tts_ctx *ctx, const float *mel, int mel_frames, const float *noise, int frame0, int n_frames,
+                      float *audio_out, int *n_samples_out);
 
 /* ---- output -------------------------------------------------------------------------------- */
 /* writeWav (main.cpp:4821-4868): RIFF, fmt 16 B, tag 3 (IEEE float), mono, 32-bit. */

@@ -1,0 +1,91 @@
+"""tools/convert_weights.py (the PyTorch -> reference-container export the reference's README promises but does not ship).
+Round trip without the trained checkpoints: synthetic weights in the reference format are turned back into PyTorch-style state dicts
+the way tortoise-tts stores them — k = 1 convolutions as 3-D Conv1d weights, UnivNet convolutions as weight_norm (weight_g, weight_v)
+pairs under 'model_g', the GPT-2 stack under its training-time names (gpt.h.N, final_norm, mel_head) plus unrelated keys — saved with
+torch.save, converted by the CLI, and the result must be the original container: same names, same shapes, same values (the fused
+weight_norm tensors to f32 round-off), accepted by the reference-format reader of the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+from conftest import ROOT
+
+
+def _to_state_dicts(src, tmp):
+    import tortoise_cpp_amd_loader
+    tortoise_cpp_amd_loader.load()
+    from tortoise_cpp_amd import synth_weights as sw
+    ar = sw.read_ggml(os.path.join(src, "ggml-model.bin"))
+    sd = {}
+    for k, v in ar.items():  # training-time naming
+        k2 = (k.replace("inference_model.transformer.h.", "gpt.h.").replace("inference_model.transformer.ln_f.", "gpt.ln_f.")
+               .replace("inference_model.lm_head.0.", "final_norm.").replace("inference_model.lm_head.1.", "mel_head."))
+        sd[k2] = torch.from_numpy(v)
+    sd["text_head.weight"] = torch.zeros(256, 1024)  # keys the reference never reads
+    sd["conditioning_encoder.init.weight"] = torch.zeros(4, 4)
+    torch.save(sd, os.path.join(tmp, "autoregressive.pth"))
+    df = sw.read_ggml(os.path.join(src, "ggml-diffusion-model.bin"))
+    sd = {}
+    for k, v in df.items():
+        if k == "diffusion_conditioning_latent":
+            torch.save(torch.from_numpy(v.reshape(1, 2048)), os.path.join(tmp, "voice_diff.pth"))
+            continue
+        t = torch.from_numpy(v)
+        if k.endswith((".qkv.weight", ".proj_out.weight", ".in_layers.2.weight")) or k == "integrating_conv.weight":
+            t = t[:, :, None]  # nn.Conv1d(kernel_size=1)
+        if k == "unconditioned_embedding":
+            t = t.reshape(1, 1024, 1)
+        sd[k] = t
+    sd["contextual_embedder.init.weight"] = torch.zeros(3, 3)
+    torch.save(sd, os.path.join(tmp, "diffusion_decoder.pth"))
+    vc = sw.read_ggml(os.path.join(src, "ggml-vocoder-model.bin"))
+    sd = {}
+    rs = np.random.RandomState(0)
+    for k, v in vc.items():
+        t = torch.from_numpy(v)
+        if k == "conv_post.1.weight":
+            t = t.reshape(1, 32, 7)
+        if k.endswith(".weight") and t.ndim == 3:  # weight_norm(dim=0): weight = g * v / ||v||
+            scale = torch.from_numpy(rs.uniform(0.5, 2.0, (t.shape[0], 1, 1)).astype(np.float32))
+            vv = t * scale
+            sd[k[:-len("weight")] + "weight_v"] = vv
+            sd[k[:-len("weight")] + "weight_g"] = torch.sqrt((t.double() ** 2).sum(dim=(1, 2), keepdim=True)).float()
+        else:
+            sd[k] = t
+    torch.save({"model_g": sd}, os.path.join(tmp, "vocoder.pth"))
+    return ar, df, vc
+
+
+def test_checkpoint_round_trip(small_models, tmp_path, oracle):
+    tmp = str(tmp_path)
+    ar, df, vc = _to_state_dicts(small_models, tmp)
+    out = os.path.join(tmp, "out")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "convert_weights.py"), "--ar", tmp + "/autoregressive.pth", "--diffusion",
+                        tmp + "/diffusion_decoder.pth", "--diffusion-conditioning-latent", tmp + "/voice_diff.pth", "--vocoder",
+                        tmp + "/vocoder.pth", "--out", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    from tortoise_cpp_amd import synth_weights as sw
+    for name, want, tol in (("ggml-model.bin", ar, 0.0), ("ggml-diffusion-model.bin", df, 0.0), ("ggml-vocoder-model.bin", vc, 1e-6)):
+        got = sw.read_ggml(os.path.join(out, name))
+        assert sorted(got) == sorted(want), (name, set(got) ^ set(want))
+        for k in want:
+            assert got[k].shape == want[k].shape, (name, k, got[k].shape, want[k].shape)
+            if tol == 0.0:
+                assert (got[k] == want[k]).all(), (name, k)
+            else:
+                assert np.abs(got[k] - want[k]).max() <= tol * max(1.0, np.abs(want[k]).max()), (name, k)
+        oracle.Model(os.path.join(out, name))  # the reference-format reader takes it
+    # byte-identical containers for the two files that need no arithmetic
+    for name in ("ggml-model.bin", "ggml-diffusion-model.bin"):
+        a, b = open(os.path.join(out, name), "rb").read(), open(os.path.join(small_models, name), "rb").read()
+        assert len(a) == len(b) and sorted(a[:64]) == sorted(b[:64])
+    # the oracle runs the converted vocoder and matches the original weights' output (fused weight_norm within round-off)
+    rs = np.random.RandomState(1)
+    mel = np.clip(rs.randn(100, 7) * 0.5, -1, 1).astype(np.float32)
+    nz = rs.randn(64, 17).astype(np.float32)
+    a0 = oracle.Vocoder(oracle.Model(os.path.join(small_models, "ggml-vocoder-model.bin"))).run(mel, noise=nz)
+    a1 = oracle.Vocoder(oracle.Model(os.path.join(out, "ggml-vocoder-model.bin"))).run(mel, noise=nz)
+    assert np.abs(a0 - a1).max() <= 1e-3 * np.abs(a0).max()

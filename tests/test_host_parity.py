@@ -188,3 +188,27 @@ def test_wav_writer_header(pkg, tmp_path):
     assert (fmt_size, tag, ch, rate, brate, align, bits) == (16, 3, 1, 24000, 96000, 4, 32)
     assert b[36:40] == b"data" and struct.unpack("<i", b[40:44])[0] == 4000
     assert (np.frombuffer(b[44:], np.float32) == x).all()
+
+
+def test_rng_state_round_trip(pkg, tmp_path):
+    """INTEGRATION.md section 2: a host program that keeps its own std::mt19937 hands the state to the library before a stage call
+    (tts_rng_load_state) and takes it back afterwards (tts_rng_save_state). The saved text is libstdc++'s `fout << generator`; a second
+    context that loads it continues the very same stream (uniforms and normals)."""
+    L = pkg.lib()
+    a = pkg.Engine.__new__(pkg.Engine); a.L = L; a.h = L.tts_create(-1)
+    b = pkg.Engine.__new__(pkg.Engine); b.L = L; b.h = L.tts_create(-1)
+    a.seed(245645656)
+    for _ in range(37):
+        a.rng_uniform()
+    a.rng_normal(10)  # an even count: no cached second value is left inside the normal distribution
+    p = str(tmp_path / "rng.txt")
+    a.rng_save_state(p)
+    b.rng_load_state(p)
+    assert [a.rng_uniform() for _ in range(5)] == [b.rng_uniform() for _ in range(5)]
+    assert (a.rng_normal(8) == b.rng_normal(8)).all()
+    # the text is what the reference's fixtures hold: the fixture loads, saves back identically
+    fx = os.path.join(GOLDEN, "reference_assets", "test_autoregressive_seed.bin")
+    b.rng_load_state(fx)
+    b.rng_save_state(p)
+    assert open(p).read().split() == open(fx).read().split()
+    a.close(); b.close()

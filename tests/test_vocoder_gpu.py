@@ -36,3 +36,20 @@ def test_vocoder_batch_and_reference_noise(engine, oracle, small_models):
         err = np.abs(got[c] - want).max() / np.abs(want).max()
         assert err < 1e-3, (c, err)
     assert engine.rng_uniform() == rng.uniform()
+
+
+@pytest.mark.parametrize("T,chunk", [(150, 40), (57, 16), (9, 5), (300, 128)])
+def test_chunked_vocoder_reproduces_the_whole_utterance(engine, small_models, T, chunk):
+    """tts_vocoder_chunk (streaming): any partition of the T + 10 frames into chunks gives the samples of the one-shot call —
+    the halo covers the stack's receptive field, windows at a sequence end keep the reference's boundary treatment."""
+    engine.load(vocoder=small_models + "/ggml-vocoder-model.bin")
+    rs = np.random.RandomState(T)
+    mel = np.clip(rs.randn(100, T) * 0.5, -1, 1).astype(np.float32)
+    nz = rs.randn(64, T + 10).astype(np.float32)
+    whole = engine.vocoder([mel], noise=[nz])[0]
+    parts = [engine.vocoder_chunk(mel, nz, f0, min(chunk, T + 10 - f0)) for f0 in range(0, T + 10, chunk)]
+    got = np.concatenate(parts)
+    assert got.shape == whole.shape
+    err = float(np.abs(got - whole).max() / np.abs(whole).max())
+    print("chunked vocoder T=%d chunk=%d: %d chunks, rel diff vs one-shot %.1e" % (T, chunk, len(parts), err))
+    assert err <= 1e-6

@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""PyTorch checkpoints of tortoise-tts -> the reference's weight container.
+
+The reference's README promises export scripts that are not in its repository (/root/reference/README.md:34, 77); its loaders
+(main.cpp:682-792, 1244-1536, 1808-1923) define the contract: legacy-ggml container (magic 0x67676d6c, F32 records,
+no alignment), tensor names = the PyTorch state_dict keys of the inference modules, PyTorch dim order reversed into ne[], k = 1
+convolutions stored squeezed to 2-D. This tool produces exactly that from
+
+  autoregressive.pth      UnifiedVoice state dict. Either the `inference_model.*` keys (GPT2InferenceModel, present after
+                          post_init_gpt2_config) or the training-time names (gpt.h.N..., gpt.ln_f, final_norm, mel_head), which are mapped.
+  diffusion_decoder.pth   DiffusionTts state dict (+ --diffusion-conditioning-latent: the [1, 2048] diffusion conditioning latent of the
+                          voice, which the reference bakes into the file as `diffusion_conditioning_latent`).
+  vocoder.pth             UnivNet generator state dict (optionally under 'model_g'); weight_norm parametrisations (weight_g / weight_v) are fused.
+
+    python tools/convert_weights.py --ar autoregressive.pth --diffusion diffusion_decoder.pth --diffusion-conditioning-latent voice_diff.pth \\
+                                    --vocoder vocoder.pth --out models/
+
+The trained checkpoints are not available offline: tests/test_convert_weights.py round-trips synthetic weights through PyTorch-style state
+dicts (3-D k=1 convs, weight_norm pairs, training-time AR names) and requires the converter to reproduce the original container.
+"""
+import argparse
+import os
+import re
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import tortoise_cpp_amd_loader  # noqa: E402
+
+tortoise_cpp_amd_loader.load()
+from tortoise_cpp_amd.synth_weights import GgmlWriter  # noqa: E402
+
+
+def _np(t):
+    return t.detach().cpu().float().numpy() if hasattr(t, "detach") else np.asarray(t, np.float32)
+
+
+def fuse_weight_norm(sd):
+    """weight = g * v / ||v|| (norm over every dim but 0: torch.nn.utils.weight_norm's default dim=0)."""
+    out = {}
+    for k, v in sd.items():
+        if k.endswith(".weight_g"):
+            base = k[:-len(".weight_g")]
+            g, w = _np(v), _np(sd[base + ".weight_v"])
+            norm = np.sqrt((w.astype(np.float64) ** 2).sum(axis=tuple(range(1, w.ndim)), keepdims=True))
+            out[base + ".weight"] = (g.astype(np.float64) * w / norm).astype(np.float32)
+        elif k.endswith(".weight_v"):
+            continue
+        else:
+            out[k] = _np(v)
+    return out
+
+
+# ---- autoregressive (main.cpp:682-792) --------------------------------------------------------------------------------------------
+AR_GLOBAL = ["text_embedding.weight", "text_pos_embedding.emb.weight", "mel_embedding.weight", "mel_pos_embedding.emb.weight"]
+AR_TRAIN_TO_INFER = [(r"^gpt\.h\.", "inference_model.transformer.h."), (r"^gpt\.ln_f\.", "inference_model.transformer.ln_f."),
+                     (r"^final_norm\.", "inference_model.lm_head.0."), (r"^mel_head\.", "inference_model.lm_head.1.")]
+AR_LAYER = ["ln_1.weight", "ln_1.bias", "attn.c_attn.weight", "attn.c_attn.bias", "attn.c_proj.weight", "attn.c_proj.bias", "ln_2.weight",
+            "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias"]
+
+
+def convert_ar(sd, path):
+    sd = {k: _np(v) for k, v in sd.items()}
+    if not any(k.startswith("inference_model.") for k in sd):
+        for k in list(sd):
+            for pat, rep in AR_TRAIN_TO_INFER:
+                if re.match(pat, k):
+                    sd[re.sub(pat, rep, k)] = sd[k]
+    w = GgmlWriter(path)
+    for k in AR_GLOBAL:
+        w.add(k, sd[k])
+    n = 0
+    while "inference_model.transformer.h.%d.ln_1.weight" % n in sd:
+        for t in AR_LAYER:
+            w.add("inference_model.transformer.h.%d.%s" % (n, t), sd["inference_model.transformer.h.%d.%s" % (n, t)])
+        n += 1
+    for k in ("inference_model.transformer.ln_f.weight", "inference_model.transformer.ln_f.bias", "inference_model.lm_head.0.weight",
+              "inference_model.lm_head.0.bias", "inference_model.lm_head.1.weight", "inference_model.lm_head.1.bias"):
+        w.add(k, sd[k])
+    w.close()
+    return n
+
+
+# ---- diffusion (main.cpp:1244-1536) -----------------------------------------------------------------------------------------------
+def _attn_names(p):
+    return [p + s for s in (".norm.weight", ".norm.bias", ".qkv.weight", ".qkv.bias", ".proj_out.weight", ".proj_out.bias",
+                            ".relative_pos_embeddings.relative_attention_bias.weight")]
+
+
+def _res_names(p):
+    return [p + s for s in (".in_layers.0.weight", ".in_layers.0.bias", ".in_layers.2.weight", ".in_layers.2.bias", ".emb_layers.1.weight",
+                            ".emb_layers.1.bias", ".out_layers.0.weight", ".out_layers.0.bias", ".out_layers.3.weight", ".out_layers.3.bias")]
+
+
+SQUEEZE_K1 = re.compile(r"(\.qkv\.weight|\.proj_out\.weight|\.in_layers\.2\.weight|^integrating_conv\.weight)$")
+
+
+def convert_diffusion(sd, cond_latent, path):
+    sd = {k: _np(v) for k, v in sd.items()}
+    names = ["latent_conditioner.0.weight", "latent_conditioner.0.bias"]
+    n_lc = 0
+    while "latent_conditioner.%d.norm.weight" % (n_lc + 1) in sd:
+        n_lc += 1
+        names += _attn_names("latent_conditioner.%d" % n_lc)
+    names += ["code_norm.weight", "code_norm.bias", "time_embed.0.weight", "time_embed.0.bias", "time_embed.2.weight", "time_embed.2.bias"]
+    n_integ = 0
+    while "conditioning_timestep_integrator.%d.resblk.in_layers.0.weight" % n_integ in sd:
+        names += _res_names("conditioning_timestep_integrator.%d.resblk" % n_integ) + _attn_names("conditioning_timestep_integrator.%d.attn" % n_integ)
+        n_integ += 1
+    names += ["inp_block.weight", "inp_block.bias", "integrating_conv.weight", "integrating_conv.bias"]
+    n_main = 0
+    while "layers.%d.resblk.in_layers.0.weight" % n_main in sd:
+        names += _res_names("layers.%d.resblk" % n_main) + _attn_names("layers.%d.attn" % n_main)
+        n_main += 1
+    n_tail = 0
+    while "layers.%d.in_layers.0.weight" % (n_main + n_tail) in sd:
+        names += _res_names("layers.%d" % (n_main + n_tail))
+        n_tail += 1
+    names += ["out.0.weight", "out.0.bias", "out.2.weight", "out.2.bias"]
+    w = GgmlWriter(path)
+    w.add("diffusion_conditioning_latent", _np(cond_latent).reshape(1, 2048))
+    for k in names:
+        t = sd[k]
+        if SQUEEZE_K1.search(k) and t.ndim == 3:  # k = 1 convolutions are stored 2-D (main.cpp:1260, 1308, 1379)
+            assert t.shape[2] == 1, (k, t.shape)
+            t = t[:, :, 0]
+        w.add(k, t)
+    w.add("unconditioned_embedding", sd["unconditioned_embedding"].reshape(-1))
+    w.close()
+    return n_lc, n_integ, n_main, n_tail
+
+
+# ---- vocoder (main.cpp:1808-1923) -------------------------------------------------------------------------------------------------
+def convert_vocoder(sd, path):
+    if "model_g" in sd:
+        sd = sd["model_g"]
+    sd = fuse_weight_norm(sd)
+    w = GgmlWriter(path)
+    for k in ("conv_pre.weight", "conv_pre.bias"):
+        w.add(k, sd[k])
+    i = 0
+    while "res_stack.%d.convt_pre.1.weight" % i in sd:
+        p = "res_stack.%d." % i
+        kp = p + "kernel_predictor."
+        names = [kp + "input_conv.0.weight", kp + "input_conv.0.bias"]
+        c = 0
+        while kp + "residual_convs.%d.1.weight" % c in sd:
+            for j in (1, 3):
+                names += [kp + "residual_convs.%d.%d.weight" % (c, j), kp + "residual_convs.%d.%d.bias" % (c, j)]
+            c += 1
+        names += [kp + "kernel_conv.weight", kp + "kernel_conv.bias", kp + "bias_conv.weight", kp + "bias_conv.bias", p + "convt_pre.1.weight",
+                  p + "convt_pre.1.bias"]
+        c = 0
+        while p + "conv_blocks.%d.1.weight" % c in sd:
+            names += [p + "conv_blocks.%d.1.weight" % c, p + "conv_blocks.%d.1.bias" % c]
+            c += 1
+        for k in names:
+            w.add(k, sd[k])
+        i += 1
+    post = sd["conv_post.1.weight"]
+    w.add("conv_post.1.weight", post.reshape(post.shape[-2], post.shape[-1]))  # [1, 32, 7] -> [32, 7] (main.cpp:1919-1923)
+    w.add("conv_post.1.bias", sd["conv_post.1.bias"])
+    w.close()
+    return i
+
+
+def main():
+    import torch
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--ar")
+    ap.add_argument("--diffusion")
+    ap.add_argument("--diffusion-conditioning-latent", help=".pth / .npy / raw f32 file holding the voice's [1, 2048] diffusion conditioning latent")
+    ap.add_argument("--vocoder")
+    ap.add_argument("--out", required=True)
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    load = lambda p: torch.load(p, map_location="cpu", weights_only=True)
+    if a.ar:
+        print("ggml-model.bin: %d transformer layers" % convert_ar(load(a.ar), os.path.join(a.out, "ggml-model.bin")))
+    if a.diffusion:
+        if not a.diffusion_conditioning_latent:
+            sys.exit("--diffusion needs --diffusion-conditioning-latent (the reference bakes the voice's diffusion latent into the weight file)")
+        p = a.diffusion_conditioning_latent
+        lat = np.load(p) if p.endswith(".npy") else load(p) if p.endswith((".pth", ".pt")) else np.fromfile(p, np.float32)
+        print("ggml-diffusion-model.bin: blocks (latent conditioner, integrator, main, tail) = %s"
+              % (convert_diffusion(load(a.diffusion), lat, os.path.join(a.out, "ggml-diffusion-model.bin")),))
+    if a.vocoder:
+        print("ggml-vocoder-model.bin: %d res stacks" % convert_vocoder(load(a.vocoder), os.path.join(a.out, "ggml-vocoder-model.bin")))
+
+
+if __name__ == "__main__":
+    main()

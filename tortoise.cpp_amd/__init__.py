@@ -49,7 +49,7 @@ def lib():
         "tts_set_option": (ci, [vp, C.c_char_p, C.c_double]),
         "tts_load_ar": (ci, [vp, C.c_char_p]), "tts_load_diffusion": (ci, [vp, C.c_char_p]),
         "tts_load_vocoder": (ci, [vp, C.c_char_p]), "tts_ar_layers": (ci, [vp]), "tts_diffusion_layers": (ci, [vp]),
-        "tts_seed": (None, [vp, C.c_uint32]), "tts_rng_load_state": (ci, [vp, C.c_char_p]),
+        "tts_seed": (None, [vp, C.c_uint32]), "tts_rng_load_state": (ci, [vp, C.c_char_p]), "tts_rng_save_state": (ci, [vp, C.c_char_p]),
         "tts_rng_uniform": (cf, [vp]), "tts_rng_normal": (None, [vp, _f32p, C.c_int64]),
         "tts_tokenizer_load": (ci, [vp, C.c_char_p]), "tts_tokenize": (ci, [vp, C.c_char_p, _i32p, ci]),
         "tts_ar_begin": (ci, [vp, _i32p, ci, _f32p, ci, ci]), "tts_ar_prefill": (ci, [vp, _f32p]),
@@ -61,6 +61,7 @@ def lib():
         "tts_diffusion": (ci, [vp, _f32p, _i32p, ci, ci, vp, ci, _f32p]),
         "tts_vocoder_samples": (ci, [ci]),
         "tts_vocoder": (ci, [vp, _f32p, _i32p, ci, vp, ci, _f32p]),
+        "tts_vocoder_chunk": (ci, [vp, _f32p, ci, _f32p, ci, ci, _f32p, C.POINTER(ci)]),
         "tts_write_wav": (ci, [C.c_char_p, _f32p, C.c_int64, ci]),
         "tts_host_schedule": (ci, [ci, _i32p] + [_f32p] * 7), "tts_host_timestep_embedding": (None, [ci, _f32p]),
         "tts_host_rel_bucket": (ci, [ci, ci]), "tts_host_pad_codes": (ci, [_i32p, ci, _i32p]), "tts_host_trimmed_rows": (ci, [_i32p]),
@@ -132,6 +133,9 @@ class Engine:
 
     def rng_load_state(self, path):
         self._ck(self.L.tts_rng_load_state(self.h, path.encode()))
+
+    def rng_save_state(self, path):
+        self._ck(self.L.tts_rng_save_state(self.h, path.encode()))
 
     def rng_uniform(self):
         return self.L.tts_rng_uniform(self.h)
@@ -241,6 +245,15 @@ class Engine:
             out.append(audio[off:off + n].copy())
             off += n
         return out
+
+    def vocoder_chunk(self, mel, noise, frame0, n_frames):
+        """Samples of frames [frame0, frame0 + n_frames) of one utterance (mel [100,T], noise [64,T+10] of the whole utterance)."""
+        mel = np.ascontiguousarray(mel, np.float32)
+        noise = np.ascontiguousarray(noise, np.float32)
+        out = np.empty(n_frames * 256, np.float32)
+        n = C.c_int(0)
+        self._ck(self.L.tts_vocoder_chunk(self.h, mel.reshape(-1), mel.shape[1], noise.reshape(-1), frame0, n_frames, out, C.byref(n)))
+        return out[:n.value].copy()
 
     # ---- profiling ----
     def prof_reset(self, enable=True):

@@ -142,6 +142,13 @@ int tts_rng_load_state(tts_ctx *c, const char *path) {
   c->normal_distribution.reset();
   return fin ? TTS_OK : fail(c, TTS_ERR_FORMAT, "bad RNG state file '%s'", path);
 }
+int tts_rng_save_state(tts_ctx *c, const char *path) {
+  if (!c || !path) return TTS_ERR_ARG;
+  std::ofstream fout(path);
+  if (!fout) return fail(c, TTS_ERR_IO, "cannot open '%s' for writing", path);
+  fout << c->generator;
+  return fout ? TTS_OK : fail(c, TTS_ERR_IO, "cannot write '%s'", path);
+}
 float tts_rng_uniform(tts_ctx *c) { return c ? c->distribution(c->generator) : 0.f; }
 void tts_rng_normal(tts_ctx *c, float *out, int64_t n) { // sample_normal_noise, main.cpp:4695-4701
   if (!c || !out) return;
@@ -302,6 +309,37 @@ int tts_vocoder_samples(int T) { return (T + 10) * 256 - 6; }
 int tts_vocoder(tts_ctx *c, const float *mel, const int32_t *frames, int B, const float *noise, int noise_mode, float *audio) {
   NEED_CTX(c);
   return guarded(c, [&] { return voc_run(c, mel, frames, B, noise, noise_mode, audio); });
+}
+
+// Streaming form of the vocoder for first-audio latency: the UnivNet stack is fully convolutional, so the samples of frames
+// [frame0, frame0 + n_frames) depend only on mel / noise frames within a bounded halo (conv_pre k7, kernel predictor k5 + 6 x k3 + k3,
+// transposed convs, the dilated 1/3/9/27 convs of the 8-sample stage ~ 6 frames, conv_post k7): a window of the sequence with
+// VOC_HALO frames on either side reproduces them exactly; windows that touch a sequence end keep the reference's boundary treatment
+// (reflect pad / zero pad / the 10 silent frames) because they coincide with it.
+static const int VOC_HALO = 24;
+int tts_vocoder_chunk(tts_ctx *c, const float *mel, int T, const float *noise, int frame0, int n_frames, float *audio_out,
+                      int *n_samples_out) {
+  NEED_CTX(c);
+  if (!mel || !noise || !audio_out || T < 1 || n_frames < 1 || frame0 < 0 || frame0 >= T + 10)
+    return fail(c, TTS_ERR_ARG, "tts_vocoder_chunk: bad argument");
+  return guarded(c, [&] {
+    const int Tm = T + 10, f1 = std::min(Tm, frame0 + n_frames);
+    int w0 = std::max(0, frame0 - VOC_HALO), w1 = f1 + VOC_HALO;
+    if (w1 >= T) w1 = Tm;                                   // the window reaches the silent pad frames: take the true end
+    const int wt = (w1 == Tm ? T : w1) - w0;                // mel frames handed to the vocoder (it appends 10 pad frames itself)
+    std::vector<float> wm((size_t)100 * wt), wn((size_t)64 * (wt + 10)), wa((size_t)(wt + 10) * 256);
+    for (int ch = 0; ch < 100; ch++) memcpy(&wm[(size_t)ch * wt], mel + (size_t)ch * T + w0, (size_t)wt * 4);
+    for (int ch = 0; ch < 64; ch++)
+      for (int t = 0; t < wt + 10; t++) wn[(size_t)ch * (wt + 10) + t] = noise[(size_t)ch * Tm + std::min(w0 + t, Tm - 1)];
+    const int32_t frames = wt;
+    int rc = voc_run(c, wm.data(), &frames, 1, wn.data(), TTS_NOISE_REFERENCE, wa.data());
+    if (rc) return rc;
+    const int64_t total = (int64_t)Tm * 256 - 6, s0 = (int64_t)frame0 * 256, s1 = std::min<int64_t>((int64_t)f1 * 256, total);
+    const int64_t n = std::max<int64_t>(0, s1 - s0);
+    memcpy(audio_out, wa.data() + (s0 - (int64_t)w0 * 256), (size_t)n * 4);
+    if (n_samples_out) *n_samples_out = (int)n;
+    return (int)TTS_OK;
+  });
 }
 
 static void prof_resolve(tts_ctx *c) {
