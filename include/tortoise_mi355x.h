@@ -57,6 +57,9 @@ const char *tts_last_error(const tts_ctx *ctx);
  * "share_uncond" (1 default: in tts_diffusion the conditioning_timestep_integrator layers of the unconditioned branch,
  * whose input does not depend on the candidate, are evaluated once per distinct sequence length instead of once per
  * candidate; 0 = once per candidate. Same arithmetic per row either way),
+ * "ar_weights" (0 default: the decode step streams the f32 weights, reference numerics; 1 — set BEFORE tts_load_ar — the decode
+ * step streams fp16 copies (half the bytes; logits ~1e-3 off, so sampled ids diverge from the f32 mode after some steps: the
+ * throughput mode of SURVEY 8d; prefill and latent pass stay f32-exact),
  * "diff_graph" (1 default: tts_diffusion captures ONE sampling step — ~125 kernels, every per-step value read through a device-side step
  * counter — into a hipGraph and replays it; 0: every step is launched kernel by kernel), "prof_eager_every" (8: while a diff_* family is
  * being profiled every 8th step runs eagerly with its event pairs, the rest replay the graph),

@@ -162,3 +162,36 @@ def test_autoregressive_driver(engine, oracle, small_models, voice, B, seed):
     for c in range(B):
         assert rel_err(lats_g[c], lat_o[c, :rows_g[c]]) < 1e-3
     assert engine.rng_uniform() == rng.uniform()
+
+
+def test_fp16_decode_weights_option(pkg, oracle, small_models, voice):
+    """Option ar_weights = 1 (throughput mode): the decode step streams fp16 copies of the weights. Logits stay within 5e-3 of the
+    oracle's f32 evaluation (teacher-forced), differ from the f32 mode's, and the prompt pass / latent pass remain f32-exact."""
+    eng = pkg.Engine(0)
+    eng.set_option("ar_weights", 1)
+    eng.load(ar=small_models + "/ggml-model.bin")
+    ar = oracle.AR(oracle.Model(small_models + "/ggml-model.bin"))
+    toks, B = DEFAULT_TOKENS, 5
+    eng.ar_begin(toks, voice, B, 8)
+    ar.start(toks, voice, B, len(toks) + 2 + 9)
+    assert rel_err(eng.ar_prefill(), ar.prefill()) < 1e-4  # the prompt pass keeps the f32 weights
+    rs = np.random.RandomState(2)
+    errs = []
+    for i in range(6):
+        prev = rs.randint(0, 8192, B).astype(np.int32)
+        errs.append(rel_err(eng.ar_step(prev, i), ar.step(prev, i)))
+    print("fp16 decode weights: logits rel err per step", ["%.1e" % e for e in errs])
+    assert max(errs) < 5e-3 and max(errs) > 1e-5
+    codes = rs.randint(0, 8192, (B, 502)).astype(np.int32)
+    codes[:, 0] = 8192
+    assert rel_err(eng.ar_latents(codes, 12), ar.latents(codes, 12)) < 1e-4
+    eng.close()
+    # toggling the option on an engine loaded without the fp16 slabs is an error, not a silent f32 run
+    e2 = pkg.Engine(0)
+    e2.load(ar=small_models + "/ggml-model.bin")
+    e2.set_option("ar_weights", 1)
+    e2.ar_begin(toks, voice, 2, 4)
+    e2.ar_prefill()
+    with pytest.raises(pkg.TtsError):
+        e2.ar_step(np.array([1, 2], np.int32), 0)
+    e2.close()

@@ -106,6 +106,7 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
   else if (k == "share_uncond") c->share_uncond = value != 0;
   else if (k == "prof_stride") c->prof_stride = value < 1 ? 1 : (int)value;
   else if (k == "diff_graph") c->diff_graph = value != 0;
+  else if (k == "ar_weights") c->ar_weights = value != 0;
   else if (k == "prof_eager_every") c->prof_eager_every = value < 1 ? 1 : (int)value;
   else if (k == "rng_shard_offset") { if (value < 0) return fail(c, TTS_ERR_ARG, "rng_shard_offset < 0"); c->rng_shard_offset = (int)value; }
   else if (k == "rng_shard_total") { if (value < 0) return fail(c, TTS_ERR_ARG, "rng_shard_total < 0"); c->rng_shard_total = (int)value; }

@@ -340,7 +340,7 @@ struct DecLnArgs {
   const float *h;            // [rows][1024]
   const float *g1, *b1;      // DEC_LOGITS: ln_f (the LayerNorm feeding W is folded into W/bias at load)
   const float *W;            // pack_mfma16 of diag(gamma) W
-  const __half *Wh;          // pack_mfma16h: the same matrix x 64 as fp16 hi|lo pairs (SPLIT variant)
+  const __half *Wh;          // SPLIT 1: pack_mfma16h, the same matrix x 64 as fp16 hi|lo pairs; SPLIT 2: pack_mfma16q, fp16 hi only (option ar_weights = 1)
   const float *bias;         // bias + beta . W
   int rows, n_valid, ldo;    // ldo: row stride of `out` for DEC_QKV (q) and DEC_LOGITS
   int prefill_B;             // DEC_QKV: 0 = decode (row = candidate, position n_past); > 0 = prompt pass (row = position,
@@ -396,8 +396,11 @@ __device__ __forceinline__ void dec_layernorm(float4 (&x)[16], const float *__re
   }
 }
 
+// SPLIT: 0 = fp32 MFMA on f32 weights, 1 = split-precision fp16 MFMA (f32-exact to 2^-22), 2 = fp16 WEIGHTS (rounded once at load:
+// half the bytes streamed; the activations keep their hi + lo split) — the throughput mode of SURVEY 8d, option "ar_weights".
 template <int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
+  constexpr int SP = SPLIT ? 1 : 0;
   __shared__ float sred[4][4][16];
   __shared__ float4 accs[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, q = lane >> 4;
@@ -415,14 +418,20 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
   }
   float4 w[16]; // SPLIT: step s = (w[2s] = 8 fp16 hi, w[2s+1] = 8 fp16 lo) of 64*W[k = koff + 32 s + e][col]
   {
-    const float4 *wp = (SPLIT ? (const float4 *)a.Wh : (const float4 *)a.W) + ((size_t)(cb * 4 + wave) * 16) * 64;
+    if (SPLIT == 2) { // 8 steps x 16 B per lane: half the slab of the split variant
+      const float4 *wp = (const float4 *)a.Wh + ((size_t)(cb * 4 + wave) * 8) * 64;
 #pragma unroll
-    for (int i = 0; i < 16; i++) w[i] = SPLIT ? wp[((i >> 1) * 64 + lane) * 2 + (i & 1)] : wp[i * 64 + lane];
+      for (int i = 0; i < 8; i++) w[2 * i] = wp[i * 64 + lane];
+    } else {
+      const float4 *wp = (SPLIT ? (const float4 *)a.Wh : (const float4 *)a.W) + ((size_t)(cb * 4 + wave) * 16) * 64;
+#pragma unroll
+      for (int i = 0; i < 16; i++) w[i] = SPLIT ? wp[((i >> 1) * 64 + lane) * 2 + (i & 1)] : wp[i * 64 + lane];
+    }
   }
   DEC_T(1);
   // the (last) LayerNorm's gamma/beta are folded into W/bias; the head's ln_f keeps its own
-  if (EPI == DEC_LOGITS) dec_layernorm<SPLIT, SPLIT ? 32 : 16>(x, a.g1, a.b1, koff, sred, wave, m);
-  dec_layernorm<SPLIT, SPLIT ? 32 : 16>(x, nullptr, nullptr, koff, sred + (EPI == DEC_LOGITS ? 2 : 0), wave, m);
+  if (EPI == DEC_LOGITS) dec_layernorm<SP, SPLIT ? 32 : 16>(x, a.g1, a.b1, koff, sred, wave, m);
+  dec_layernorm<SP, SPLIT ? 32 : 16>(x, nullptr, nullptr, koff, sred + (EPI == DEC_LOGITS ? 2 : 0), wave, m);
   DEC_T(2);
   floatx4 acc;
   if (SPLIT) {
@@ -438,9 +447,12 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
         xh[e] = (_Float16)xs[e];
         xl[e] = (_Float16)(xs[e] - (float)xh[e]);
       }
-      const half8 wh = *(const half8 *)&w[2 * s], wl = *(const half8 *)&w[2 * s + 1];
+      const half8 wh = *(const half8 *)&w[2 * s];
       a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, a1, 0, 0, 0);
+      if (SPLIT == 1) {
+        const half8 wl = *(const half8 *)&w[2 * s + 1];
+        a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, a1, 0, 0, 0);
+      }
       a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, a2, 0, 0, 0);
     }
     acc = ((a1 + a2) + a0) * (1.0f / 64.0f);
@@ -502,7 +514,8 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
 // NT threads per workgroup (256 or 512): with 512 the K range of a thread halves and twice as many activation loads
 // are in flight per CU — the c_proj of the MLP (K = 4096) reads 256 KB of activations per workgroup and is bound by how
 // many of those loads the CU keeps in flight.
-template <int KG, int NT = 256>
+// WH: the slab holds fp16 weights (pack_cols4 order, 8 bytes per (k, 4 columns): option ar_weights = 1), converted to f32 in registers.
+template <int KG, int NT = 256, bool WH = false>
 __global__ __launch_bounds__(NT) void dec_gemv_resid_kernel(const float *__restrict__ X, int rows, const float *__restrict__ W,
                                                             const float *__restrict__ bias, float *__restrict__ h) {
   constexpr int K = 1024 * KG, NW = NT / 64, NG = K / (NT * 4); // NG K groups of NT*4 values per workgroup
@@ -516,11 +529,23 @@ __global__ __launch_bounds__(NT) void dec_gemv_resid_kernel(const float *__restr
   float4 w[NG][4];
   {
     // pack_cols4 order: float4 index ((k / 1024) * 4 + kk) * 256 + (k % 1024) / 4 for k = g * NT * 4 + 4 * tid + kk
-    const float4 *wp = (const float4 *)W + (size_t)cb * KG * 1024 + (tid & 255);
+    if (WH) {
+      const uint2 *wp = (const uint2 *)W + (size_t)cb * KG * 1024 + (tid & 255);
 #pragma unroll
-    for (int i = 0; i < NG; i++)
+      for (int i = 0; i < NG; i++)
 #pragma unroll
-      for (int kk = 0; kk < 4; kk++) w[i][kk] = wp[((i * (NT / 256) + (tid >> 8)) * 4 + kk) * 256];
+        for (int kk = 0; kk < 4; kk++) {
+          const uint2 u = wp[((i * (NT / 256) + (tid >> 8)) * 4 + kk) * 256];
+          const float2 f0 = __half22float2(*(const __half2 *)&u.x), f1 = __half22float2(*(const __half2 *)&u.y);
+          w[i][kk] = make_float4(f0.x, f0.y, f1.x, f1.y);
+        }
+    } else {
+      const float4 *wp = (const float4 *)W + (size_t)cb * KG * 1024 + (tid & 255);
+#pragma unroll
+      for (int i = 0; i < NG; i++)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) w[i][kk] = wp[((i * (NT / 256) + (tid >> 8)) * 4 + kk) * 256];
+    }
   }
   // Activations (L2 hits) are fetched 8 candidates at a time, double-buffered against the FMAs; K group i of the
   // weight slab is consumed for all 16 candidates as soon as it has arrived (vmcnt retires in order), so the
@@ -832,6 +857,7 @@ struct ArLayerDev {
   __half *dh_attn = nullptr, *dh_fc = nullptr; // pack_mfma16h of the same (split-precision variant)
   float *db_attn = nullptr, *db_fc = nullptr; // bias + ln beta . W
   float *d_proj = nullptr, *d_fc2 = nullptr;  // pack_cols4  (decode step)
+  __half *q_attn = nullptr, *q_fc = nullptr, *q_proj = nullptr, *q_fc2 = nullptr; // fp16-weight decode slabs (option ar_weights = 1 at load)
 };
 
 struct ArState {
@@ -841,6 +867,8 @@ struct ArState {
   float *lnf_g = nullptr, *lnf_b = nullptr, *lmh_g = nullptr, *lmh_b = nullptr;
   float *lm_w = nullptr /*[1024][VPAD] strip-major*/, *lm_b = nullptr /*[VPAD]*/, *d_lm = nullptr /*pack_mfma16, lm_head.0 folded*/, *d_lmb = nullptr;
   __half *dh_lm = nullptr; // pack_mfma16h
+  __half *q_lm = nullptr;  // pack_mfma16q (option ar_weights = 1 at load)
+  bool has_f16_weights = false;
   std::vector<void *> owned;
   // run state
   int B = 0, n_text = 0, P = 0, max_pos = 0;
@@ -857,15 +885,15 @@ struct ArState {
   hipGraphExec_t graph_exec = nullptr;
   // everything the captured step bakes into its nodes: the graph of the previous utterance is replayed when nothing moved
   struct GraphSig {
-    int B = 0, max_pos = 0, lut = 0;
+    int B = 0, max_pos = 0, lut = 0, wmode = 0;
     const void *p[10] = {};
     bool operator==(const GraphSig &o) const {
-      return B == o.B && max_pos == o.max_pos && lut == o.lut && std::equal(p, p + 10, o.p);
+      return B == o.B && max_pos == o.max_pos && lut == o.lut && wmode == o.wmode && std::equal(p, p + 10, o.p);
     }
   } graph_sig;
-  GraphSig current_sig(int lut) const {
+  GraphSig current_sig(int lut, int wmode) const {
     GraphSig g;
-    g.B = B; g.max_pos = max_pos; g.lut = lut;
+    g.B = B; g.max_pos = max_pos; g.lut = lut; g.wmode = wmode;
     const void *q[10] = {h.p, qkv.p, att.p, ff.p, kcache.p, vcache.p, d_toks.p, logits.p, h_toks, h_logits};
     std::copy(q, q + 10, g.p);
     return g;
@@ -944,6 +972,23 @@ static std::vector<__half> pack_mfma16h(const float *w, int K, int N) {
             t[base + e] = hi;
             t[base + 8 + e] = __float2half_rn(v - __half2float(hi));
           }
+  return t;
+}
+// pack_mfma16q: pack_mfma16h without the lo halves — fp16(64 w), 16 contiguous bytes per lane and K step (option ar_weights = 1).
+static std::vector<__half> pack_mfma16q(const float *w, int K, int N) {
+  std::vector<__half> t((size_t)K * N);
+  for (int cb = 0; cb < N / 16; cb++)
+    for (int wv = 0; wv < 4; wv++)
+      for (int s2 = 0; s2 < 8; s2++)
+        for (int lane = 0; lane < 64; lane++)
+          for (int e = 0; e < 8; e++)
+            t[((((size_t)cb * 4 + wv) * 8 + s2) * 64 + lane) * 8 + e] =
+                __float2half_rn(64.0f * w[(size_t)(wv * 256 + s2 * 32 + 8 * (lane >> 4) + e) * N + cb * 16 + (lane & 15)]);
+  return t;
+}
+static std::vector<__half> to_half(const std::vector<float> &v) {
+  std::vector<__half> t(v.size());
+  for (size_t i = 0; i < v.size(); i++) t[i] = __float2half_rn(v[i]);
   return t;
 }
 // pack_cols4 (K = 1024 KG): slab of workgroup cb (4 columns) = KG x 4 x 256 threads x float4 (the 4 columns),
@@ -1035,6 +1080,16 @@ int ar_load(tts_ctx *ctx, const char *path) {
     if ((r = upload(ctx, st.get(), cfold, &l.db_fc))) return r;
     if ((r = upload(ctx, st.get(), pack_cols4(wf.t.at(p + ".attn.c_proj.weight").data.data(), D, D), &l.d_proj))) return r;
     if ((r = upload(ctx, st.get(), pack_cols4(wf.t.at(p + ".mlp.c_proj.weight").data.data(), FF, D), &l.d_fc2))) return r;
+    if (ctx->ar_weights) { // fp16-weight decode slabs (same packing orders)
+      fold_layernorm(wf.t.at(p + ".attn.c_attn.weight").data.data(), D, 3 * D, wf.t.at(p + ".ln_1.weight").data.data(),
+                     wf.t.at(p + ".ln_1.bias").data.data(), wf.t.at(p + ".attn.c_attn.bias").data.data(), wfold, cfold);
+      if ((r = upload_h(ctx, st.get(), pack_mfma16q(wfold.data(), D, 3 * D), &l.q_attn))) return r;
+      fold_layernorm(wf.t.at(p + ".mlp.c_fc.weight").data.data(), D, FF, wf.t.at(p + ".ln_2.weight").data.data(),
+                     wf.t.at(p + ".ln_2.bias").data.data(), wf.t.at(p + ".mlp.c_fc.bias").data.data(), wfold, cfold);
+      if ((r = upload_h(ctx, st.get(), pack_mfma16q(wfold.data(), D, FF), &l.q_fc))) return r;
+      if ((r = upload_h(ctx, st.get(), to_half(pack_cols4(wf.t.at(p + ".attn.c_proj.weight").data.data(), D, D)), &l.q_proj))) return r;
+      if ((r = upload_h(ctx, st.get(), to_half(pack_cols4(wf.t.at(p + ".mlp.c_proj.weight").data.data(), FF, D)), &l.q_fc2))) return r;
+    }
   }
 #undef FETCH
 #undef FETCHT
@@ -1069,10 +1124,12 @@ int ar_load(tts_ctx *ctx, const char *path) {
                      wf.t.at("inference_model.lm_head.0.bias").data.data(), bt.data(), wfold, cfold);
       if (dec_f32_mfma) { r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, VPAD), &st->d_lm); if (r) return r; }
       r = upload_h(ctx, st.get(), pack_mfma16h(wfold.data(), D, VPAD), &st->dh_lm); if (r) return r;
+      if (ctx->ar_weights) { r = upload_h(ctx, st.get(), pack_mfma16q(wfold.data(), D, VPAD), &st->q_lm); if (r) return r; }
       r = upload(ctx, st.get(), cfold, &st->d_lmb); if (r) return r;
     }
     r = upload(ctx, st.get(), bt, &st->lm_b); if (r) return r;
   }
+  st->has_f16_weights = ctx->ar_weights != 0;
   if (ctx->ar) ar_free(ctx->ar);
   ctx->ar = st.release();
   return TTS_OK;
@@ -1293,29 +1350,37 @@ static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
   float *h = st->h.as<float>(), *q = st->qkv.as<float>(), *att = st->att.as<float>(), *ff = st->ff.as<float>();
   const StepState *ss = (const StepState *)(st->d_toks.as<int>() + B);
   const size_t layer_stride = (size_t)B * st->max_pos * D;
+  const bool wq = ctx->ar_weights != 0; // fp16 weights: half the bytes per step (throughput mode, not f32-exact)
+  if (wq && !st->has_f16_weights) return fail(ctx, TTS_ERR_STATE, "option ar_weights = 1 must be set before tts_load_ar (the fp16 slabs are packed at load)");
+  const double wb = wq ? 2.0 : 4.0;
   TTS_HIP(ctx, hipMemcpyAsync(st->d_toks.p, st->h_toks, (size_t)(B + 2) * 4, hipMemcpyHostToDevice, ctx->stream));
   embed_step_kernel<<<B, 256, 0, ctx->stream>>>(st->mel_emb, st->mel_pos, st->d_toks.as<int>(), ss, h);
   for (int l = 0; l < st->n_layers; l++) {
     const ArLayerDev &w = st->L[l];
     __half *kc = st->kcache.as<__half>() + l * layer_stride, *vc = st->vcache.as<__half>() + l * layer_stride;
-    { ProfScope ps(ctx, "ar_gemv", 3.0 * D * D * 4.0 * tiles);
-      DecLnArgs a{h, nullptr, nullptr, w.d_attn, w.dh_attn, w.db_attn, B, 3 * D, D, 0, q, kc, vc, ss, st->max_pos, ctx->ggml_lut};
-      DEC_LN_LAUNCH(DEC_QKV, dim3(3 * D / 16, tiles)); }
+    { ProfScope ps(ctx, "ar_gemv", 3.0 * D * D * wb * tiles);
+      DecLnArgs a{h, nullptr, nullptr, w.d_attn, wq ? w.q_attn : w.dh_attn, w.db_attn, B, 3 * D, D, 0, q, kc, vc, ss, st->max_pos, ctx->ggml_lut};
+      if (wq) dec_ln_gemv_kernel<DEC_QKV, 2><<<dim3(3 * D / 16, tiles), 256, 0, ctx->stream>>>(a);
+      else DEC_LN_LAUNCH(DEC_QKV, dim3(3 * D / 16, tiles)); }
     { ProfScope ps(ctx, "ar_attention");
       if (ctx->ggml_lut) attn_decode_kernel<<<dim3(B, NH), 256, 0, ctx->stream>>>(q, kc, vc, ss, st->max_pos, att, 1);
       else attn_decode_fast_kernel<<<dim3(B, NH), 256, 0, ctx->stream>>>(q, kc, vc, ss, st->max_pos, att); }
-    { ProfScope ps(ctx, "ar_gemv", 1.0 * D * D * 4.0 * tiles);
-      dec_gemv_resid_kernel<1><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, w.d_proj, w.b_proj, h); }
-    { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * 4.0 * tiles);
-      DecLnArgs a{h, nullptr, nullptr, w.d_fc, w.dh_fc, w.db_fc, B, FF, 0, 0, ff, nullptr, nullptr, ss, 0, ctx->ggml_lut};
-      DEC_LN_LAUNCH(DEC_GELU, dim3(FF / 16, tiles)); }
-    { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * 4.0 * tiles);
-      dec_gemv_resid_kernel<4, 512><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, w.d_fc2, w.b_fc2, h); }
+    { ProfScope ps(ctx, "ar_gemv", 1.0 * D * D * wb * tiles);
+      if (wq) dec_gemv_resid_kernel<1, 256, true><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, (const float *)w.q_proj, w.b_proj, h);
+      else dec_gemv_resid_kernel<1><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, w.d_proj, w.b_proj, h); }
+    { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * wb * tiles);
+      DecLnArgs a{h, nullptr, nullptr, w.d_fc, wq ? w.q_fc : w.dh_fc, w.db_fc, B, FF, 0, 0, ff, nullptr, nullptr, ss, 0, ctx->ggml_lut};
+      if (wq) dec_ln_gemv_kernel<DEC_GELU, 2><<<dim3(FF / 16, tiles), 256, 0, ctx->stream>>>(a);
+      else DEC_LN_LAUNCH(DEC_GELU, dim3(FF / 16, tiles)); }
+    { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * wb * tiles);
+      if (wq) dec_gemv_resid_kernel<4, 512, true><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, (const float *)w.q_fc2, w.b_fc2, h);
+      else dec_gemv_resid_kernel<4, 512><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, w.d_fc2, w.b_fc2, h); }
   }
-  { ProfScope ps(ctx, "ar_gemv", (double)D * VPAD * 4.0 * tiles);
-    DecLnArgs a{h, st->lnf_g, st->lnf_b, st->d_lm, st->dh_lm, st->d_lmb, B, V, V, 0, st->logits.as<float>(),
+  { ProfScope ps(ctx, "ar_gemv", (double)D * VPAD * wb * tiles);
+    DecLnArgs a{h, st->lnf_g, st->lnf_b, st->d_lm, wq ? st->q_lm : st->dh_lm, st->d_lmb, B, V, V, 0, st->logits.as<float>(),
                 nullptr, nullptr, ss, 0, ctx->ggml_lut};
-    DEC_LN_LAUNCH(DEC_LOGITS, dim3(VPAD / 16, tiles)); }
+    if (wq) dec_ln_gemv_kernel<DEC_LOGITS, 2><<<dim3(VPAD / 16, tiles), 256, 0, ctx->stream>>>(a);
+    else DEC_LN_LAUNCH(DEC_LOGITS, dim3(VPAD / 16, tiles)); }
   TTS_HIP(ctx, hipMemcpyAsync(st->h_logits, st->logits.p, (size_t)B * V * 4, hipMemcpyDeviceToHost, ctx->stream));
   TTS_HIP(ctx, hipGetLastError());
   return TTS_OK;
@@ -1340,7 +1405,7 @@ int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out
   if (prof_ar || no_graph) {
     CHECK(enqueue_decode_step(ctx, st));
   } else {
-    const ArState::GraphSig sig = st->current_sig(ctx->ggml_lut);
+    const ArState::GraphSig sig = st->current_sig(ctx->ggml_lut, ctx->ar_weights);
     if (st->graph_exec && !(sig == st->graph_sig)) st->drop_graph();
     if (!st->graph_exec) {
       st->graph_sig = sig;
@@ -1352,7 +1417,7 @@ int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out
       TTS_HIP(ctx, hipGraphInstantiate(&st->graph_exec, st->graph, nullptr, nullptr, 0));
     }
     // HBM-bound step: every weight once (f32: 12 d^2 per layer + the padded head) + the fp16 K/V rows read + logits
-    const double step_bytes = 4.0 * ((double)st->n_layers * 12.0 * D * D + (double)D * V) +
+    const double step_bytes = (ctx->ar_weights ? 2.0 : 4.0) * ((double)st->n_layers * 12.0 * D * D + (double)D * V) +
                               (double)st->B * st->n_layers * 2.0 * (st->P + step_i + 1) * D * 2.0 + (double)st->B * V * 4.0;
     ProfScope ps(ctx, "ar_decode_step", step_bytes);
     TTS_HIP(ctx, hipGraphLaunch(st->graph_exec, ctx->stream));

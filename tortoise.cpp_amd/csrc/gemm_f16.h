@@ -729,10 +729,10 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
     cus_per_xcd = cus / 8 > 0 ? cus / 8 : 32;
   }
   {
-    // default: the QKV projection only (fp16 outputs, 5.1 rounds at B = 16): alternate groups of 32 workgroups of an XCD start 16 us apart —
-    // measured 241.6 -> 221.6 us per launch (tools/gemm_diag: stag20/32). The f32-output GEMMs measured slower with any stagger (their first
-    // round is already the whole launch's critical path: 1.7 - 2.3 rounds).
-    const float us = gemm_stagger_us() >= 0 ? gemm_stagger_us() : (g.mode == GEMM_OUT_QKV ? 16.f : 0.f);
+    // OFF by default. Stand-alone (tools/gemm_diag, back-to-back launches of one shape) the QKV projection gained 8 % with groups of 32
+    // workgroups 20 us apart (241.6 -> 221.6 us) and the f32-output GEMMs lost 2-10 % with any stagger; inside the diffusion step the QKV
+    // default measured nothing (bench 129.9 vs 130.3-130.6 audio-s/s without): kept as a switch, documented in DESIGN.md.
+    const float us = gemm_stagger_us() >= 0 ? gemm_stagger_us() : 0.f;
     const int wgs_res = conv3 ? 3 : (g.mode == GEMM_OUT_QKV && qkv3) ? 3 : (g.mode == GEMM_OUT_F16 || (g.mode == GEMM_OUT_F32 && wgs3)) ? 3 : 4;
     gg.stagger_ticks = us > 0 ? (int)(us * 100.0f) : 0;
     gg.stagger_slots = cus_per_xcd * wgs_res;
