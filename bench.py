@@ -114,14 +114,18 @@ def cpu_baseline_once(model_dir, voice, toks, S, L_bench, n_diff_steps, quick, t
 def cpu_baseline(model_dir, voice, toks, S, L_bench, n_diff_steps, quick):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     nproc = os.cpu_count() or 1
-    runs = [cpu_baseline_once(model_dir, voice, toks, S, L_bench, n_diff_steps, quick, th) for th in sorted({min(4, nproc), nproc})]
+    # 4 threads = ggml's default team (what ./tortoise would use); 16 = the largest team that still scales for this restatement. A team of ALL
+    # host cores is NOT run by default: on the 256-thread GPU-box host it measured 0.00076 audio-s/s (30x slower than 4 threads: 33 s per decode
+    # step of fork/join overhead) and took 17 minutes; TTS_BENCH_CPU_ALL_CORES=1 adds it.
+    teams = sorted({min(4, nproc), min(16, nproc)} | ({nproc} if os.environ.get("TTS_BENCH_CPU_ALL_CORES") else set()))
+    runs = [cpu_baseline_once(model_dir, voice, toks, S, L_bench, n_diff_steps, quick, th) for th in teams]
     best = max(runs, key=lambda r: r["value"])
     return {
         "value": best["value"], "unit": "audio-seconds/sec", "cores": best["threads"], "kind": "port", "host_nproc": nproc,
         "runs": runs,
         "sample": "oracle (f32 C++/OpenMP restatement of the ggml graphs; the reference itself cannot be built: ggml submodule absent), "
-                  "B=1, at 4 OpenMP threads (ggml's default, what ./tortoise would use) and at all %d host cores; `value`/`cores` = the "
-                  "faster of the two. Measured per run: prompt pass, 24 decode steps, latent conditioner + two cond+uncond forward pairs at "
+                  "B=1, at 4 OpenMP threads (ggml's default, what ./tortoise would use) and at 16 (host: %d hardware threads; a team of all of them "
+                  "was measured 30x SLOWER than 4 threads on the 256-thread GPU-box host, DESIGN.md section 5); `value`/`cores` = the faster run. Measured per run: prompt pass, 24 decode steps, latent conditioner + two cond+uncond forward pairs at "
                   "the workload's own L=%d/T, the vocoder at the same T; extrapolated by repetition counts only (S=%d decode steps, %d "
                   "diffusion steps) to one candidate. Audio seconds = T*256/24000 (SURVEY 8d)" % (nproc, L_bench, S, n_diff_steps),
     }
