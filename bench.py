@@ -405,7 +405,7 @@ def main():
         "stage_ms_per_step": stages,
         "other_share_uncond_setting": other,
         "ar_weights_f16_option": f16,
-        "roofline": {"kernel": "gemm_f16_glds_kernel / gemm_f16_pers_kernel + gemm_f16_conv3_kernel (diffusion convs/projections)", "bound": "mfma",
+        "roofline": {"kernel": "gemm_f16_glds_kernel + gemm_f16_conv3_kernel (diffusion convs/projections)", "bound": "mfma",
                      "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
                      "traffic": traffic, "traffic_source": traffic_src, "launches_timed": int(g_n),
                      "launch_sampling": "every %dth launch of the family is bracketed by HIP events" % a.prof_stride,

@@ -2,8 +2,9 @@
 // the benchmark's shapes and, in the trace build, prints per-workgroup phase statistics from in-kernel wall-clock stamps
 // (gemm_f16.h, TTS_GEMM_TRACE): setup | first K tile (DMA round trip) | rest of the K loop | epilogue issue | store drain, plus the
 // dispatch timeline (workgroup starts per 5 us).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tortoise.cpp_amd/csrc [-DTTS_GEMM_TRACE] [-DTTS_GEMM_DIAG_NOEPI] tools/gemm_diag.hip -o gemm_diag
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I tortoise.cpp_amd/csrc -I tools [-DTTS_GEMM_TRACE] [-DTTS_GEMM_DIAG_NOEPI] tools/gemm_diag.hip -o gemm_diag
 //   hipcc ... -DTTS_GEMM_VARIANT=6 -I tools tools/gemm_diag.hip -o gemm_diag_v6      (the 8-phase 256^2 experiment kernel)
+#define TTS_GEMM_DIAG 1
 #include "gemm_f16.h"
 #include <algorithm>
 #include <cstdio>
@@ -57,7 +58,7 @@ int main(int argc, char **argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   // variants: classic, then the round stagger sweep (delay us, div)
   struct Var { const char *name; int bal; float us; int div; };
-  const std::vector<Var> vars = {{"classic", 0, 0.f, 1},      {"stag6/1", 0, 6.f, 1},   {"stag10/1", 0, 10.f, 1}, {"stag14/1", 0, 14.f, 1},
+  const std::vector<Var> vars = {{"classic", 0, 0.f, 1}, {"balanced", 1, 0.f, 1},      {"stag6/1", 0, 6.f, 1},   {"stag10/1", 0, 10.f, 1}, {"stag14/1", 0, 14.f, 1},
                                  {"stag20/1", 0, 20.f, 1},    {"stag30/1", 0, 30.f, 1}, {"stag10/32", 0, 10.f, 32}, {"stag20/32", 0, 20.f, 32},
                                  {"stag30/32", 0, 30.f, 32},  {"stag14/4", 0, 14.f, 4}, {"stag20/2", 0, 20.f, 2}};
   const int npers = (int)vars.size();
