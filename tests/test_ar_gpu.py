@@ -195,3 +195,30 @@ def test_fp16_decode_weights_option(pkg, oracle, small_models, voice):
     with pytest.raises(pkg.TtsError):
         e2.ar_step(np.array([1, 2], np.int32), 0)
     e2.close()
+
+
+def test_maximum_sizes(engine, oracle, small_models, voice):
+    """The reference's limits at once: 404 text ids (all text positions), 500 sampled codes (what apply_padding accepts, main.cpp:4517),
+    decode context 406 + 500 positions, the latent pass over all 502 mel positions (907 rows per candidate)."""
+    engine.load(ar=small_models + "/ggml-model.bin")
+    ar = oracle.AR(oracle.Model(small_models + "/ggml-model.bin"))
+    toks = np.random.RandomState(3).randint(1, 250, 404).astype(np.int32)
+    toks[0], toks[-1] = 255, 0
+    B, S = 2, 500
+    engine.ar_begin(toks, voice, B, S)
+    ar.start(toks, voice, B, len(toks) + 2 + S + 1)
+    errs = [rel_err(engine.ar_prefill(), ar.prefill())]
+    rs = np.random.RandomState(4)
+    for i in range(S - 1):
+        prev = rs.randint(0, 8192, B).astype(np.int32)
+        lo = ar.step(prev, i)
+        lg = engine.ar_step(prev, i)
+        if i in (0, 1, 250, 497, 498):
+            errs.append(rel_err(lg, lo))
+    print("max-size AR logits rel errs:", ["%.1e" % e for e in errs])
+    assert max(errs) < 1e-4
+    codes = rs.randint(0, 8192, (B, 502)).astype(np.int32)
+    codes[:, 0] = 8192
+    lg, lo = engine.ar_latents(codes, 502), ar.latents(codes, 502)
+    assert lg.shape == lo.shape == (B, 500, 1024)
+    assert rel_err(lg, lo) < 1e-4
