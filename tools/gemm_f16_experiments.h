@@ -191,7 +191,10 @@ static __global__ __launch_bounds__(256) void gemm_f16_ring_kernel(GemmArgs g) {
   };
   if (MODE == GEMM_OUT_QKV && natural) kloop(std::true_type{});
   else kloop(std::false_type{});
-  gemm_epilogue<MODE, 4>(g, acc, m0, n0, wm, wn, fr, fq);
+#ifdef TTS_GEMM_DIAG_NOEPI
+  if (g.ldo != -12345) return;
+#endif
+  gemm_epilogue<MODE, 4>(g, acc, m0, n0, wm, wn, fr, fq, g.M);
 }
 
 template <int NST>
@@ -287,7 +290,10 @@ static __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g) {
   };
   if (MODE == GEMM_OUT_QKV && natural) kloop(std::true_type{});
   else kloop(std::false_type{});
-  if (m0 + wm * 64 < g.M) gemm_epilogue<MODE, 4>(g, acc, m0, n0, wm, wn, fr, fq);
+#ifdef TTS_GEMM_DIAG_NOEPI
+  if (g.ldo != -12345) return;
+#endif
+  if (m0 + wm * 64 < g.M) gemm_epilogue<MODE, 4>(g, acc, m0, n0, wm, wn, fr, fq, g.M);
 }
 
 static inline hipError_t launch_gemm_big(const GemmArgs &g, hipStream_t s) {
