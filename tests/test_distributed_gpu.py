@@ -86,3 +86,31 @@ def test_bench_two_ranks_on_two_gpus():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["value"] > 0
+
+
+def test_cli_devices_shards_reproduce_the_single_process_batch(small_models, tmp_path):
+    """The product's own multi-GPU entry: `tortoise --candidates 4 --devices 2` re-executes itself once per device (here both workers
+    are mapped onto device 0 with --device-map 0,0: the GPU box has one), worker r takes candidates [2r, 2r + 2) of the ONE batch.
+    The four WAV files must be the ones a single process writes for --candidates 4 with the same seed."""
+    import shutil
+    exe = os.path.join(ROOT, "tortoise.cpp_amd", "tortoise")
+    if not os.path.exists(exe):
+        pytest.skip("CLI binary not built")
+    d = tmp_path / "models"
+    d.mkdir()
+    for f in ("ggml-model.bin", "ggml-diffusion-model.bin", "ggml-vocoder-model.bin"):
+        os.symlink(os.path.join(small_models, f), d / f)
+    shutil.copy(os.path.join(ROOT, "models", "tokenizer.json"), d / "tokenizer.json")
+    base = [exe, "--models", str(d), "--message", "this is a test message.", "--voice", os.path.join(ROOT, "models", "mol.bin"), "--seed", "3",
+            "--codes", "16", "--steps", "4", "--candidates", "4"]
+    outs = {}
+    for tag, extra in (("one", []), ("two", ["--devices", "2", "--device-map", "0,0"])):
+        out = tmp_path / (tag + ".wav")
+        r = subprocess.run(base + ["--output", str(out)] + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        files = [out] + [tmp_path / ("%s.wav.%d.wav" % (tag, c)) for c in range(1, 4)]
+        assert all(f.exists() for f in files), [f.name for f in files if not f.exists()]
+        outs[tag] = [np.frombuffer(f.read_bytes()[44:], np.float32) for f in files]
+    for c in range(4):
+        a, b = outs["one"][c], outs["two"][c]
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-4 * max(1e-6, np.abs(a).max()), c

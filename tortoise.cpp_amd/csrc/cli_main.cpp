@@ -10,7 +10,13 @@
 // and the tokenizer from ../models/tokenizer.json (main.cpp:5078, 5625, 6046, 6551).
 // Extensions (not in the reference): --models <dir>, --candidates <n> (all candidates are carried
 // through; candidate 0 is written to --output like the reference, others to <output>.<c>.wav),
-// --steps <n> diffusion steps (default 80), --device <ordinal>.
+// --steps <n> diffusion steps (default 80), --device <ordinal>, --codes <n>,
+// --devices <N> [--device-map a,b,...]: candidate-parallel multi-GPU run. The process re-executes itself once per GPU
+//   (one process per device, replicated weights); worker r takes candidates [r B/N, (r+1) B/N) of the ONE batch: the RNG stream
+//   partition (options rng_shard_offset / rng_shard_total) makes the N x B/N codes identical to a single-GPU run of B candidates,
+//   device noise is keyed by the global candidate id, and the throughput stop rule (TTS_AR_RETIRE) needs no per-step exchange.
+//   Nothing is exchanged between workers — candidates never interact — each writes its own candidates' WAV files
+//   (<output> for candidate 0, <output>.<c>.wav for the others, c = global candidate index).
 #include "tortoise_mi355x.h"
 #include <cstdio>
 #include <cstdlib>
@@ -18,6 +24,9 @@
 #include <iostream>
 #include <string>
 #include <vector>
+#include <sys/wait.h>
+#include <unistd.h>
+#include <chrono>
 
 static int die(tts_ctx *c, const char *what) {
   fprintf(stderr, "%s: %s\n", what, tts_last_error(c));
@@ -30,7 +39,8 @@ int main(int argc, char **argv) {
   std::string outputPath = "./output.wav";
   std::string modelsDir = "../models";
   bool have_seed = false;
-  int seed = 0, candidates = 1, steps = 80, device = 0, fixed_codes = 0;
+  int seed = 0, candidates = 1, steps = 80, device = 0, fixed_codes = 0, devices = 1, shard = -1, nshards = 1;
+  std::string device_map;
   for (int i = 1; i < argc - 1; ++i) {
     std::string a(argv[i]);
     if (a == "--voice") voicePath = argv[i + 1];
@@ -42,13 +52,62 @@ int main(int argc, char **argv) {
     else if (a == "--steps") steps = std::stoi(argv[i + 1]);
     else if (a == "--device") device = std::stoi(argv[i + 1]);
     else if (a == "--codes") fixed_codes = std::stoi(argv[i + 1]); // exactly N sampled codes, stop token masked (synthetic weights never stop)
+    else if (a == "--devices") devices = std::stoi(argv[i + 1]);
+    else if (a == "--device-map") device_map = argv[i + 1];
+    else if (a == "--shard") { // worker mode (set by the parent): "r/N"
+      std::string v(argv[i + 1]);
+      const size_t sl = v.find('/');
+      if (sl != std::string::npos) { shard = std::stoi(v.substr(0, sl)); nshards = std::stoi(v.substr(sl + 1)); }
+    }
   }
+  if (devices > 1 && shard < 0) { // parent: one worker process per GPU
+    if (candidates % devices) { fprintf(stderr, "--candidates %d does not divide over --devices %d\n", candidates, devices); return 1; }
+    std::vector<int> map;
+    for (size_t p = 0; p < device_map.size();) {
+      const size_t q = device_map.find(',', p);
+      map.push_back(std::stoi(device_map.substr(p, q == std::string::npos ? std::string::npos : q - p)));
+      if (q == std::string::npos) break;
+      p = q + 1;
+    }
+    if (!have_seed) // every worker must draw from the same stream
+      seed = (int)(std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count() & 0x7fffffff);
+    std::vector<pid_t> pids;
+    for (int r = 0; r < devices; r++) {
+      const pid_t pid = fork();
+      if (pid < 0) { perror("fork"); return 1; }
+      if (pid == 0) {
+        std::vector<std::string> args(argv, argv + argc);
+        const std::string extra[] = {"--shard", std::to_string(r) + "/" + std::to_string(devices), "--device",
+                                     std::to_string(r < (int)map.size() ? map[r] : r), "--seed", std::to_string(seed), "--end", "-"};
+        args.insert(args.end(), std::begin(extra), std::end(extra)); // later flags override earlier ones; "--end -" keeps the last pair inside i < argc-1
+        std::vector<char *> av;
+        for (auto &x : args) av.push_back(&x[0]);
+        av.push_back(nullptr);
+        execv("/proc/self/exe", av.data());
+        perror("execv");
+        _exit(127);
+      }
+      pids.push_back(pid);
+    }
+    int rc = 0;
+    for (pid_t pid : pids) {
+      int st = 0;
+      if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1;
+    }
+    return rc;
+  }
+  const int total_candidates = candidates;
+  if (shard >= 0) candidates = total_candidates / nshards;
   tts_ctx *ctx = tts_create(device);
   if (!ctx) {
     fprintf(stderr, "tts_create(%d) failed: no HIP device (this engine has no CPU path)\n", device);
     return 1;
   }
   if (have_seed) tts_seed(ctx, (uint32_t)seed);
+  if (shard >= 0) {
+    tts_set_option(ctx, "rng_shard_offset", (double)(shard * candidates));
+    tts_set_option(ctx, "rng_shard_total", (double)total_candidates);
+  }
   if (tts_tokenizer_load(ctx, (modelsDir + "/tokenizer.json").c_str()) < 0) return die(ctx, "tokenizer");
   std::vector<int32_t> tokens(4096);
   int n = tts_tokenize(ctx, message.c_str(), tokens.data(), (int)tokens.size());
@@ -66,7 +125,9 @@ int main(int argc, char **argv) {
   std::vector<int32_t> codes((size_t)B * 502), rows(B);
   std::vector<float> latents((size_t)B * 500 * 1024);
   int32_t nsteps = 0;
-  if (tts_autoregressive(ctx, tokens.data(), n, voice.data(), B, fixed_codes > 0 ? fixed_codes : 500, fixed_codes > 0 ? TTS_AR_MASK_STOP : 0,
+  // sharded batches use the throughput stop rule: the reference's "all B samples of one step are 8193" would need a per-step exchange
+  const unsigned ar_flags = (fixed_codes > 0 ? TTS_AR_MASK_STOP : 0) | (shard >= 0 ? TTS_AR_RETIRE : 0);
+  if (tts_autoregressive(ctx, tokens.data(), n, voice.data(), B, fixed_codes > 0 ? fixed_codes : 500, ar_flags,
                          codes.data(), rows.data(), latents.data(), &nsteps))
     return die(ctx, "autoregressive");
   printf("tokens sampled: %d\n", nsteps);
@@ -81,17 +142,18 @@ int main(int argc, char **argv) {
   }
   std::vector<float> mel(mel_total), audio(audio_total);
   // B == 1: the reference's exact RNG order (AR uniforms, x_T, per-step noise, vocoder noise)
-  const int noise_mode = (B == 1) ? TTS_NOISE_REFERENCE : TTS_NOISE_DEVICE;
+  const int noise_mode = (total_candidates == 1) ? TTS_NOISE_REFERENCE : TTS_NOISE_DEVICE;
   if (tts_diffusion(ctx, latents.data(), rows.data(), B, steps, nullptr, noise_mode, mel.data())) return die(ctx, "diffusion");
   if (tts_load_vocoder(ctx, (modelsDir + "/ggml-vocoder-model.bin").c_str())) return die(ctx, "vocoder_model_load");
   if (tts_vocoder(ctx, mel.data(), frames.data(), B, nullptr, noise_mode, audio.data())) return die(ctx, "vocoder");
   size_t off = 0;
   for (int c = 0; c < B; c++) {
     size_t ns = (size_t)tts_vocoder_samples(frames[c]);
-    std::string path = (c == 0) ? outputPath : outputPath + "." + std::to_string(c) + ".wav";
+    const int gc = (shard >= 0 ? shard * B : 0) + c; // global candidate index
+    std::string path = (gc == 0) ? outputPath : outputPath + "." + std::to_string(gc) + ".wav";
     if (tts_write_wav(path.c_str(), audio.data() + off, (int64_t)ns, 24000)) {
       std::cerr << "Error opening output file." << std::endl;
-    } else if (c == 0) {
+    } else if (gc == 0) {
       std::cout << "WAV file saved successfully. :^)" << std::endl;
     }
     off += ns;
