@@ -306,6 +306,10 @@ static __global__ __launch_bounds__(256, WGS) void gemm_f16_glds_kernel(GemmArgs
 // The weight tiles alternate between two LDS buffers: tap p+1's tile is requested before tap p's is waited for
 // (counted vmcnt + raw barrier), so only the slab load at the start of a chunk is exposed.
 template <int MI> constexpr int conv3_lds() { return (32 * MI + 8) * 128 + 2 * 16384; }
+// (Residual handling, measured: read in the epilogue as below 203-216 us; accumulators started from it 237-249 us — the pending loads sit in
+//  front of the pipelined weight DMA in the in-order vmcnt queue; "dripped" into the accumulators block by block inside the K loop by inline-asm
+//  loads with two phases of latency budget 210-225 us — the epilogue halves (20 -> 11 us per tile) but the K loop grows by 15 us: a true HBM read
+//  in the in-order queue gates the retirement of the L2-hit weight tiles behind it. profiles/r2_gemm_tile_phases.txt, c8/c9.)
 template <int MODE, int MI>
 static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_kernel(GemmArgs g) {
   constexpr int BM = 32 * MI, SLAB = (BM + 8) * 128;
@@ -327,8 +331,6 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_kernel(GemmArgs 
   GEMM_TR(0);
   const int prow = lane >> 3, pslot = lane & 7;
   const int fr = lane & 15, fq = lane >> 4;
-  // (residual-first accumulators, as in gemm_f16_glds_kernel, were measured SLOWER here: 237-249 vs 216-225 us —
-  //  the pending residual loads sit in front of the pipelined weight DMA in the in-order vmcnt queue)
   floatx4 acc[MI][4];
 #pragma unroll
   for (int i = 0; i < MI; i++)
@@ -365,35 +367,40 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_kernel(GemmArgs 
 #pragma unroll
     for (int i = 0; i < 4; i++) __builtin_amdgcn_global_load_lds((gptr_t)(src + boff[i]), (lptr_t)(dst + (wave * 4 + i) * 1024), 16, 0, 0);
   };
+  // one phase; TAP = p % 3 is compile-time (the caller unrolls the three taps of a K chunk)
+  auto phase = [&](int kc, int p, auto tap_c) {
+    constexpr int TAP = decltype(tap_c)::value;
+    stageB(p + 1); // its buffer was last read in phase p-1, which every wave has left (trailing barrier)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // all but the 4 pieces just issued: B(p) and the slab have landed
+    __builtin_amdgcn_s_barrier();
+#ifdef TTS_GEMM_TRACE
+    if (p == 0) GEMM_TR(2);
+#endif
+    const char *sbp = sb + (p & 1) * 16384;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      half8 af[MI], bf[4];
+#pragma unroll
+      for (int i = 0; i < MI; i++) af[i] = *(const half8 *)(sa + lds_off(wm * (16 * MI) + i * 16 + fr + TAP, ks * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < 4; i++) bf[i] = *(const half8 *)(sbp + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier(); // every wave is done reading the slab and B(p)
+    if (TAP == 2) stageA(kc + 1);
+  };
   stageA(0);
   stageB(0);
   GEMM_TR(1);
-  for (int kc = 0, p = 0; kc < nchunks; kc++) {
-#pragma unroll
-    for (int tap = 0; tap < 3; tap++, p++) {
-      stageB(p + 1); // its buffer was last read in phase p-1, which every wave has left (trailing barrier)
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); // all but the 4 pieces just issued: B(p) and the slab have landed
-      __builtin_amdgcn_s_barrier();
-#ifdef TTS_GEMM_TRACE
-      if (p == 0) GEMM_TR(2);
-#endif
-      const char *sbp = sb + (p & 1) * 16384;
-#pragma unroll
-      for (int ks = 0; ks < 2; ks++) {
-        half8 af[MI], bf[4];
-#pragma unroll
-        for (int i = 0; i < MI; i++) af[i] = *(const half8 *)(sa + lds_off(wm * (16 * MI) + i * 16 + fr + tap, ks * 4 + fq));
-#pragma unroll
-        for (int i = 0; i < 4; i++) bf[i] = *(const half8 *)(sbp + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
-#pragma unroll
-        for (int i = 0; i < MI; i++)
-#pragma unroll
-          for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier(); // every wave is done reading the slab and B(p)
-      if (tap == 2) stageA(kc + 1);
-    }
+  for (int kc = 0; kc < nchunks; kc++) {
+    const int p = 3 * kc;
+    phase(kc, p, std::integral_constant<int, 0>{});
+    phase(kc, p + 1, std::integral_constant<int, 1>{});
+    phase(kc, p + 2, std::integral_constant<int, 2>{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // trailing (clamped) pieces must land before the LDS is released
   GEMM_TR(3);
@@ -408,7 +415,6 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_kernel(GemmArgs 
 #endif
   GEMM_TR_FLUSH(blockIdx.x);
 }
-
 
 #ifdef TTS_GEMM_DIAG // tools/gemm_diag.hip only (compiled with -I tools): the measured-and-rejected balanced persistent kernels
 #include "gemm_f16_balanced.h"
@@ -487,14 +493,14 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
 #endif
 #define TTS_LAUNCH_MI(MI_)                                                                                              \
   do {                                                                                                                  \
-    if (conv3) {                                                                                                               \
+    if (conv3) {                                                                                                        \
       static bool attr = false;                                                                                         \
       if (!attr) {                                                                                                      \
         (void)hipFuncSetAttribute((const void *)gemm_f16_conv3_kernel<GEMM_OUT_F32, MI_>, hipFuncAttributeMaxDynamicSharedMemorySize, conv3_lds<MI_>()); \
         (void)hipFuncSetAttribute((const void *)gemm_f16_conv3_kernel<GEMM_OUT_F16, MI_>, hipFuncAttributeMaxDynamicSharedMemorySize, conv3_lds<MI_>()); \
         attr = true;                                                                                                    \
       }                                                                                                                 \
-      if (g.mode == GEMM_OUT_F32) gemm_f16_conv3_kernel<GEMM_OUT_F32, MI_><<<grid1, 256, conv3_lds<MI_>(), s>>>(gg);     \
+      if (g.mode == GEMM_OUT_F32) gemm_f16_conv3_kernel<GEMM_OUT_F32, MI_><<<grid1, 256, conv3_lds<MI_>(), s>>>(gg); \
       else gemm_f16_conv3_kernel<GEMM_OUT_F16, MI_><<<grid1, 256, conv3_lds<MI_>(), s>>>(gg);                            \
     } else if (g.mode == GEMM_OUT_F32 && wgs3) gemm_f16_glds_kernel<GEMM_OUT_F32, MI_><<<grid1, 256, 0, s>>>(gg);        \
     else if (g.mode == GEMM_OUT_F32) gemm_f16_glds_kernel<GEMM_OUT_F32, MI_, (MI_ <= 4 ? 4 : 3)><<<grid1, 256, 0, s>>>(gg); \
