@@ -195,3 +195,32 @@ def test_config2_batch16(full_engine, oracle, full_models, voice, pkg):
     ov = oracle.Vocoder(oracle.Model(full_models + "/ggml-vocoder-model.bin"))
     for c in (0, 15):
         assert rel_err(aus[c], ov.run(mels[c], noise=nz[c])) < 1e-3
+
+
+def test_config2_full_shape_batch_invariance(full_engine, pkg):
+    """configs[2] at its REAL shapes — 16 candidates of L = 200 latent rows (T = 870), 80 diffusion steps, full-size weights, device noise, the
+    vocoder on all 16 — against the single-candidate path on the same inputs: candidate c of the batch (32 sequences in one row space, shared
+    unconditioned integrator, 128-row GEMM tiles) must equal candidate c run alone (2 sequences, 64-row tiles) with the same noise stream
+    (stream = global candidate id, option rng_shard_offset). A size-independent property: no oracle run is needed at this size, and the
+    single-candidate path is the one the oracle checks at T = 870 (test_diffusion_forward_full_depth)."""
+    eng = full_engine
+    B, L = 16, 200
+    rs = np.random.RandomState(21)
+    lats = [rs.randn(L, 1024).astype(np.float32) for _ in range(B)]
+    eng.seed(99)
+    mels = eng.diffusion(lats, n_steps=80, noise_mode=pkg.NOISE_DEVICE)
+    audio = eng.vocoder(mels, noise_mode=pkg.NOISE_DEVICE)
+    assert all(m.shape == (100, 870) and np.isfinite(m).all() and np.abs(m).max() <= 1.0 + 1e-6 for m in mels)
+    try:
+        for c in (0, 7, 15):
+            eng.set_option("rng_shard_offset", c)
+            eng.set_option("rng_shard_total", B)
+            eng.seed(99)
+            m1 = eng.diffusion([lats[c]], n_steps=80, noise_mode=pkg.NOISE_DEVICE)[0]
+            a1 = eng.vocoder([m1], noise_mode=pkg.NOISE_DEVICE)[0]
+            dm, da = float(np.abs(m1 - mels[c]).max()), float(np.abs(a1 - audio[c]).max() / np.abs(audio[c]).max())
+            print("configs[2] full shape, candidate %d: batch-of-16 vs alone: mel max abs diff %.1e, audio rel diff %.1e" % (c, dm, da))
+            assert dm <= 1e-5 and da <= 1e-5
+    finally:
+        eng.set_option("rng_shard_offset", 0)
+        eng.set_option("rng_shard_total", 0)
