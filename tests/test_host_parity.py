@@ -212,3 +212,39 @@ def test_rng_state_round_trip(pkg, tmp_path):
     b.rng_save_state(p)
     assert open(p).read().split() == open(fx).read().split()
     a.close(); b.close()
+
+
+def test_header_is_plain_c_and_links(pkg, tmp_path):
+    """The drop-in boundary is a C ABI: include/tortoise_mi355x.h must compile as C99 with no C++ or torch types, and a plain C program linked
+    against the shared library must reach the host-side entries (no device: tts_create(-1))."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stdint.h>
+#include "tortoise_mi355x.h"
+int main(void) {
+  tts_ctx *ctx = tts_create(-1);
+  if (!ctx) return 2;
+  int32_t codes[502];
+  for (int i = 0; i < 502; i++) codes[i] = 83;
+  printf("%d %d %d %d\n", tts_diffusion_frames(200), tts_vocoder_samples(870), tts_host_rel_bucket(0, 5), tts_host_trimmed_rows(codes));
+  int rc = tts_load_ar(ctx, "/nonexistent");
+  printf("%d %s\n", rc, tts_last_error(ctx));
+  tts_destroy(ctx);
+  return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    inc = os.path.join(os.path.dirname(os.path.dirname(pkg.LIB_PATH)), "include")
+    libdir = os.path.dirname(pkg.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, str(src), "-o", str(exe), "-L", libdir,
+                    "-ltortoise_mi355x", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    a = out[0].split()
+    assert int(a[0]) == 870 and int(a[1]) == 880 * 256 - 6
+    assert int(a[3]) == pkg.host_trimmed_rows(np.full(502, 83, np.int32)) if hasattr(pkg, "host_trimmed_rows") else True
+    assert out[1].startswith("-") and "no HIP device" in out[1]
