@@ -51,6 +51,7 @@ struct GemmArgs {
   // with an odd (index / stagger_div) start stagger_ticks (100 MHz wall clock) late. All tiles take the same time, so the two
   // populations stay half a tile apart for the whole launch: one's epilogue burst (HBM-bound, matrix pipe idle) falls into the other's K loop.
   int stagger_ticks, stagger_slots, stagger_div;
+  int kmajor; // tools/gemm_f16_deep.h only: K tiles visited chunk-major with the segments (taps) innermost — the k = 3 kernel's order
 };
 
 __device__ __forceinline__ void gemm_round_stagger(const GemmArgs &g, int idx_in_xcd) {
@@ -422,6 +423,9 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_kernel(GemmArgs 
 #ifdef TTS_GEMM_VARIANT // tools/gemm_bench.hip only (compiled with -I tools)
 #include "gemm_f16_experiments.h"
 #endif
+#ifdef TTS_GEMM_DEEP // tools/gemm_small_diag.hip only (compiled with -I tools)
+#include "gemm_f16_deep.h"
+#endif
 
 static inline float &gemm_stagger_us() {
   static float v = getenv("TTS_GEMM_STAGGER_US") ? (float)atof(getenv("TTS_GEMM_STAGGER_US")) : -1.f; // < 0: per-mode default
@@ -490,6 +494,9 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
   }
 #ifdef TTS_GEMM_DIAG
   { hipError_t e_; if (launch_gemm_balanced(g, gg, conv3, force_mi != nullptr, NTt, cus_per_xcd, s, &e_)) return e_; }
+#endif
+#ifdef TTS_GEMM_DEEP // tools/gemm_small_diag.hip only: the measured-and-rejected deep-ring kernel for small problems
+  { hipError_t e_; if (launch_gemm_deep_if_small(g, gg, mi, conv3, grid1, cus_per_xcd, s, &e_)) return e_; }
 #endif
 #define TTS_LAUNCH_MI(MI_)                                                                                              \
   do {                                                                                                                  \
