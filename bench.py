@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU plumbing test with --dry-engine)")
     ap.add_argument("--dry-engine", action="store_true", help="no device work: host-only contexts, fake stage outputs (tests of the launch / collective plumbing)")
     ap.add_argument("--models", default=None)
+    ap.add_argument("--device-map", default=None, help="comma list: HIP device of each local rank (default: LOCAL_RANK). `--backend gloo --device-map 0,0` "
+                                                       "runs two real engines on one GPU (test of the N > 1 path on a one-GPU box; RCCL needs one GPU per rank)")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -172,14 +174,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    device = local_rank
+    if a.device_map:
+        dm = [int(x) for x in a.device_map.split(",")]
+        if len(dm) <= local_rank:
+            sys.exit("bench.py: --device-map has %d entries, local rank %d" % (len(dm), local_rank))
+        if a.backend == "nccl" and len(set(dm)) != len(dm):
+            sys.exit("bench.py: RCCL needs a distinct GPU per rank (--device-map %s); use --backend gloo to share a device" % a.device_map)
+        device = dm[local_rank]
     dist = None
     dev = None
     if world > 1:
         import torch
         import torch.distributed as dist
         if a.backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            dev = torch.device("cuda", local_rank)
+            torch.cuda.set_device(device)
+            dev = torch.device("cuda", device)
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
         else:
             dev = torch.device("cpu")
@@ -229,7 +239,7 @@ def main():
         eng.L = pkg.lib()
         eng.h = eng.L.tts_create(-1)
     else:
-        eng = pkg.Engine(local_rank)  # raises without the HIP library/device: there is no fallback path
+        eng = pkg.Engine(device)  # raises without the HIP library/device: there is no fallback path
         if world > 1:  # N processes share the host: leave each rank's sampler pool its share of the cores
             eng.set_option("sampler_threads", max(0, min(7, (os.cpu_count() or 8) // world - 2)))
         eng.load(model_dir)
@@ -346,7 +356,7 @@ def main():
         t0 = time.time()
         c32, _, _, _ = eng.autoregressive(prompts[0], voice, B, S, mask_stop=True)
         t32 = time.time() - t0
-        e2 = pkg.Engine(local_rank)
+        e2 = pkg.Engine(device)
         e2.set_option("ar_weights", 1)
         e2.load(ar=os.path.join(model_dir, "ggml-model.bin"))
         e2.seed(4242)

@@ -88,6 +88,23 @@ def test_bench_two_ranks_on_two_gpus():
     assert out["n_gpus"] == 2 and out["value"] > 0
 
 
+def test_bench_two_ranks_share_one_gpu():
+    """bench.py's whole N > 1 path with REAL engines on a one-GPU box: it launches its own two ranks (torch.distributed.run, 127.0.0.1), both
+    ranks create their context on device 0 (`--device-map 0,0`), gloo carries the prompt / voice broadcast and the audio gather (RCCL needs one
+    GPU per rank). configs[3] shape: one batch of 4 candidates sharded 2 + 2 with the RNG stream partition."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device-map", "0,0", "--quick", "--config", "4",
+           "--candidates", "4", "--steps", "1", "--warmup", "0", "--decode-steps", "8", "--diff-steps", "4", "--no-cpu-baseline", "--no-ab"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["config"]["candidates_per_gpu"] == 2
+    assert "roofline" in out and out["roofline"]["launches_timed"] > 0
+
+
 def test_cli_devices_shards_reproduce_the_single_process_batch(small_models, tmp_path):
     """The product's own multi-GPU entry: `tortoise --candidates 4 --devices 2` re-executes itself once per device (here both workers
     are mapped onto device 0 with --device-map 0,0: the GPU box has one), worker r takes candidates [2r, 2r + 2) of the ONE batch.
