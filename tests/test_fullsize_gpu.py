@@ -5,6 +5,8 @@ so the reduced-depth tests in test_ar_gpu.py / test_diffusion_gpu.py do not cove
 
 Gates: AR logits 1e-4 relative (f32 on both sides), latents and mel/audio 1e-3 relative (north star), the sampling loop the
 reference's own gate abs 0.01 (main.cpp:6223). configs[1] = test_config1_end_to_end, configs[2] = test_config2_batch16."""
+import os
+
 import numpy as np
 import pytest
 
@@ -224,3 +226,19 @@ def test_config2_full_shape_batch_invariance(full_engine, pkg):
     finally:
         eng.set_option("rng_shard_offset", 0)
         eng.set_option("rng_shard_total", 0)
+
+
+@pytest.mark.skipif(not os.environ.get("TTS_LONG_TESTS"), reason="about 3 minutes of oracle time on the host: run with TTS_LONG_TESTS=1 (result in DESIGN.md section 4)")
+def test_full_size_80_steps_at_bench_length(full_engine, oracle, full_models):
+    """The benchmark's own diffusion problem for one candidate — full-size weights, L = 200 latent rows, T = 870 mel frames, all 80 steps — against
+    the oracle with the same explicit noise, at the reference's gate (max abs 0.01, main.cpp:6223). 160 full-size oracle forwards: opt-in."""
+    L = 200
+    od = oracle.Diffusion(oracle.Model(full_models + "/ggml-diffusion-model.bin"))
+    lat = np.random.RandomState(31).randn(L, 1024).astype(np.float32)
+    T = full_engine.frames(L)
+    noise = np.random.RandomState(6).randn(81, 100 * T).astype(np.float32)
+    mel = full_engine.diffusion([lat], n_steps=80, noise=[noise])[0]
+    want = od.sample(lat, n_steps=80, noise=noise)
+    err = np.abs(mel - want)
+    print("full-size 80-step loop at T=%d: max abs %.2e mean %.2e" % (T, err.max(), err.mean()))
+    assert T == 870 and np.abs(want).max() <= 1.5 and err.max() <= 0.01, (err.max(), err.mean())
