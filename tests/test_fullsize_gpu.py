@@ -71,16 +71,16 @@ def test_diffusion_forward_full_depth(full_engine, oracle, full_models, L):
         assert got.shape == want.shape == (200, T) and e < 1e-3, e
 
 
-def test_vocoder_full(full_engine, oracle, full_models):
+@pytest.mark.parametrize("T", [187, 870])  # the reference fixture's length and the benchmark's
+def test_vocoder_full(full_engine, oracle, full_models, T):
     eng = full_engine
     ov = oracle.Vocoder(oracle.Model(full_models + "/ggml-vocoder-model.bin"))
-    T = 187
     rs = np.random.RandomState(3)
     mel = np.clip(rs.randn(100, T) * 0.5, -1, 1).astype(np.float32)
     nz = rs.randn(64, T + 10).astype(np.float32)
     au, ao = eng.vocoder([mel], noise=[nz])[0], ov.run(mel, noise=nz)
     e = rel_err(au, ao)
-    print("vocoder T=187 rel err %.2e" % e)
+    print("vocoder T=%d rel err %.2e" % (T, e))
     assert au.shape == ao.shape and e < 1e-3
 
 
@@ -242,3 +242,24 @@ def test_full_size_80_steps_at_bench_length(full_engine, oracle, full_models):
     err = np.abs(mel - want)
     print("full-size 80-step loop at T=%d: max abs %.2e mean %.2e" % (T, err.max(), err.mean()))
     assert T == 870 and np.abs(want).max() <= 1.5 and err.max() <= 0.01, (err.max(), err.mean())
+
+
+@pytest.mark.skipif(not os.environ.get("TTS_LONG_TESTS"), reason="about 2 minutes of oracle time on the host: run with TTS_LONG_TESTS=1 (result in DESIGN.md section 4)")
+def test_full_size_ar_192_steps_teacher_forced(full_engine, oracle, full_models, voice):
+    """The benchmark's own AR problem: 30 layers, the 64-token prompt, 16 candidates, all 192 decode steps (context 68 .. 260), the oracle replaying the
+    device's sampled ids; logits of every step within 1e-4, then the latent pass over the full L = 200 rows for candidates 0 and 15."""
+    eng = full_engine
+    toks, B, S = bench_prompt(), 16, 192
+    eng.seed(5)
+    codes, rows, lats, steps = eng.autoregressive(toks, voice, B, S, mask_stop=True)
+    assert steps == S and int(rows[0]) == 200
+    ar = oracle.AR(oracle.Model(full_models + "/ggml-model.bin"))
+    ar.start(toks, voice, B, len(toks) + 2 + S + 1)
+    eng.ar_begin(toks, voice, B, S)
+    worst = rel_err(eng.ar_prefill(), ar.prefill())
+    for i in range(S - 1):
+        worst = max(worst, rel_err(eng.ar_step(codes[:, 1 + i], i), ar.step(codes[:, 1 + i], i)))
+    lat_o = ar.latents(codes[[0, 15]], 201)
+    e_lat = max(rel_err(lats[c], lat_o[k, :200]) for k, c in enumerate((0, 15)))
+    print("full-size AR, 16 candidates x 192 steps teacher-forced: worst logits rel err %.1e; latents (200 rows) rel err %.1e" % (worst, e_lat))
+    assert worst < 1e-4 and e_lat < 1e-3
