@@ -244,7 +244,6 @@ def test_full_size_80_steps_at_bench_length(full_engine, oracle, full_models):
     assert T == 870 and np.abs(want).max() <= 1.5 and err.max() <= 0.01, (err.max(), err.mean())
 
 
-@pytest.mark.skipif(not os.environ.get("TTS_LONG_TESTS"), reason="about 2 minutes of oracle time on the host: run with TTS_LONG_TESTS=1 (result in DESIGN.md section 4)")
 def test_full_size_ar_192_steps_teacher_forced(full_engine, oracle, full_models, voice):
     """The benchmark's own AR problem: 30 layers, the 64-token prompt, 16 candidates, all 192 decode steps (context 68 .. 260), the oracle replaying the
     device's sampled ids; logits of every step within 1e-4, then the latent pass over the full L = 200 rows for candidates 0 and 15."""
