@@ -84,6 +84,22 @@ def test_sampling_loop_matches_oracle(engine, oracle, small_models):
         assert err.max() <= 0.01, (c, err.max(), err.mean())
 
 
+def test_sampling_loop_200_steps_config5(engine, oracle, small_models):
+    """configs[4] runs 200 diffusion steps (timestep_map = round(i * 3999 / 199), the generalisation the reference hard-codes away for 80): the
+    device loop over that schedule against the oracle's, same explicit noise (201 vectors), the reference's gate max abs 0.01."""
+    engine.load(diffusion=small_models + "/ggml-diffusion-model.bin")
+    od = oracle.Diffusion(oracle.Model(small_models + "/ggml-diffusion-model.bin"))
+    lat = _latents(9, 3)
+    T = engine.frames(9)
+    noise = np.random.RandomState(8).randn(201, 100 * T).astype(np.float32)
+    mel = engine.diffusion([lat], n_steps=200, noise=[noise])[0]
+    want = od.sample(lat, n_steps=200, noise=noise)
+    err = np.abs(mel - want)
+    print("200-step sampling loop (T=%d): max abs %.2e mean %.2e" % (T, err.max(), err.mean()))
+    assert mel.shape == want.shape == (100, T) and np.isfinite(mel).all() and np.abs(mel).max() <= 1.0 + 1e-6
+    assert err.max() <= 0.01, (err.max(), err.mean())
+
+
 def test_reference_noise_stream(engine, oracle, small_models):
     """noise_mode REFERENCE consumes the ctx RNG exactly like the reference: x_T then one vector per step."""
     engine.load(diffusion=small_models + "/ggml-diffusion-model.bin")
