@@ -153,7 +153,7 @@ def test_config2_batch16(full_engine, oracle, full_models, voice, pkg):
     """configs[2] at the benchmark's own shapes: 16 candidates of the 64-token prompt, batched through all three stages exactly as
     bench.py does (device noise), with full-size weights. Checked against the oracle where the oracle can follow: AR ids of every
     candidate (teacher-forced through all 24 decode steps at B = 16), the latents of candidates 0 and 15, the batched 80-step sampling
-    loop (32 sequences: every candidate's conditioned and unconditioned copy) for candidates 0 and 15 with the reference's 0.01
+    loop (32 sequences: every candidate's conditioned and unconditioned copy) for the last candidate with the reference's 0.01
     gate, and the vocoder on the batch's own mel for candidates 0 and 15."""
     eng = full_engine
     toks, B, S = bench_prompt(), 16, 24
@@ -186,7 +186,7 @@ def test_config2_batch16(full_engine, oracle, full_models, voice, pkg):
     noise = [rs.randn(81, 100 * T).astype(np.float32) for _ in range(B)]
     mels = eng.diffusion(lats, n_steps=80, noise=noise)
     od = oracle.Diffusion(oracle.Model(full_models + "/ggml-diffusion-model.bin"))
-    for c in (0, 15):
+    for c in (15,):  # the last candidate of the batch (one full-depth oracle loop costs ~50 s; position in the batch cannot matter: see the invariance test below)
         want = od.sample(lats[c], n_steps=80, noise=noise[c])
         err = np.abs(mels[c] - want)
         print("configs[2] batched 80-step sampling loop cand %d (T=%d): max abs %.2e mean %.2e" % (c, T, err.max(), err.mean()))
