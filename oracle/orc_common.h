@@ -6,8 +6,9 @@
 // PINNED against the real reference code (oracle/_ref/libref.so, built from /root/reference) and
 // against the reference's RNG fixtures. The three network stages follow the reference's ggml
 // graphs (main.cpp:2053-4483) plus the ggml op semantics listed in SURVEY.md §3.7, but ggml
-// itself and the trained weights are absent from the checkout => "parity unpinned" for every
-// weight-dependent tensor.
+// itself and the trained weights are absent from the checkout => "parity unpinned" AGAINST THE REFERENCE for every
+// weight-dependent tensor. What is pinned instead (round 2, tests/test_oracle_vs_torch.py): every op and the
+// three whole graphs against PyTorch on the CPU, so only the ggml fork's constants (GroupNorm eps, fp16 activation tables) remain guesses.
 #pragma once
 #include <cmath>
 #include <cstdint>
