@@ -393,6 +393,12 @@ def main():
             break
         except Exception:
             pass
+    dec_traffic, dec_traffic_src = None, None  # L2-miss bytes fetched per decode step (PMC FETCH_SIZE pass over the decode launches, committed profile)
+    try:
+        dec_traffic = int(json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_decode_traffic.json")))["fetch_bytes_per_step"])
+        dec_traffic_src = "profiles/r2_pmc_decode_traffic.json"
+    except Exception:
+        pass
     L, T = shape.get("L", 0), shape.get("T", 0)
     n_prompts = len(my_prompts) if a.config != 5 else 8
     out = {
@@ -422,7 +428,7 @@ def main():
                      "avg_launch_us": round(1000.0 * g_ms / max(g_n, 1), 2), "algorithmic_gflop_per_launch": round(g_flops / max(g_n, 1) / 1e9, 2)},
         "roofline_decode": {"kernel": "AR decode step (one hipGraph replay: 151 kernels streaming every weight once)", "bound": "hbm",
                             "achieved": round(dec_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dec_gbs / HBM_PEAK_GBS, 4),
-                            "traffic": None, "steps_timed": int(d_n), "avg_step_us": round(1000.0 * d_ms / max(d_n, 1), 1),
+                            "traffic": dec_traffic, "traffic_source": dec_traffic_src, "steps_timed": int(d_n), "avg_step_us": round(1000.0 * d_ms / max(d_n, 1), 1),
                             "algorithmic_mb_per_step": round(d_bytes / max(d_n, 1) / 1e6, 1)},
     }
     if a.dry_engine:
