@@ -1,0 +1,202 @@
+// Developer tool (round 3): the table-scheduled GEMM kernels (csrc/gemm_f16_tiles.h) against the one-tile-per-workgroup kernels on the
+// benchmark's shapes, for a list of tile-height / ordering policies. Every policy's output is compared bit for bit with the one-tile
+// kernel's; timings are interleaved rounds in one process (median and min).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I tortoise.cpp_amd/csrc -I tools [-DTTS_GEMM_TRACE] tools/gemm_tab_bench.hip -o tools/bin/gemm_tab_bench
+//   tools/bin/gemm_tab_bench [shape-filter] [policy ...]      policy = name=h,h,..[/cn][/order]   e.g.  u7=7  mix=8,6/8/0
+#define tts tts_r2 // the round-2 one-tile-per-workgroup kernels, for reference output and timing
+#include "gemm_f16_onetile.h"
+#undef tts
+#undef GEMM_TR_DECL
+#undef GEMM_TR
+#undef GEMM_TR_FLUSH
+#include "gemm_f16.h"
+#include "gemm_tile_tables.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+using namespace tts;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+struct Shape { const char *name; int M, N, K, nseg, mode, resid; };
+struct Policy { std::string name; GemmPlanSpec sp; };
+
+static Policy parse_policy(const char *s) {
+  Policy p;
+  std::string str(s);
+  size_t eq = str.find('=');
+  p.name = str.substr(0, eq);
+  std::string rest = str.substr(eq + 1);
+  std::vector<std::string> parts;
+  size_t pos = 0;
+  while (true) { size_t q = rest.find('/', pos); parts.push_back(rest.substr(pos, q == std::string::npos ? q : q - pos)); if (q == std::string::npos) break; pos = q + 1; }
+  p.sp.nh = 0;
+  { const std::string &hs = parts[0]; size_t a = 0; while (a < hs.size()) { size_t b = hs.find(',', a); p.sp.h[p.sp.nh++] = atoi(hs.substr(a, b == std::string::npos ? b : b - a).c_str()); if (b == std::string::npos) break; a = b + 1; } }
+  if (parts.size() > 1) p.sp.cn = atoi(parts[1].c_str());
+  if (parts.size() > 2) p.sp.order = atoi(parts[2].c_str());
+  return p;
+}
+
+int main(int argc, char **argv) {
+  const int Mmax = 28032, Kmax = 1024;
+  std::vector<Shape> shapes = {
+      {"in_layers k1 N1024 K1024", 28032, 1024, 1024, 1, GEMM_OUT_F32, 0},
+      {"proj_out  k1 N1024 K1024 +resid", 28032, 1024, 1024, 1, GEMM_OUT_F32, 1},
+      {"qkv       k1 N3072 K1024", 28032, 3072, 1024, 1, GEMM_OUT_QKV, 0},
+      {"conv3     k3 N1024 K3x1024 +resid", 28032, 1024, 1024, 3, GEMM_OUT_F32, 1},
+      {"integ k1  N1024 K1024 M14848", 14848, 1024, 1024, 1, GEMM_OUT_F32, 0},
+      {"integ k3  N1024 K3x1024 M14848 +resid", 14848, 1024, 1024, 3, GEMM_OUT_F32, 1},
+      {"single k1 N1024 K1024 M1792", 1792, 1024, 1024, 1, GEMM_OUT_F32, 1},
+      {"single k3 N1024 K3x1024 M1792 +resid", 1792, 1024, 1024, 3, GEMM_OUT_F32, 1},
+      {"single qkv N3072 K1024 M1792", 1792, 3072, 1024, 1, GEMM_OUT_QKV, 0},
+  };
+  const char *filter = argc > 1 ? argv[1] : "";
+  std::vector<Policy> pols;
+  for (int i = 2; i < argc; i++) pols.push_back(parse_policy(argv[i]));
+  if (pols.empty()) {
+    const char *def[] = {"arith=0", "u8=8", "u7=7", "m86=8,6"};
+    for (const char *d : def) pols.push_back(parse_policy(d));
+  }
+  std::vector<__half> hA((size_t)(Mmax + 2) * Kmax), hW((size_t)3072 * 3 * Kmax);
+  srand(1);
+  for (auto &v : hA) v = __float2half((rand() % 2001 - 1000) / 1000.f);
+  for (auto &v : hW) v = __float2half((rand() % 2001 - 1000) / 4000.f);
+  __half *dA, *dW, *dH, *dVt, *dH2, *dVt2; float *dC, *dC2, *dRes, *dBias; int *dSeq;
+  const size_t hbytes = (size_t)(Mmax + 128) * 2048 * 2, vbytes = (size_t)1024 * (Mmax + 128) * 2, cbytes = (size_t)Mmax * 1024 * 4;
+  CK(hipMalloc(&dA, hA.size() * 2)); CK(hipMalloc(&dW, hW.size() * 2)); CK(hipMalloc(&dC, cbytes)); CK(hipMalloc(&dC2, cbytes));
+  CK(hipMalloc(&dRes, cbytes)); CK(hipMalloc(&dBias, 3072 * 4));
+  CK(hipMalloc(&dH, hbytes)); CK(hipMalloc(&dVt, vbytes)); CK(hipMalloc(&dH2, hbytes)); CK(hipMalloc(&dVt2, vbytes)); CK(hipMalloc(&dSeq, Mmax * 4));
+  CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
+  {
+    std::vector<float> r((size_t)Mmax * 1024), b(3072);
+    for (auto &v : r) v = (rand() % 2001 - 1000) / 500.f;
+    for (auto &v : b) v = (rand() % 2001 - 1000) / 1000.f;
+    CK(hipMemcpy(dRes, r.data(), r.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dBias, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+    std::vector<int> seq(Mmax, 0);
+    for (int i = 0; i < Mmax; i += 877) seq[i] = -1; // some guard rows
+    CK(hipMemcpy(dSeq, seq.data(), Mmax * 4, hipMemcpyHostToDevice));
+  }
+  hipStream_t s; CK(hipStreamCreate(&s));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  int4 *dTab; CK(hipMalloc(&dTab, (size_t)8 * 65536 * sizeof(int4)));
+  std::vector<std::vector<int4>> tabs;
+  const int rounds = 3, iters = 12;
+  for (const Shape &sh : shapes) {
+    if (filter[0] && strcmp(filter, "all") && !strstr(sh.name, filter)) continue;
+    auto mk = [&](float *outF, __half *outH, __half *outVt) {
+      GemmArgs g{};
+      const int lda = sh.K;
+      for (int i = 0; i < 3; i++) { g.A[i] = dA + lda; g.row_off[i] = sh.nseg == 3 ? i - 1 : 0; }
+      g.nseg = sh.nseg; g.kseg = sh.K; g.lda = lda; g.W = dW; g.M = sh.M; g.N = sh.N; g.bias = dBias; g.row_seq = dSeq;
+      g.mode = sh.mode; g.outF = outF; g.ldo = sh.N; g.resid = sh.resid ? dRes : nullptr;
+      g.outH = outH; g.ldh = 2048; g.outVt = outVt; g.ldvt = Mmax + 128;
+      return g;
+    };
+    const double fl = 2.0 * sh.M * sh.N * (double)sh.K * sh.nseg;
+    printf("== %s  (%.1f GFLOP)\n", sh.name, fl * 1e-9);
+    // reference output from the one-tile kernels
+    CK(hipMemset(dC, 0, cbytes)); CK(hipMemset(dH, 0, hbytes)); CK(hipMemset(dVt, 0, vbytes));
+    auto mk_r2 = [&](float *outF, __half *outH, __half *outVt) {
+      tts_r2::GemmArgs g{};
+      const int lda = sh.K;
+      for (int i = 0; i < 3; i++) { g.A[i] = dA + lda; g.row_off[i] = sh.nseg == 3 ? i - 1 : 0; }
+      g.nseg = sh.nseg; g.kseg = sh.K; g.lda = lda; g.W = dW; g.M = sh.M; g.N = sh.N; g.bias = dBias; g.row_seq = dSeq;
+      g.mode = sh.mode; g.outF = outF; g.ldo = sh.N; g.resid = sh.resid ? dRes : nullptr;
+      g.outH = outH; g.ldh = 2048; g.outVt = outVt; g.ldvt = Mmax + 128;
+      return g;
+    };
+    { tts_r2::GemmArgs gref = mk_r2(dC, dH, dVt); CK(tts_r2::launch_gemm_f16(gref, s)); CK(hipStreamSynchronize(s)); }
+    std::vector<float> refC; std::vector<__half> refH, refV;
+    if (sh.mode == GEMM_OUT_F32) { refC.resize((size_t)sh.M * sh.N); CK(hipMemcpy(refC.data(), dC, refC.size() * 4, hipMemcpyDeviceToHost)); }
+    else { refH.resize(hbytes / 2); refV.resize(vbytes / 2); CK(hipMemcpy(refH.data(), dH, hbytes, hipMemcpyDeviceToHost)); CK(hipMemcpy(refV.data(), dVt, vbytes, hipMemcpyDeviceToHost)); }
+    // plans
+    std::vector<GemmPlan> plans(pols.size());
+    std::vector<std::string> status(pols.size());
+    for (size_t pi = 0; pi < pols.size(); pi++) {
+      const bool arith = pols[pi].name.rfind("arith", 0) == 0; // arithmetic tile walk of the product (th = first height, 0 = automatic)
+      if (!arith) {
+        gemm_plan_build(plans[pi], sh.M, sh.N, pols[pi].sp);
+        CK(hipMalloc(&plans[pi].dev, plans[pi].host.size() * sizeof(int4)));
+        CK(hipMemcpy(plans[pi].dev, plans[pi].host.data(), plans[pi].host.size() * sizeof(int4), hipMemcpyHostToDevice));
+      }
+      CK(hipMemset(dC2, 0xff, cbytes)); CK(hipMemset(dH2, 0, hbytes)); CK(hipMemset(dVt2, 0, vbytes));
+      GemmArgs g = mk(dC2, dH2, dVt2);
+      g.tiles = plans[pi].dev; g.tab_len = plans[pi].len; g.th = arith ? pols[pi].sp.h[0] : 0;
+      CK(launch_gemm_f16(g, s)); CK(hipStreamSynchronize(s));
+      size_t bad = 0;
+      if (sh.mode == GEMM_OUT_F32) {
+        std::vector<float> c(refC.size());
+        CK(hipMemcpy(c.data(), dC2, c.size() * 4, hipMemcpyDeviceToHost));
+        bad = memcmp(c.data(), refC.data(), c.size() * 4) ? 1 : 0;
+        if (bad) { bad = 0; for (size_t i = 0; i < c.size(); i++) bad += memcmp(&c[i], &refC[i], 4) != 0; }
+      } else {
+        std::vector<__half> h(refH.size()), v(refV.size());
+        CK(hipMemcpy(h.data(), dH2, hbytes, hipMemcpyDeviceToHost)); CK(hipMemcpy(v.data(), dVt2, vbytes, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < h.size(); i++) bad += memcmp(&h[i], &refH[i], 2) != 0;
+        for (size_t i = 0; i < v.size(); i++) bad += memcmp(&v[i], &refV[i], 2) != 0;
+      }
+      char buf[96];
+      snprintf(buf, sizeof buf, "%s (%d tiles, %d per XCD)", bad ? "MISMATCH" : "bit-identical", plans[pi].tiles, plans[pi].len);
+      if (bad) snprintf(buf + strlen(buf), sizeof buf - strlen(buf), " %zu elements differ", bad);
+      status[pi] = buf;
+    }
+    // timing: variant -1 = one-tile kernels
+    std::vector<std::vector<double>> us(pols.size() + 1);
+    for (int r = 0; r < rounds; r++)
+      for (int v = -1; v < (int)pols.size(); v++) {
+        GemmArgs g = mk(dC2, dH2, dVt2);
+        tts_r2::GemmArgs g2 = mk_r2(dC2, dH2, dVt2);
+        if (v >= 0) { g.tiles = plans[v].dev; g.tab_len = plans[v].len; g.th = pols[v].name.rfind("arith", 0) == 0 ? pols[v].sp.h[0] : 0; }
+        auto go = [&]() { return v < 0 ? tts_r2::launch_gemm_f16(g2, s) : launch_gemm_f16(g, s); };
+        for (int i = 0; i < 2; i++) CK(go());
+        CK(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; i++) CK(go());
+        CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        us[v + 1].push_back(1000.0 * ms / iters);
+      }
+    for (int v = -1; v < (int)pols.size(); v++) {
+      auto &u = us[v + 1];
+      std::sort(u.begin(), u.end());
+      const double med = u[u.size() / 2];
+      printf("  %-12s med %8.1f us  min %8.1f  %7.1f TF/s   %s\n", v < 0 ? "round-2" : pols[v].name.c_str(), med, u[0], fl / (med * 1e-6) / 1e12,
+             v < 0 ? "" : status[v].c_str());
+    }
+#ifdef TTS_GEMM_TRACE
+    for (size_t pi = 0; pi < pols.size(); pi++) {
+      static std::vector<unsigned long long> tr(65536 * 8);
+      std::fill(tr.begin(), tr.end(), 0ull);
+      CK(hipMemcpyToSymbol(HIP_SYMBOL(tts_gemm_trace), tr.data(), tr.size() * 8));
+      GemmArgs g = mk(dC2, dH2, dVt2);
+      g.tiles = plans[pi].dev; g.tab_len = plans[pi].len; g.th = pols[pi].name.rfind("arith", 0) == 0 ? pols[pi].sp.h[0] : 0;
+      CK(launch_gemm_f16(g, s)); CK(hipStreamSynchronize(s));
+      CK(hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(tts_gemm_trace), tr.size() * 8));
+      unsigned long long tmin = ~0ull, tmax = 0;
+      double kl[9] = {0}, ep[9] = {0}, dr[9] = {0}; int cnt[9] = {0};
+      std::vector<unsigned long long> starts, ends;
+      for (size_t w = 0; w < 65536; w++) {
+        const unsigned long long *p = &tr[w * 8];
+        if (!p[0] || !p[4]) continue;
+        tmin = std::min(tmin, p[0]); tmax = std::max(tmax, p[5]);
+        starts.push_back(p[0]); ends.push_back(p[3]);
+        const int nb = (int)p[2];
+        if (nb >= 0 && nb <= 8) { kl[nb] += (p[3] - p[1]) * 0.01; ep[nb] += (p[4] - p[3]) * 0.01; dr[nb] += (p[5] - p[4]) * 0.01; cnt[nb]++; }
+      }
+      printf("  [trace %s] span %.1f us;", pols[pi].name.c_str(), (tmax - tmin) * 0.01);
+      for (int nb = 2; nb <= 8; nb++) if (cnt[nb]) printf("  h%d: n=%d K-loop %.1f epilogue issue %.1f store drain %.1f us;", nb, cnt[nb], kl[nb] / cnt[nb], ep[nb] / cnt[nb], dr[nb] / cnt[nb]);
+      printf("\n    starts per 5 us:");
+      std::vector<int> hist((size_t)((tmax - tmin) / 500) + 1, 0), hend(hist.size(), 0);
+      for (auto t : starts) hist[(size_t)((t - tmin) / 500)]++;
+      for (auto t : ends) hend[(size_t)((t - tmin) / 500)]++;
+      for (int h : hist) printf(" %d", h);
+      printf("\n    K-loop ends per 5 us:");
+      for (int h : hend) printf(" %d", h);
+      printf("\n");
+    }
+#endif
+    for (auto &p : plans) if (p.dev) CK(hipFree(p.dev));
+  }
+  return 0;
+}

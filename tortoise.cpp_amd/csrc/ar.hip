@@ -25,6 +25,15 @@ static constexpr int D = 1024, NH = 16, HD = 64, FF = 4096, V = TTS_VOCAB_MEL, V
 // A/B switch for the LayerNorm-GEMV decode kernels: split-precision fp16 MFMA (default: three products per K step,
 // 2^-22 relative) vs exact-f32 MFMA products (TTS_DEC_F32MFMA=1, read at load time: it selects the weight packing)
 static const bool dec_f32_mfma = getenv("TTS_DEC_F32MFMA") != nullptr;
+// Weight slabs of the decode step are streamed once per step by exactly one workgroup: non-temporal loads keep them from displacing the
+// activations / KV rows in L2 (MI355X_MICROARCH.md, row "nt-weights"). TTS_DEC_NT=0 is the A/B switch back to default-policy loads.
+static const bool dec_nt = !(getenv("TTS_DEC_NT") && atoi(getenv("TTS_DEC_NT")) == 0);
+typedef float ntfloat4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ float4 ldw4(const float4 *p) {
+  if (!NT) return *p;
+  const ntfloat4 v = __builtin_nontemporal_load((const ntfloat4 *)p);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
 
 // ---------------------------------------------------------------------------------------------
 // kernels
@@ -398,7 +407,7 @@ __device__ __forceinline__ void dec_layernorm(float4 (&x)[16], const float *__re
 
 // SPLIT: 0 = fp32 MFMA on f32 weights, 1 = split-precision fp16 MFMA (f32-exact to 2^-22), 2 = fp16 WEIGHTS (rounded once at load:
 // half the bytes streamed; the activations keep their hi + lo split) — the throughput mode of SURVEY 8d, option "ar_weights".
-template <int EPI, int SPLIT = 0>
+template <int EPI, int SPLIT = 0, bool NTW = false>
 __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
   constexpr int SP = SPLIT ? 1 : 0;
   __shared__ float sred[4][4][16];
@@ -421,11 +430,11 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
     if (SPLIT == 2) { // 8 steps x 16 B per lane: half the slab of the split variant
       const float4 *wp = (const float4 *)a.Wh + ((size_t)(cb * 4 + wave) * 8) * 64;
 #pragma unroll
-      for (int i = 0; i < 8; i++) w[2 * i] = wp[i * 64 + lane];
+      for (int i = 0; i < 8; i++) w[2 * i] = ldw4<NTW>(wp + i * 64 + lane);
     } else {
       const float4 *wp = (SPLIT ? (const float4 *)a.Wh : (const float4 *)a.W) + ((size_t)(cb * 4 + wave) * 16) * 64;
 #pragma unroll
-      for (int i = 0; i < 16; i++) w[i] = SPLIT ? wp[((i >> 1) * 64 + lane) * 2 + (i & 1)] : wp[i * 64 + lane];
+      for (int i = 0; i < 16; i++) w[i] = ldw4<NTW>(SPLIT ? wp + ((i >> 1) * 64 + lane) * 2 + (i & 1) : wp + i * 64 + lane);
     }
   }
   DEC_T(1);
@@ -515,7 +524,7 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
 // are in flight per CU — the c_proj of the MLP (K = 4096) reads 256 KB of activations per workgroup and is bound by how
 // many of those loads the CU keeps in flight.
 // WH: the slab holds fp16 weights (pack_cols4 order, 8 bytes per (k, 4 columns): option ar_weights = 1), converted to f32 in registers.
-template <int KG, int NT = 256, bool WH = false>
+template <int KG, int NT = 256, bool WH = false, bool NTW = false>
 __global__ __launch_bounds__(NT) void dec_gemv_resid_kernel(const float *__restrict__ X, int rows, const float *__restrict__ W,
                                                             const float *__restrict__ bias, float *__restrict__ h) {
   constexpr int K = 1024 * KG, NW = NT / 64, NG = K / (NT * 4); // NG K groups of NT*4 values per workgroup
@@ -544,7 +553,7 @@ __global__ __launch_bounds__(NT) void dec_gemv_resid_kernel(const float *__restr
 #pragma unroll
       for (int i = 0; i < NG; i++)
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) w[i][kk] = wp[((i * (NT / 256) + (tid >> 8)) * 4 + kk) * 256];
+        for (int kk = 0; kk < 4; kk++) w[i][kk] = ldw4<NTW>(wp + ((i * (NT / 256) + (tid >> 8)) * 4 + kk) * 256);
     }
   }
   // Activations (L2 hits) are fetched 8 candidates at a time, double-buffered against the FMAs; K group i of the
@@ -1202,6 +1211,7 @@ static int launch_mfma_matmul(tts_ctx *ctx, ArState *st, const float *X, int row
 #define DEC_LN_LAUNCH(EPI_, GRID_)                                                         \
   do {                                                                                     \
     if (dec_f32_mfma) dec_ln_gemv_kernel<EPI_, 0><<<GRID_, 256, 0, ctx->stream>>>(a);       \
+    else if (dec_nt) dec_ln_gemv_kernel<EPI_, 1, true><<<GRID_, 256, 0, ctx->stream>>>(a);  \
     else dec_ln_gemv_kernel<EPI_, 1><<<GRID_, 256, 0, ctx->stream>>>(a);                    \
   } while (0)
 
@@ -1367,6 +1377,7 @@ static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
       else attn_decode_fast_kernel<<<dim3(B, NH), 256, 0, ctx->stream>>>(q, kc, vc, ss, st->max_pos, att); }
     { ProfScope ps(ctx, "ar_gemv", 1.0 * D * D * wb * tiles);
       if (wq) dec_gemv_resid_kernel<1, 256, true><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, (const float *)w.q_proj, w.b_proj, h);
+      else if (dec_nt) dec_gemv_resid_kernel<1, 256, false, true><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, w.d_proj, w.b_proj, h);
       else dec_gemv_resid_kernel<1><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, w.d_proj, w.b_proj, h); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * wb * tiles);
       DecLnArgs a{h, nullptr, nullptr, w.d_fc, wq ? w.q_fc : w.dh_fc, w.db_fc, B, FF, 0, 0, ff, nullptr, nullptr, ss, 0, ctx->ggml_lut};
@@ -1374,6 +1385,7 @@ static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
       else DEC_LN_LAUNCH(DEC_GELU, dim3(FF / 16, tiles)); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * wb * tiles);
       if (wq) dec_gemv_resid_kernel<4, 512, true><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, (const float *)w.q_fc2, w.b_fc2, h);
+      else if (dec_nt) dec_gemv_resid_kernel<4, 512, false, true><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, w.d_fc2, w.b_fc2, h);
       else dec_gemv_resid_kernel<4, 512><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, w.d_fc2, w.b_fc2, h); }
   }
   { ProfScope ps(ctx, "ar_gemv", (double)D * VPAD * wb * tiles);
