@@ -121,14 +121,18 @@ int tts_sample(tts_ctx *ctx, const float *logits, const int32_t *penalty_ids, in
  *   flags: TTS_AR_MASK_STOP -> stop token never sampled, exactly max_steps codes (bench workload).
  *   codes_out [B][502]; rows_out [B] trimmed latent rows; latents_out: the trimmed latents of all
  *   candidates back to back (capacity B*500*1024 floats); steps_out: sampling iterations run. */
-/*          TTS_AR_RETIRE (n_candidates > 1; throughput mode) -> a candidate retires at its first 8193 and
+/*          TTS_AR_RETIRE (throughput mode) -> a candidate retires at its first 8193 and
  *          the loop ends when all have retired (the reference ends only when all B samples of ONE step are 8193,
- *          main.cpp:5214-5222); reaching max_steps pads and returns TTS_OK. No sequence differs from strict mode:
+ *          main.cpp:5214-5222); reaching max_steps pads the unfinished sequences and returns TTS_OK — which candidates
+ *          were cut is reported by tts_ar_stop_status. No sequence differs from strict mode:
  *          sequences freeze at the first 8193 (5210-5213) and the uniforms are consumed identically. */
 enum { TTS_AR_MASK_STOP = 1, TTS_AR_RETIRE = 2 };
 int tts_autoregressive(tts_ctx *ctx, const int32_t *text_ids, int n_text, const float *voice1024,
                        int n_candidates, int max_steps, unsigned flags, int32_t *codes_out,
                        int32_t *rows_out, float *latents_out, int32_t *steps_out);
+/* Per candidate of the last tts_autoregressive call: 1 = the sequence ends in a sampled stop token (what main.cpp:5214-5222
+ * waits for), 0 = it was cut at max_steps (TTS_AR_RETIRE / TTS_AR_MASK_STOP) and padded like a finished one. */
+int tts_ar_stop_status(tts_ctx *ctx, int32_t *stopped_out, int n_candidates);
 
 /* ---- diffusion stage ----------------------------------------------------------------------- */
 /* T = L*4*24000/22050 (main.cpp:5616-5617) */

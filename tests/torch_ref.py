@@ -56,13 +56,18 @@ class Weights:
 # diffusion (diffusion_graph, main.cpp:3066-4044)
 # ------------------------------------------------------------------------------------------------------------------
 class TorchDiffusion:
-    def __init__(self, path, buckets, gn_eps=1e-6, dtype=torch.float32):
-        """dtype float64: the same graph (same fp16 rounding points) evaluated in double — the yardstick for how far two f32
+    def __init__(self, path, buckets, gn_eps=1e-6, dtype=torch.float32, f16_attention=False):
+        """f16_attention: emulate the ENGINE's AttentionBlock arithmetic instead of the reference's F32 one (DESIGN.md section 4,
+        north-star "MFMA ... for the dense fp16 GEMMs in attention"): q, k, v, the unnormalised softmax numerators, the attention
+        output and the proj_out weight are rounded to fp16, accumulation stays f32/f64. Used by tests/test_parity_floor.py to
+        separate what the fp16 attention costs from what ANY f32 evaluation order costs.
+        dtype float64: the same graph (same fp16 rounding points) evaluated in double — the yardstick for how far two f32
         evaluations with different summation orders may legitimately be apart. buckets(n) -> int array [n, n] of T5 relative-position buckets, index [query][key] (main.cpp:4722-4749; pinned against
         the reference's own code in tests/test_host_parity.py — passed in so this file stays free of oracle imports)."""
         self.w = Weights(path, dtype)
         self.buckets = buckets
         self.eps = gn_eps
+        self.f16_attention = f16_attention
         w = self.w
         self.n_lc = 0
         while w.has("latent_conditioner.%d.norm.weight" % (self.n_lc + 1)):
@@ -87,6 +92,13 @@ class TorchDiffusion:
         rel = w[p + ".relative_pos_embeddings.relative_attention_bias.weight"]  # [32 buckets, 16 heads]
         bk = torch.from_numpy(np.asarray(self.buckets(T), np.int64))  # [query, key]
         bias = rel[bk].permute(2, 0, 1) * 8.0  # [head, query, key]
+        if self.f16_attention:  # the engine: fp16 MFMA operands, f32 accumulate; row sums taken over the ROUNDED numerators
+            q, k, v = h16(q), h16(k), h16(v)
+            att = torch.einsum("hdi,hdj->hij", q, k) * (1.0 / 8.0) + bias
+            e = h16(torch.exp(att - att.max(dim=-1, keepdim=True).values))
+            a = h16((torch.einsum("hij,hdj->hdi", e, v) / e.sum(dim=-1)[:, None, :]).reshape(C, T))
+            o = F.conv1d(a[None], h16(w[p + ".proj_out.weight"]).reshape(C, C, 1), w[p + ".proj_out.bias"])[0]
+            return x + o
         att = torch.einsum("hdi,hdj->hij", q, k) * (1.0 / 8.0) + bias
         att = torch.softmax(att, dim=-1)
         a = torch.einsum("hij,hdj->hdi", att, v).reshape(C, T)

@@ -193,8 +193,7 @@ int tts_sample(tts_ctx *c, const float *logits, const int32_t *ids, int ids_per_
   if (!c || !logits || !ids || !out || B < 1 || ids_per_cand < 1) return TTS_ERR_ARG;
   for (int i = 0; i < B * ids_per_cand; i++)
     if (ids[i] < 0 || ids[i] >= TTS_VOCAB_MEL) return fail(c, TTS_ERR_ARG, "penalty id out of range");
-  if (c->rng_shard_total > 0 && c->rng_shard_offset + B > c->rng_shard_total)
-    return fail(c, TTS_ERR_ARG, "candidates [%d, %d) exceed rng_shard_total %d", c->rng_shard_offset, c->rng_shard_offset + B, c->rng_shard_total);
+  if (int rc = shard_check(c, B)) return rc;
   return guarded(c, [&] { sample_candidates(c, logits, ids, ids_per_cand, B, out); return (int)TTS_OK; });
 }
 
@@ -228,9 +227,8 @@ static int autoregressive_impl(tts_ctx *c, const int32_t *text_ids, int n_text, 
   // ignored — the loop ends when every candidate has retired, and reaching max_steps pads and returns instead of failing.
   // The uniforms are consumed exactly as in strict mode (two per candidate and step, candidate order), so every
   // sequence is the one strict mode would have produced.
-  const bool retire = (flags & TTS_AR_RETIRE) && B > 1;
-  if (c->rng_shard_total > 0 && c->rng_shard_offset + B > c->rng_shard_total)
-    return fail(c, TTS_ERR_ARG, "candidates [%d, %d) exceed rng_shard_total %d", c->rng_shard_offset, c->rng_shard_offset + B, c->rng_shard_total);
+  const bool retire = (flags & TTS_AR_RETIRE) != 0;
+  if ((rc = shard_check(c, B))) return rc;
   std::vector<char> done(B, 0);
   int i = 0;
   for (;;) {
@@ -260,6 +258,8 @@ static int autoregressive_impl(tts_ctx *c, const int32_t *text_ids, int n_text, 
   }
   const double t_after_loop = now();
   if (steps_out) *steps_out = i;
+  c->ar_stopped.assign(B, 0); // who was cut at max_steps (TTS_AR_RETIRE / TTS_AR_MASK_STOP): tts_ar_stop_status
+  for (int b = 0; b < B; b++) c->ar_stopped[b] = (!seq[b].empty() && seq[b].back() == 8193) ? 1 : 0;
   int max_rows = 0;
   for (int b = 0; b < B; b++) {
     if (seq[b].size() > 500) seq[b].resize(500); // the reference asserts (main.cpp:4517)
@@ -296,6 +296,13 @@ int tts_autoregressive(tts_ctx *c, const int32_t *text_ids, int n_text, const fl
   });
 }
 
+int tts_ar_stop_status(tts_ctx *c, int32_t *stopped_out, int n_candidates) {
+  if (!c || !stopped_out || n_candidates < 1) return TTS_ERR_ARG;
+  if ((int)c->ar_stopped.size() != n_candidates) return fail(c, TTS_ERR_STATE, "tts_ar_stop_status: the last tts_autoregressive call had %d candidates", (int)c->ar_stopped.size());
+  std::copy(c->ar_stopped.begin(), c->ar_stopped.end(), stopped_out);
+  return TTS_OK;
+}
+
 int tts_diffusion_frames(int L) { return L * 4 * 24000 / 22050; }
 int tts_diffusion_forward(tts_ctx *c, const float *latents, int L, const float *x_t, int timestep, int cond_free, float *out) {
   NEED_CTX(c);
@@ -304,11 +311,13 @@ int tts_diffusion_forward(tts_ctx *c, const float *latents, int L, const float *
 int tts_diffusion(tts_ctx *c, const float *latents, const int32_t *rows, int B, int n_steps, const float *noise,
                   int noise_mode, float *mel_out) {
   NEED_CTX(c);
+  if (B >= 1) if (int rc = shard_check(c, B)) return rc; // the device noise streams are keyed by the global candidate id
   return guarded(c, [&] { return diff_sample(c, latents, rows, B, n_steps, noise, noise_mode, mel_out); });
 }
 int tts_vocoder_samples(int T) { return (T + 10) * 256 - 6; }
 int tts_vocoder(tts_ctx *c, const float *mel, const int32_t *frames, int B, const float *noise, int noise_mode, float *audio) {
   NEED_CTX(c);
+  if (B >= 1) if (int rc = shard_check(c, B)) return rc;
   return guarded(c, [&] { return voc_run(c, mel, frames, B, noise, noise_mode, audio); });
 }
 

@@ -415,7 +415,12 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, q = lane >> 4;
   const int cb = blockIdx.x, row = blockIdx.y * 16 + m;
   DEC_T(0);
-  // activations first (L2 hits), then the weight slab (HBM): vmcnt retires in order, so the LayerNorm runs on
+  // Everything the epilogue reads (bias, the step's n_past) is requested FIRST: loaded after the reduction they were one or two
+  // dependent L2 round trips (~0.5 us each) at the end of every one of the step's 91 launches of this kernel.
+  const float4 bi = *(const float4 *)(a.bias + cb * 16 + 4 * q);
+  int n_past = 0;
+  if (EPI == DEC_QKV) n_past = a.prefill_B == 0 ? a.ss->n_past : 0;
+  // activations next (L2 hits), then the weight slab (HBM): vmcnt retires in order, so the LayerNorm runs on
   // the activations while the 16 x 1 KB-per-wave weight loads are still streaming in
   const int koff = wave * 256 + (SPLIT ? 8 : 4) * q;
   float4 x[16];
@@ -484,7 +489,6 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
   if (wave != 0 || row >= a.rows) return;
   const float4 p0 = accs[0][lane], p1 = accs[1][lane], p2 = accs[2][lane], p3 = accs[3][lane];
   const int col = cb * 16 + 4 * q; // lane: candidate `row`, columns col .. col+3
-  const float4 bi = *(const float4 *)(a.bias + col);
   float4 v;
   v.x = (((p0.x + p1.x) + p2.x) + p3.x) + bi.x; v.y = (((p0.y + p1.y) + p2.y) + p3.y) + bi.y;
   v.z = (((p0.z + p1.z) + p2.z) + p3.z) + bi.z; v.w = (((p0.w + p1.w) + p2.w) + p3.w) + bi.w;
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
       u.x = *(const unsigned *)&h01;
       u.y = *(const unsigned *)&h23;
       __half *base = (sec == 1 ? a.kc : a.vc) + cc;
-      if (a.prefill_B == 0) *(uint2 *)(base + ((size_t)row * a.max_pos + a.ss->n_past) * D) = u;
+      if (a.prefill_B == 0) *(uint2 *)(base + ((size_t)row * a.max_pos + n_past) * D) = u;
       else
         for (int c = 0; c < a.prefill_B; c++) *(uint2 *)(base + ((size_t)c * a.max_pos + row) * D) = u;
     }
@@ -532,6 +536,10 @@ __global__ __launch_bounds__(NT) void dec_gemv_resid_kernel(const float *__restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cb = blockIdx.x, row0 = blockIdx.y * 16;
   DEC_T(0);
+  // the residual element and the bias this thread adds at the very end (threads 0-63: output 4 * candidate + column) are requested
+  // first instead of after the reduction (a dependent L2 round trip at the end of 60 launches per step)
+  const int er = min(row0 + ((tid & 63) >> 2), rows - 1), ecol = cb * 4 + (tid & 3);
+  const float h_old = h[(size_t)er * D + ecol], b_old = bias[ecol];
   float4 xa0[8]; // candidates 0-7 of K group 0: requested before the weight stream
 #pragma unroll
   for (int r = 0; r < 8; r++) xa0[r] = *(const float4 *)(X + (size_t)min(row0 + r, rows - 1) * K + 4 * tid);
@@ -629,7 +637,7 @@ __global__ __launch_bounds__(NT) void dec_gemv_resid_kernel(const float *__restr
       float t = red[0][tid];
 #pragma unroll
       for (int w2 = 1; w2 < NW; w2++) t += red[w2][tid];
-      h[(size_t)r * D + col] += t + bias[col];
+      h[(size_t)r * D + col] = h_old + (t + b_old);
     }
   }
 }

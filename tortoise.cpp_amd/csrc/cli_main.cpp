@@ -125,12 +125,19 @@ int main(int argc, char **argv) {
   std::vector<int32_t> codes((size_t)B * 502), rows(B);
   std::vector<float> latents((size_t)B * 500 * 1024);
   int32_t nsteps = 0;
-  // sharded batches use the throughput stop rule: the reference's "all B samples of one step are 8193" would need a per-step exchange
-  const unsigned ar_flags = (fixed_codes > 0 ? TTS_AR_MASK_STOP : 0) | (shard >= 0 ? TTS_AR_RETIRE : 0);
+  // More than one candidate (in this process or across --devices shards): the throughput stop rule. The reference's "all B samples of ONE
+  // step are 8193" practically never fires for B > 1 (and would need a per-step exchange between shards); every sequence is the same.
+  const unsigned ar_flags = (fixed_codes > 0 ? TTS_AR_MASK_STOP : 0) | (total_candidates > 1 ? TTS_AR_RETIRE : 0);
   if (tts_autoregressive(ctx, tokens.data(), n, voice.data(), B, fixed_codes > 0 ? fixed_codes : 500, ar_flags,
                          codes.data(), rows.data(), latents.data(), &nsteps))
     return die(ctx, "autoregressive");
   printf("tokens sampled: %d\n", nsteps);
+  if (fixed_codes <= 0) {
+    std::vector<int32_t> stopped(B);
+    if (tts_ar_stop_status(ctx, stopped.data(), B) == 0)
+      for (int c = 0; c < B; c++)
+        if (!stopped[c]) fprintf(stderr, "warning: candidate %d sampled no stop token within 500 codes (sequence cut)\n", (shard >= 0 ? shard * B : 0) + c);
+  }
 
   if (tts_load_diffusion(ctx, (modelsDir + "/ggml-diffusion-model.bin").c_str())) return die(ctx, "diffusion_model_load");
   size_t mel_total = 0, audio_total = 0;

@@ -81,6 +81,7 @@ struct tts_ctx {
   // candidate-parallel sharding: this context runs candidates [rng_shard_offset, +B) of a batch of rng_shard_total
   // (0 = unsharded). The sampler skips the other ranks' uniforms; device noise streams are keyed by the global candidate id.
   int rng_shard_offset = 0, rng_shard_total = 0;
+  std::vector<int32_t> ar_stopped; // last tts_autoregressive call, per candidate: 1 = it sampled the stop token, 0 = cut at max_steps (tts_ar_stop_status)
   // profiling: per kernel family, HIP event pairs recorded on the ctx stream around every launch and
   // resolved lazily (no host sync inside the timed region)
   bool prof_on = false;
@@ -98,6 +99,17 @@ struct tts_ctx {
 namespace tts {
 
 int fail(tts_ctx *ctx, int code, const char *fmt, ...);
+
+// Global id of this context's candidate 0: the ONE place that interprets rng_shard_offset / rng_shard_total, used by the
+// sampler's stream partition and by the device noise streams of the diffusion and vocoder stages alike. total == 0 = unsharded:
+// the offset is ignored everywhere.
+inline int shard_base(const tts_ctx *c) { return c->rng_shard_total > 0 ? c->rng_shard_offset : 0; }
+// B candidates must fit the declared batch; TTS_OK or TTS_ERR_ARG (message set).
+inline int shard_check(tts_ctx *c, int B) {
+  if (c->rng_shard_total > 0 && c->rng_shard_offset + B > c->rng_shard_total)
+    return fail(c, TTS_ERR_ARG, "candidates [%d, %d) exceed rng_shard_total %d", c->rng_shard_offset, c->rng_shard_offset + B, c->rng_shard_total);
+  return TTS_OK;
+}
 
 #define TTS_HIP(ctx, expr)                                                                      \
   do {                                                                                          \

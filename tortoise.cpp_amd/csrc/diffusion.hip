@@ -891,27 +891,28 @@ __global__ __launch_bounds__(NT) void gn_reg_kernel(int getenv_gn_xcd, const flo
   // the activation mode is workgroup-uniform: one copy of the unrolled store loop per mode, no per-element branch
   auto apply = [&](auto mode) {
     constexpr int MODE = decltype(mode)::value; // 0 none, 1 SiLU, 2 SiLU through the fp16 table emulation
+    // Straight-line stores: a row past the sequence end was loaded from (and is written back to) row T - 1 — the same value from
+    // every thread that holds it. Under `if (t < T)` hipcc's wait-count pass loses track at every exec-mask join and puts a
+    // vmcnt(0) in front of each block, i.e. each of the NJ stores waited for the previous one's acknowledgement.
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-      const int t = t0 + j * SWEEP;
-      if (t < T) {
-        float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+      const int t = min(t0 + j * SWEEP, T - 1);
+      float e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          float u = e[i] * rstd;
-          u = u * ge[i];
-          u = u + be[i];
-          u = u * sc4[i]; // (1, 0 without scale/shift: exact no-ops)
-          u = u + sh4[i];
-          if (MODE) u = silu_dev(u, MODE == 2);
-          e[i] = u;
-        }
-        const __half2 p0 = __floats2half2_rn(e[0], e[1]), p1 = __floats2half2_rn(e[2], e[3]);
-        uint2 o;
-        o.x = *(const unsigned *)&p0;
-        o.y = *(const unsigned *)&p1;
-        *(uint2 *)(y + (size_t)(r0 + t) * C + c) = o;
+      for (int i = 0; i < 4; i++) {
+        float u = e[i] * rstd;
+        u = u * ge[i];
+        u = u + be[i];
+        u = u * sc4[i]; // (1, 0 without scale/shift: exact no-ops)
+        u = u + sh4[i];
+        if (MODE) u = silu_dev(u, MODE == 2);
+        e[i] = u;
       }
+      const __half2 p0 = __floats2half2_rn(e[0], e[1]), p1 = __floats2half2_rn(e[2], e[3]);
+      uint2 o;
+      o.x = *(const unsigned *)&p0;
+      o.y = *(const unsigned *)&p1;
+      *(uint2 *)(y + (size_t)(r0 + t) * C + c) = o;
     }
   };
   if (!do_silu) apply(std::integral_constant<int, 0>{});
@@ -1273,7 +1274,7 @@ int diff_sample(tts_ctx *ctx, const float *latents, const int32_t *rows, int B, 
   } else {
     for (int c = 0; c < B; c++) {
       int64_t n = (int64_t)100 * lay.len[c];
-      philox_fill_kernel<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(st->xbuf.as<float>() + xoff[c], n, ctx->seed_value, (uint32_t)(ctx->rng_shard_offset + c), 0xFFFFFFFFu);
+      philox_fill_kernel<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(st->xbuf.as<float>() + xoff[c], n, ctx->seed_value, (uint32_t)(shard_base(ctx) + c), 0xFFFFFFFFu);
     }
   }
   if (timing) (void)hipStreamSynchronize(ctx->stream);
@@ -1309,7 +1310,7 @@ int diff_sample(tts_ctx *ctx, const float *latents, const int32_t *rows, int B, 
       ddpm_update_kernel<<<lay.rows, 128, 0, ctx->stream>>>(
           st->net.as<float>(), st->xbuf.as<float>(), st->xoff.as<int64_t>(), lay.d_row_seq.as<int>(), lay.d_row_t.as<int>(),
           lay.d_len.as<int>(), lay.d_start.as<int>(), B, st->step_tab.as<StepEntry>(), st->step_ctr.as<int>(),
-          host_noise ? st->noise.as<float>() : nullptr, ctx->seed_value, (uint32_t)ctx->rng_shard_offset);
+          host_noise ? st->noise.as<float>() : nullptr, ctx->seed_value, (uint32_t)shard_base(ctx));
     }
     step_advance_kernel<<<1, 1, 0, ctx->stream>>>(st->step_ctr.as<int>());
     TTS_HIP(ctx, hipGetLastError());

@@ -372,7 +372,7 @@ void sample_candidates(tts_ctx *ctx, const float *logits, const int32_t *ids, in
   // Sharded batch (options "rng_shard_offset" / "rng_shard_total"): this context holds candidates
   // [offset, offset + B) of a batch of `total`; the used uniform of (step s, global candidate c) is output 2 (s total + c) + 1
   // of the one mt19937 stream, so the draws of the other ranks' candidates are skipped (each uniform is one 32-bit output).
-  const int total = ctx->rng_shard_total > 0 ? ctx->rng_shard_total : B, c0 = ctx->rng_shard_total > 0 ? ctx->rng_shard_offset : 0;
+  const int total = ctx->rng_shard_total > 0 ? ctx->rng_shard_total : B, c0 = shard_base(ctx);
   std::vector<float> samples(B);
   if (c0 > 0) ctx->generator.discard(2ull * c0);
   for (int c = 0; c < B; c++) {

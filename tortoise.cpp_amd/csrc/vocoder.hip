@@ -555,7 +555,7 @@ int voc_run(tts_ctx *ctx, const float *mel, const int32_t *frames, int B, const 
   } else {
     for (int c = 0; c < B; c++) {
       int64_t n = (int64_t)64 * lay.len[c];
-      voc_philox_kernel<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(st->nzsrc.as<float>() + nz_off[c], n, ctx->seed_value, (uint32_t)(ctx->rng_shard_offset + c)); // stream = global candidate id
+      voc_philox_kernel<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(st->nzsrc.as<float>() + nz_off[c], n, ctx->seed_value, (uint32_t)(shard_base(ctx) + c)); // stream = global candidate id
     }
   }
   voc_mel_rows_kernel<<<R, 128, 0, ctx->stream>>>(st->melsrc.as<float>(), d_mel_off, d_rs, d_rt, d_ln, st->melrows.as<float>());
