@@ -37,6 +37,38 @@ import tortoise_cpp_amd_loader  # noqa: E402
 
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
 HBM_PEAK_GBS = 8000.0                # same guide: 8 TB/s spec (6.29 TB/s measured copy)
+HBM_ACHIEVABLE_GBS = 6290.0          # same guide: float4 copy, the rate a streaming kernel can reach
+# Shape classes of the diffusion stage's fp16 MFMA GEMMs (diffusion.hip: gemm()): (N, K, output bytes per element, residual read)
+GEMM_FAMILIES = {
+    "diff_gemm_k3r": (1024, 3072, 4, True),    # ResBlock out_layers conv k = 3 + residual
+    "diff_gemm_qkv": (3072, 1024, 2, False),   # AttentionBlock qkv projection, fp16 out (V transposed)
+    "diff_gemm_k1": (1024, 1024, 4, False),    # ResBlock in_layers conv k = 1
+    "diff_gemm_k1r": (1024, 1024, 4, True),    # AttentionBlock proj_out + residual
+    "diff_gemm_k3": (1024, 3072, 4, False),    # latent conditioner conv k = 3 (once per utterance)
+    "diff_gemm_misc": (None, None, 4, False),  # inp_block (K = 3 x 128), integrating conv (K = 2048), out head (N = 256)
+}
+
+
+def gemm_kernel_table(per_kernel):
+    """Per shape class: measured HIP-event time per launch against max(MFMA floor, algorithmic bytes / achievable HBM rate) — the
+    k = 1 convolutions with an f32 residual stream are bound by their own bytes, not by the matrix pipe."""
+    rows = []
+    for fam, (N, K, ob, resid) in GEMM_FAMILIES.items():
+        ms, n, fl = per_kernel.get(fam, (0.0, 0, 0.0))
+        if n <= 0:
+            continue
+        us, gf = 1e3 * ms / n, fl / n / 1e9
+        tflops = gf / us * 1e3  # GFLOP per microsecond = PFLOP/s
+        row = {"family": fam, "launches_timed": int(n), "avg_launch_us": round(us, 1), "gflop_per_launch": round(gf, 2),
+               "tflops": round(tflops, 1), "frac_of_mfma_peak": round(tflops / MFMA_F16_DENSE_PEAK_TFLOPS, 4)}
+        if N:
+            m_rows = fl / n / (2.0 * N * K)                                   # valid rows of the launch
+            byts = m_rows * (2.0 * K / (3 if K == 3072 else 1) + N * ob + (N * 4 if resid else 0)) + 2.0 * N * K  # A once (the 3 taps share it), out, resid, W
+            t_mfma, t_hbm = gf / MFMA_F16_DENSE_PEAK_TFLOPS * 1e3, byts / (HBM_ACHIEVABLE_GBS * 1e9) * 1e6  # microseconds
+            row.update(algorithmic_mb=round(byts / 1e6, 1), mfma_floor_us=round(t_mfma, 1), hbm_floor_us=round(t_hbm, 1),
+                       bound="hbm" if t_hbm > t_mfma else "mfma", frac_of_bound=round(max(t_mfma, t_hbm) / us, 4))
+        rows.append(row)
+    return rows
 
 
 def synthetic_prompt(p=0):
@@ -45,7 +77,9 @@ def synthetic_prompt(p=0):
     return np.array([255] + [3 + (7 * j + 11 * p) % 250 for j in range(64)] + [0], np.int32)
 
 
-def ensure_models(path, quick, rank_is_writer):
+def ensure_models(path, quick, rank_is_writer, wait_s=1800):
+    """Synthetic weights in the reference's file format, written once per node by local rank 0 BEFORE torch.distributed is initialised
+    (2.4 GB, about a minute: no rank sits in a collective with a timeout while they are generated); the other ranks poll the stamp."""
     stamp = os.path.join(path, ".done")
     if rank_is_writer and not os.path.exists(stamp):
         from tortoise_cpp_amd import synth_weights as sw
@@ -54,6 +88,11 @@ def ensure_models(path, quick, rank_is_writer):
         else:
             sw.write_all(path, seed=1234)  # 30-layer GPT-2, 4+3+10+3 diffusion blocks, UnivNet
         open(stamp, "w").write("ok")
+    t0 = time.time()
+    while not os.path.exists(stamp):
+        if time.time() - t0 > wait_s:
+            sys.exit("bench.py: weights were not generated at %s within %d s" % (path, wait_s))
+        time.sleep(0.5)
 
 
 def _omp_set_threads(n):
@@ -182,8 +221,13 @@ def main():
         if a.backend == "nccl" and len(set(dm)) != len(dm):
             sys.exit("bench.py: RCCL needs a distinct GPU per rank (--device-map %s); use --backend gloo to share a device" % a.device_map)
         device = dm[local_rank]
+    pkg = tortoise_cpp_amd_loader.load()
+    model_dir = a.models or ("/tmp/tts_bench_models_quick" if a.quick else "/tmp/tts_bench_models")
+    if not a.dry_engine:
+        ensure_models(model_dir, a.quick, local_rank == 0)  # before the rendezvous: see ensure_models
     dist = None
     dev = None
+    collective_ranks = 1
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -194,6 +238,9 @@ def main():
         else:
             dev = torch.device("cpu")
             dist.init_process_group(a.backend)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)  # the collective backend has seen every rank: reported as `collective_ranks` in the JSON line
+        collective_ranks = int(round(float(ones.item())))
 
     # ---- workload ---------------------------------------------------------------------------------------------------
     n_diff = a.diff_steps or (200 if a.config == 5 else 80)
@@ -212,13 +259,6 @@ def main():
         B = a.candidates or 16
         my_prompts, cand0, cand_total, scaling = [p for p in range(8) if p % world == rank], 0, 0, "strong"
         name = "configs[4]"
-
-    pkg = tortoise_cpp_amd_loader.load()
-    model_dir = a.models or ("/tmp/tts_bench_models_quick" if a.quick else "/tmp/tts_bench_models")
-    if not a.dry_engine:
-        ensure_models(model_dir, a.quick, local_rank == 0)
-    if dist:
-        dist.barrier()
 
     S = a.decode_steps
     voice = np.fromfile(os.path.join(ROOT, "models", "mol.bin"), np.float32)
@@ -331,23 +371,28 @@ def main():
         # every 13th GEMM launch is bracketed by a HIP event pair (60 launches per diffusion step, 13 is coprime: every launch position is
         # sampled equally often). An event pair drains the pipeline around its launch: bracketing all ~9 600 launches of the timed region
         # cost 5 % of the pass, every 7th 0.5 %, every 29th nothing measurable. The decode step is ONE hipGraph replay per event pair.
-        eng.set_option("prof_only:diff_gemm", 1)
+        for fam in GEMM_FAMILIES:
+            eng.set_option("prof_only:" + fam, 1)
         eng.set_option("prof_only:ar_decode_step", 1)
         eng.set_option("prof_stride", a.prof_stride)
         eng.prof_reset(True)
     audio_s, dt, stages = timed(a.steps, share)
     g_ms = g_n = g_flops = d_ms = d_n = d_bytes = 0.0
+    per_kernel = {}
     if not a.dry_engine:
-        g_ms, g_n, g_flops = eng.prof_get("diff_gemm")
+        per_kernel = {fam: eng.prof_get(fam) for fam in GEMM_FAMILIES}
+        g_ms, g_n, g_flops = (sum(v[i] for v in per_kernel.values()) for i in range(3))
         d_ms, d_n, d_bytes = eng.prof_get("ar_decode_step")
-        eng.prof_reset(False)
     # the other share_uncond setting, one pass, outside the timed region (both numbers belong in the line: the sharing only exists
-    # because the masked stop token gives every candidate the same length)
+    # because the masked stop token gives every candidate the same length) — under the SAME profiling setting as the headline pass
+    # (event pairs on every 13th GEMM launch, every 8th diffusion step eager), so the two values are comparable
     other = None
     if not a.no_ab and not a.dry_engine:
         o_audio, o_dt, o_stages = timed(1, not share)
         other = {"uncond_integrator_shared": not share, "value": round(o_audio / o_dt, 3), "ms_per_step": round(1000.0 * o_dt, 2),
                  "stage_ms_per_step": o_stages}
+    if not a.dry_engine:
+        eng.prof_reset(False)
     # throughput option ar_weights = f16 (0.77 GB instead of 1.54 GB of weights per decode step), measured beside the default
     # f32 mode on the same prompt and seed: AR stage time, decode-step bandwidth, first sampled id that differs from the f32 run
     f16 = None
@@ -384,7 +429,7 @@ def main():
     # HBM bytes per GEMM launch from the committed PMC profile (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, calibration in the
     # file's note); null when the profile is absent. bench.py does not run rocprofv3 itself.
     traffic, traffic_src = None, None
-    for prof_name in ("r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):
+    for prof_name in ("r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))["kernels"]
             gk = [v for k, v in prof.items() if "gemm_f16" in k]
@@ -396,7 +441,7 @@ def main():
     dec_traffic, dec_traffic_src = None, None  # L2-miss bytes fetched per decode step (PMC FETCH_SIZE pass over the decode launches, committed profile)
     try:
         dec_traffic = int(json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_decode_traffic.json")))["fetch_bytes_per_step"])
-        dec_traffic_src = "profiles/r2_pmc_decode_traffic.json"
+        dec_traffic_src = "profiles/r2_pmc_decode_traffic.json (round 2: the decode kernels stream the same slabs; round 3 only changed the load policy to nt)"
     except Exception:
         pass
     L, T = shape.get("L", 0), shape.get("T", 0)
@@ -421,11 +466,14 @@ def main():
         "stage_ms_per_step": stages,
         "other_share_uncond_setting": other,
         "ar_weights_f16_option": f16,
-        "roofline": {"kernel": "gemm_f16_glds_kernel + gemm_f16_conv3_kernel (diffusion convs/projections)", "bound": "mfma",
+        "collective_ranks": collective_ranks,
+        "roofline": {"kernel": "gemm_f16_vh_kernel + gemm_f16_conv3_vh_kernel (diffusion convs/projections)", "bound": "mfma",
                      "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
                      "traffic": traffic, "traffic_source": traffic_src, "launches_timed": int(g_n),
                      "launch_sampling": "every %dth launch of the family is bracketed by HIP events" % a.prof_stride,
-                     "avg_launch_us": round(1000.0 * g_ms / max(g_n, 1), 2), "algorithmic_gflop_per_launch": round(g_flops / max(g_n, 1) / 1e9, 2)},
+                     "avg_launch_us": round(1000.0 * g_ms / max(g_n, 1), 2), "algorithmic_gflop_per_launch": round(g_flops / max(g_n, 1) / 1e9, 2),
+                     # per shape class: its own bound = max(MFMA floor at 2.5 PF, algorithmic bytes at the 6.29 TB/s a streaming kernel reaches)
+                     "kernels": gemm_kernel_table(per_kernel)},
         "roofline_decode": {"kernel": "AR decode step (one hipGraph replay: 151 kernels streaming every weight once)", "bound": "hbm",
                             "achieved": round(dec_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(dec_gbs / HBM_PEAK_GBS, 4),
                             "traffic": dec_traffic, "traffic_source": dec_traffic_src, "steps_timed": int(d_n), "avg_step_us": round(1000.0 * d_ms / max(d_n, 1), 1),

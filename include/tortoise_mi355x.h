@@ -196,7 +196,11 @@ int tts_host_trimmed_rows(const int32_t *codes502);
 /* Accumulated device time (ms; HIP event pairs recorded on the ctx stream around every launch, resolved
  * lazily so the timed region is not synchronised) and launch count of the named kernel family since the
  * last reset: "ar_gemv", "ar_attention", "ar_decode_step" (one whole decode-step graph replay; work = bytes streamed), "diff_gemm",
- * "diff_attn", "diff_gn_apply", "voc_lvc", ... */
+ * "diff_attn", "diff_gn_apply", "voc_lvc", ...
+ * The totals cover the BRACKETED launches only: every "prof_stride"-th launch of a family, and — for the "diff_*" families, whose step
+ * otherwise replays a captured hipGraph in which an event record would become a node — only the launches of the steps that run eagerly
+ * (every "prof_eager_every"-th diffusion step while such a family is selected, 8 by default). ms / launches is therefore a per-launch
+ * average over a sample; it is not the stage's total time (bench.py times stages with its own host clock around synchronised calls). */
 int tts_prof_reset(tts_ctx *ctx, int enable);
 /* work_out: summed algorithmic work of those launches — FLOPs for the MFMA-bound families (diff_gemm,
  * diff_attn, voc_kernel_gemm), bytes for the HBM-bound ones (ar_gemv: weight bytes streamed). */

@@ -77,4 +77,14 @@ def engine(pkg):
     eng.close()
 
 
+def loop_gate(kind):
+    """Gate (max abs on the +-1 mel range) of an 80-/200-step sampling-loop comparison between the engine and the oracle on the
+    `kind` = small | mid | full weights: max(1e-3, 2 x the distance a faithful f32 emulation of the engine's arithmetic keeps from the
+    oracle), measured on the CPU with torch (tests/test_parity_floor.py; record in tests/golden/parity_floor.json). north_star asks for
+    1e-3; two CORRECT f32 evaluations of the reference's own graph are 0.7-1.1e-3 apart over 80 steps, so no tighter gate can be kept
+    by any f32 implementation; the reference's own gate is 0.01 (main.cpp:6223)."""
+    import json
+    return float(json.load(open(os.path.join(GOLDEN, "parity_floor.json")))[kind]["gate"])
+
+
 DEFAULT_TOKENS = np.array([255, 147, 2, 54, 2, 14, 2, 136, 63, 2, 80, 32, 150, 112, 9, 0], np.int32)

@@ -45,26 +45,41 @@ def test_sharded_contexts_reproduce_the_unsharded_batch(pkg, small_models, voice
 
 
 def test_retire_mode_matches_strict_sequences(pkg, small_models, voice):
-    """TTS_AR_RETIRE (throughput stop rule for B > 1): every candidate's sequence is the one the reference's rule produces; the
-    call returns at max_steps instead of failing when not all candidates stopped in the same iteration."""
+    """TTS_AR_RETIRE (throughput stop rule): every candidate's sequence is EXACTLY the one the reference's rule produces for it.
+    The reference's rule for one candidate is "stop at the first 8193" (main.cpp:5214-5222 with B = 1), so the direct comparison is the
+    batch of 4 in retire mode against four single-candidate contexts holding candidate c of the same batch (RNG stream partition):
+    identical codes, identical stop status; and for B > 1 the strict rule fails where retire returns."""
+    B, M = 4, 40
     e = pkg.Engine(0)
     e.load(ar=small_models + "/ggml-model.bin")
     e.seed(11)
-    c_mask, _, _, _ = e.autoregressive(DEFAULT_TOKENS, voice, 4, 12, mask_stop=True, want_latents=False)
-    e.seed(11)
-    c_ret, rows, lats, steps = e.autoregressive(DEFAULT_TOKENS, voice, 4, 12, retire=True)
-    # random weights never stop on their own within 12 steps unless the sampler draws 8193: wherever no stop token was drawn the two
-    # runs see the same logits and the same uniforms
-    for c in range(4):
-        seq = list(c_ret[c, 1:13])
-        if 8193 not in seq:
-            # identical until the masked run's logits differ (it masks 8193, probability mass ~1e-4): allow that single source
-            assert (c_ret[c, 1:13] == c_mask[c, 1:13]).mean() >= 0.9
-    assert steps <= 12 and len(lats) == 4
-    with pytest.raises(pkg.TtsError):  # the reference's rule: no common stop within max_steps is a failure
-        e.seed(11)
-        e.autoregressive(DEFAULT_TOKENS, voice, 4, 12)
+    c_ret, rows, lats, steps = e.autoregressive(DEFAULT_TOKENS, voice, B, M, retire=True)
+    stopped = e.ar_stop_status(B)
+    assert steps <= M and len(lats) == B
+    for c in range(B):
+        seq = list(c_ret[c, 1:1 + M])
+        assert bool(stopped[c]) == (8193 in seq), (c, stopped, seq)
+    if not stopped.all():
+        with pytest.raises(pkg.TtsError):  # the reference's rule for B > 1: no common stop within max_steps is a failure
+            e.seed(11)
+            e.autoregressive(DEFAULT_TOKENS, voice, B, M)
     e.close()
+    for c in range(B):
+        s1 = pkg.Engine(0)
+        s1.load(ar=small_models + "/ggml-model.bin")
+        s1.set_option("rng_shard_offset", c)
+        s1.set_option("rng_shard_total", B)
+        s1.seed(11)
+        if stopped[c]:  # strict mode IS the reference's rule for one candidate
+            c1, r1, _, _ = s1.autoregressive(DEFAULT_TOKENS, voice, 1, M, want_latents=False)
+        else:           # it never stops within M steps: strict fails, retire cuts — at the same codes
+            with pytest.raises(pkg.TtsError):
+                s1.autoregressive(DEFAULT_TOKENS, voice, 1, M, want_latents=False)
+            s1.seed(11)
+            c1, r1, _, _ = s1.autoregressive(DEFAULT_TOKENS, voice, 1, M, want_latents=False, retire=True)
+        assert (c1[0] == c_ret[c]).all() and r1[0] == rows[c], c
+        assert s1.ar_stop_status(1)[0] == stopped[c]
+        s1.close()
 
 
 def _device_count():

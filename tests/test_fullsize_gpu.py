@@ -3,14 +3,16 @@ conditioner + 3 integrator + 10 main + 3 tail diffusion blocks, UnivNet — the 
 against the oracle through the C ABI. Error compounds with depth (30 fp16-QKV rounding points, 13 AttentionBlocks with fp16 P.V),
 so the reduced-depth tests in test_ar_gpu.py / test_diffusion_gpu.py do not cover this.
 
-Gates: AR logits 1e-4 relative (f32 on both sides), latents and mel/audio 1e-3 relative (north star), the sampling loop the
-reference's own gate abs 0.01 (main.cpp:6223). configs[1] = test_config1_end_to_end, configs[2] = test_config2_batch16."""
+Gates: AR logits 1e-4 relative (f32 on both sides), latents and mel/audio of ONE evaluation 1e-3 relative (north star), the 80-/200-step
+sampling loop conftest.loop_gate = max(1e-3, 2 x the distance a faithful f32 emulation of the engine's arithmetic keeps from the oracle,
+tests/test_parity_floor.py): 2.3e-3 .. 5e-3 against the reference's own 0.01 (main.cpp:6223).
+configs[1] = test_config1_end_to_end, configs[2] = test_config2_batch16 (+ the two full-shape tests), configs[4] = test_config5_shape_200_steps."""
 import os
 
 import numpy as np
 import pytest
 
-from conftest import DEFAULT_TOKENS
+from conftest import DEFAULT_TOKENS, loop_gate
 
 pytestmark = pytest.mark.gpu
 
@@ -86,8 +88,8 @@ def test_vocoder_full(full_engine, oracle, full_models, T):
 
 @pytest.mark.parametrize("models,L", [("small", 12), ("mid", 12)])
 def test_sampling_loop_80_steps(engine, oracle, small_models, mid_models, models, L):
-    """tts_diffusion over the full 80-step schedule against the oracle's diffusion() with the same explicit noise — the
-    reference's own gate: max abs 0.01 on the mel (main.cpp:6223); mean reported."""
+    """tts_diffusion over the full 80-step schedule against the oracle's diffusion() with the same explicit noise; gate conftest.loop_gate
+    (the reference's own: max abs 0.01 on the mel, main.cpp:6223); mean reported."""
     d = small_models if models == "small" else mid_models
     engine.load(diffusion=d + "/ggml-diffusion-model.bin")
     od = oracle.Diffusion(oracle.Model(d + "/ggml-diffusion-model.bin"))
@@ -97,8 +99,8 @@ def test_sampling_loop_80_steps(engine, oracle, small_models, mid_models, models
     mel = engine.diffusion([lat], n_steps=80, noise=[noise])[0]
     want = od.sample(lat, n_steps=80, noise=noise)
     err = np.abs(mel - want)
-    print("80-step loop (%s weights, T=%d): max abs %.2e mean %.2e" % (models, T, err.max(), err.mean()))
-    assert np.abs(want).max() <= 1.5 and err.max() <= 0.01, (err.max(), err.mean())
+    print("80-step loop (%s weights, T=%d): max abs %.2e mean %.2e (gate %.1e)" % (models, T, err.max(), err.mean(), loop_gate(models)))
+    assert np.abs(want).max() <= 1.5 and err.max() <= loop_gate(models), (err.max(), err.mean())
 
 
 def test_config1_end_to_end(full_engine, oracle, full_models, voice):
@@ -113,7 +115,11 @@ def test_config1_end_to_end(full_engine, oracle, full_models, voice):
     rng = oracle.Rng(seed)
     rc, codes_o, steps_o, _ = ar.generate(toks, voice, 1, rng, S, mask_stop=True)
     assert rc == 0 and steps == steps_o == S
-    if not (codes == codes_o).all():  # a split must be explained by sub-tolerance logits at the first divergent step
+    ids_identical = bool((codes == codes_o).all())
+    if not ids_identical:
+        # A split must be explained by sub-tolerance logits at the first divergent step (the reference's fp16 rounding of QKV turns 1e-7
+        # round-off into occasional 5e-4 jumps that can flip a multinomial draw) — and then the later stages are STILL checked, teacher-forced:
+        # the engine continues on the oracle's codes (both sides have consumed 2 uniforms per step, so the RNG stream is in lock-step).
         j = int(np.argwhere(codes[0] != codes_o[0])[0][0])
         ar.start(toks, voice, 1, len(toks) + 2 + S + 1)
         eng.ar_begin(toks, voice, 1, S)
@@ -121,8 +127,9 @@ def test_config1_end_to_end(full_engine, oracle, full_models, voice):
         for i in range(j - 1):
             lo, lg = ar.step(codes_o[:, 1 + i], i), eng.ar_step(codes_o[:, 1 + i], i)
         assert rel_err(lg, lo) < 1e-4
-        pytest.skip("AR trajectories split at step %d with logits within %.1e (fp16-QKV rounding flip): the lock-step comparison of "
-                    "the later stages does not apply to this seed" % (j - 1, rel_err(lg, lo)))
+        print("configs[1]: AR trajectories split at step %d with logits within %.1e; later stages teacher-forced on the oracle's codes" % (j - 1, rel_err(lg, lo)))
+        rows = np.array([oracle.trimmed_rows(codes_o[0])], np.int32)
+        lats = [eng.ar_latents(codes_o, int(rows[0]) + 1)[0, :int(rows[0])]]
     L = int(rows[0])
     lat_o = ar.latents(codes_o, L + 1)[0, :L]
     e_lat = rel_err(lats[0], lat_o)
@@ -142,10 +149,10 @@ def test_config1_end_to_end(full_engine, oracle, full_models, voice):
     # mel difference through a network that amplifies it; it is reported, the reference gates each stage on its own fixture)
     nz = np.random.RandomState(4).randn(64, mel_o.shape[1] + 10).astype(np.float32)
     e_voc = rel_err(eng.vocoder([mel_o], noise=[nz])[0], ov.run(mel_o, noise=nz))
-    print("configs[1] end to end: ids identical (%d codes), latents rel %.1e, mel max abs %.2e mean %.2e, vocoder on the oracle's mel rel %.2e; "
-          "end-to-end audio max abs %.2e of range %.2f" % (S, e_lat, dm.max(), dm.mean(), e_voc, da.max(), np.abs(au_o).max()))
+    print("configs[1] end to end: ids %s (%d codes), latents rel %.1e, mel max abs %.2e mean %.2e, vocoder on the oracle's mel rel %.2e; "
+          "end-to-end audio max abs %.2e of range %.2f" % ("identical" if ids_identical else "teacher-forced", S, e_lat, dm.max(), dm.mean(), e_voc, da.max(), np.abs(au_o).max()))
     assert e_lat < 1e-3
-    assert dm.max() <= 0.01  # the reference's gate on target_mel (main.cpp:6223)
+    assert dm.max() <= loop_gate("full")  # (the reference's gate on target_mel: 0.01, main.cpp:6223)
     assert e_voc < 1e-3
 
 
@@ -180,7 +187,7 @@ def test_config2_batch16(full_engine, oracle, full_models, voice, pkg):
     mels = eng.diffusion(lats, n_steps=4, noise_mode=pkg.NOISE_DEVICE)
     assert all(np.isfinite(m).all() and np.abs(m).max() <= 1.5 for m in mels)
     # the same batch over the full 80-step schedule with explicit noise, against the oracle for the first and the last candidate:
-    # the reference's gate, max abs 0.01 (main.cpp:6223)
+    # conftest.loop_gate (the reference's own gate: max abs 0.01, main.cpp:6223)
     T = eng.frames(L)
     rs = np.random.RandomState(9)
     noise = [rs.randn(81, 100 * T).astype(np.float32) for _ in range(B)]
@@ -190,7 +197,7 @@ def test_config2_batch16(full_engine, oracle, full_models, voice, pkg):
         want = od.sample(lats[c], n_steps=80, noise=noise[c])
         err = np.abs(mels[c] - want)
         print("configs[2] batched 80-step sampling loop cand %d (T=%d): max abs %.2e mean %.2e" % (c, T, err.max(), err.mean()))
-        assert err.max() <= 0.01, (c, err.max(), err.mean())
+        assert err.max() <= loop_gate("full"), (c, err.max(), err.mean())
     del od
     nz = [rs.randn(64, T + 10).astype(np.float32) for _ in range(B)]
     aus = eng.vocoder(mels, noise=nz)
@@ -228,10 +235,10 @@ def test_config2_full_shape_batch_invariance(full_engine, pkg):
         eng.set_option("rng_shard_total", 0)
 
 
-@pytest.mark.skipif(not os.environ.get("TTS_LONG_TESTS"), reason="about 3 minutes of oracle time on the host: run with TTS_LONG_TESTS=1 (result in DESIGN.md section 4)")
+@pytest.mark.skipif(bool(os.environ.get("TTS_SKIP_LONG_TESTS")), reason="TTS_SKIP_LONG_TESTS set (about 2.5 minutes of oracle time on the host)")
 def test_full_size_80_steps_at_bench_length(full_engine, oracle, full_models):
     """The benchmark's own diffusion problem for one candidate — full-size weights, L = 200 latent rows, T = 870 mel frames, all 80 steps — against
-    the oracle with the same explicit noise, at the reference's gate (max abs 0.01, main.cpp:6223). 160 full-size oracle forwards: opt-in."""
+    the oracle with the same explicit noise (160 full-size oracle forwards, about 2.5 minutes of host time; runs by default since round 3)."""
     L = 200
     od = oracle.Diffusion(oracle.Model(full_models + "/ggml-diffusion-model.bin"))
     lat = np.random.RandomState(31).randn(L, 1024).astype(np.float32)
@@ -240,8 +247,44 @@ def test_full_size_80_steps_at_bench_length(full_engine, oracle, full_models):
     mel = full_engine.diffusion([lat], n_steps=80, noise=[noise])[0]
     want = od.sample(lat, n_steps=80, noise=noise)
     err = np.abs(mel - want)
-    print("full-size 80-step loop at T=%d: max abs %.2e mean %.2e" % (T, err.max(), err.mean()))
-    assert T == 870 and np.abs(want).max() <= 1.5 and err.max() <= 0.01, (err.max(), err.mean())
+    print("full-size 80-step loop at T=%d: max abs %.2e mean %.2e (gate %.1e)" % (T, err.max(), err.mean(), loop_gate("full")))
+    assert T == 870 and np.abs(want).max() <= 1.5 and err.max() <= loop_gate("full"), (err.max(), err.mean())
+
+
+def test_config5_shape_200_steps(full_engine, oracle, full_models, pkg):
+    """configs[4] on one GPU at its real shapes: 2 distinct prompts x 16 candidates of L = 200 latent rows (T = 870), 200 diffusion steps
+    (timestep_map = round(i * 3999 / 199)), full-size weights, device noise. Size-independent property at that size: a candidate of either
+    prompt's batch equals the same candidate run alone (noise stream = global candidate id). Against the oracle where the oracle can follow
+    in suite time: the 200-step loop at full depth for one short candidate (400 full-depth oracle forwards at T = 39), explicit noise."""
+    eng = full_engine
+    B, L, steps = 16, 200, 200
+    rs = np.random.RandomState(41)
+    for prompt in range(2):
+        lats = [rs.randn(L, 1024).astype(np.float32) for _ in range(B)]
+        eng.seed(500 + prompt)
+        mels = eng.diffusion(lats, n_steps=steps, noise_mode=pkg.NOISE_DEVICE)
+        assert all(m.shape == (100, 870) and np.isfinite(m).all() and np.abs(m).max() <= 1.0 + 1e-6 for m in mels)
+        try:
+            c = (3, 12)[prompt]
+            eng.set_option("rng_shard_offset", c)
+            eng.set_option("rng_shard_total", B)
+            eng.seed(500 + prompt)
+            m1 = eng.diffusion([lats[c]], n_steps=steps, noise_mode=pkg.NOISE_DEVICE)[0]
+            dm = float(np.abs(m1 - mels[c]).max())
+            print("configs[4] shape, prompt %d candidate %d, 200 steps: batch-of-16 vs alone: mel max abs diff %.1e" % (prompt, c, dm))
+            assert dm <= 1e-5
+        finally:
+            eng.set_option("rng_shard_offset", 0)
+            eng.set_option("rng_shard_total", 0)
+    od = oracle.Diffusion(oracle.Model(full_models + "/ggml-diffusion-model.bin"))
+    lat = rs.randn(9, 1024).astype(np.float32)
+    T = eng.frames(9)
+    noise = np.random.RandomState(8).randn(steps + 1, 100 * T).astype(np.float32)
+    mel = eng.diffusion([lat], n_steps=steps, noise=[noise])[0]
+    want = od.sample(lat, n_steps=steps, noise=noise)
+    err = np.abs(mel - want)
+    print("configs[4] schedule at full depth, 200 steps, T=%d: max abs %.2e mean %.2e (gate %.1e)" % (T, err.max(), err.mean(), loop_gate("full")))
+    assert err.max() <= loop_gate("full"), (err.max(), err.mean())
 
 
 def test_full_size_ar_192_steps_teacher_forced(full_engine, oracle, full_models, voice):

@@ -10,11 +10,13 @@ with the SAME explicit noise for every evaluation, what that number has to be co
                 (north-star: "MFMA ... for the dense fp16 GEMMs in attention") vs the reference's F32 AttentionBlock — the part of the
                 GPU-vs-oracle distance that is a design decision, not evaluation order.
 
-Measured (8 threads, L = 12 / T = 52, small and mid weights; L = 40 / T = 174; full depth L = 32 / T = 139 in tests/golden/parity_floor.json):
-floor_f32 7-9e-4, oracle 7-8e-4, engine_math 1.0e-3, engine_math in f32 1.1e-3 — i.e. the north-star's 1e-3 is the distance between two
-CORRECT f32 evaluations of this loop; no f32 implementation can promise to be inside it against another one. The GPU gates in
-tests/test_diffusion_gpu.py / tests/test_fullsize_gpu.py are max(1e-3, 2 x floor) with the floors recorded in tests/golden/parity_floor.json
-(regenerate: TTS_REGEN_FLOOR=1 python -m pytest tests/test_parity_floor.py -s).
+Measured (tests/golden/parity_floor.json: small / mid weights at L = 9 .. 30, full depth at L = 20 / 32, T = 87 / 139): floor_f32 7-8e-4 at reduced
+depth and 1.1e-3 at full depth, the oracle 7-9e-4, engine_math 1.0-1.4e-3 at reduced depth and 1.9-2.1e-3 at full depth, `pair` (an f32 emulation of
+the engine's arithmetic vs the oracle, i.e. what a correct GPU implementation should show against the oracle) 1.0-1.4e-3 / 2.0-2.5e-3.
+So north-star's 1e-3 is the distance between two CORRECT f32 evaluations of the reference's own graph over this loop: no f32 implementation can
+promise to stay inside it against another one, and the engine's fp16 attention (a north-star design decision) costs about one more floor.
+The GPU gates in tests/test_diffusion_gpu.py / tests/test_fullsize_gpu.py are conftest.loop_gate = max(1e-3, 2 x pair): 2.3e-3 / 2.9e-3 / 5.0e-3
+instead of the reference's 0.01 (regenerate the small-weights sample: TTS_REGEN_FLOOR=1 python -m pytest tests/test_parity_floor.py -s).
 """
 import json
 import os
@@ -81,10 +83,14 @@ def test_loop_level_parity_floor(small_models, oracle):
 
 
 def test_floor_record_is_consistent():
-    """The committed floors the GPU gates are derived from: every gate is max(1e-3, 2 x floor), and no floor is below north-star's 1e-3
-    by enough to make 1e-3 a promise an f32 implementation could keep against another f32 implementation."""
+    """The committed floors the GPU gates are derived from: gate = max(1e-3, 2 x pair) where pair = the largest distance an f32 emulation
+    of the engine's arithmetic kept from the oracle over the recorded samples; and no floor is so far below north-star's 1e-3 that 1e-3 would
+    be a promise one f32 implementation could keep against another."""
     rec = json.load(open(FLOOR_JSON))
     for key in ("small", "mid", "full"):
         f = rec[key]
-        assert 4e-4 < f["floor_f32"] < 5e-3 and 4e-4 < f["engine_math"] < 5e-3, (key, f)
-        assert f["gate"] == pytest.approx(max(1e-3, 2.0 * max(f["floor_f32"], f["engine_math"])), rel=0.26), (key, f)
+        for fld in ("floor_f32", "oracle", "engine_math", "pair"):
+            assert f[fld] == max(x[fld] for x in f["samples"]), (key, fld)
+            assert 4e-4 < f[fld] < 5e-3, (key, fld, f[fld])
+        assert f["gate"] == pytest.approx(max(1e-3, 2.0 * f["pair"]), rel=1e-2), (key, f["gate"], f["pair"])
+        assert f["gate"] < 0.01  # tighter than the reference's own gate (main.cpp:6223) at every depth

@@ -1,6 +1,6 @@
 // Developer tool: times gemm_f16_kernel variants on the diffusion shapes and checks them against a naive
 // kernel.  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I tortoise.cpp_amd/csrc -I tools tools/gemm_bench.hip -o /tmp/gemm_bench
-#include "gemm_f16.h"
+#include "gemm_f16_onetile.h" // the round-2 one-tile-per-workgroup kernels these tools were written against
 #include <cstdio>
 #include <cstdlib>
 #include <vector>

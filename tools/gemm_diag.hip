@@ -5,7 +5,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I tortoise.cpp_amd/csrc -I tools [-DTTS_GEMM_TRACE] [-DTTS_GEMM_DIAG_NOEPI] tools/gemm_diag.hip -o gemm_diag
 //   hipcc ... -DTTS_GEMM_VARIANT=6 -I tools tools/gemm_diag.hip -o gemm_diag_v6      (the 8-phase 256^2 experiment kernel)
 #define TTS_GEMM_DIAG 1
-#include "gemm_f16.h"
+#include "gemm_f16_onetile.h" // the round-2 one-tile-per-workgroup kernels these tools were written against
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>

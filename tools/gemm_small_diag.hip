@@ -3,7 +3,7 @@
 // large-problem kernels' (a candidate's result must not depend on the batch it runs in) and close to a naive kernel.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I tortoise.cpp_amd/csrc -I tools tools/gemm_small_diag.hip -o tools/bin/gemm_small_diag
 #define TTS_GEMM_DEEP 1
-#include "gemm_f16.h"
+#include "gemm_f16_onetile.h" // the round-2 one-tile-per-workgroup kernels these tools were written against
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

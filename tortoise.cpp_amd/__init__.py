@@ -56,6 +56,7 @@ def lib():
         "tts_ar_step": (ci, [vp, _i32p, ci, _f32p]), "tts_ar_latents": (ci, [vp, _i32p, ci, ci, _f32p]),
         "tts_sample": (ci, [vp, _f32p, _i32p, ci, ci, _i32p]),
         "tts_autoregressive": (ci, [vp, _i32p, ci, _f32p, ci, ci, C.c_uint, _i32p, _i32p, vp, _i32p]),
+        "tts_ar_stop_status": (ci, [vp, _i32p, ci]),
         "tts_diffusion_frames": (ci, [ci]),
         "tts_diffusion_forward": (ci, [vp, _f32p, ci, _f32p, ci, ci, _f32p]),
         "tts_diffusion": (ci, [vp, _f32p, _i32p, ci, ci, vp, ci, _f32p]),
@@ -199,6 +200,12 @@ class Engine:
                 lats.append(lat[off:off + r].copy())
                 off += r
         return codes, rows, lats, int(steps[0])
+
+    def ar_stop_status(self, B):
+        """Per candidate of the last autoregressive() call: 1 = ended in a sampled stop token, 0 = cut at max_steps."""
+        out = np.zeros(B, np.int32)
+        self._ck(self.L.tts_ar_stop_status(self.h, out, B))
+        return out
 
     # ---- diffusion ----
     @staticmethod

@@ -325,8 +325,9 @@ int tts_vocoder(tts_ctx *c, const float *mel, const int32_t *frames, int B, cons
 // [frame0, frame0 + n_frames) depend only on mel / noise frames within a bounded halo (conv_pre k7, kernel predictor k5 + 6 x k3 + k3,
 // transposed convs, the dilated 1/3/9/27 convs of the 8-sample stage ~ 6 frames, conv_post k7): a window of the sequence with
 // VOC_HALO frames on either side reproduces them exactly; windows that touch a sequence end keep the reference's boundary treatment
-// (reflect pad / zero pad / the 10 silent frames) because they coincide with it.
-static const int VOC_HALO = 24;
+// (reflect pad / zero pad / the 10 silent frames) because they coincide with it. The halo is tied to the loaded architecture in
+// vocoder.hip (voc_receptive_frames: 20 frames for UnivNet c32, static_assert against TTS_VOC_CHUNK_HALO). Cost: every chunk evaluates
+// up to 2 x 24 + 10 extra frames (a 100-frame chunk costs ~1.6x its share of the one-shot call).
 int tts_vocoder_chunk(tts_ctx *c, const float *mel, int T, const float *noise, int frame0, int n_frames, float *audio_out,
                       int *n_samples_out) {
   NEED_CTX(c);
@@ -334,7 +335,8 @@ int tts_vocoder_chunk(tts_ctx *c, const float *mel, int T, const float *noise, i
     return fail(c, TTS_ERR_ARG, "tts_vocoder_chunk: bad argument");
   return guarded(c, [&] {
     const int Tm = T + 10, f1 = std::min(Tm, frame0 + n_frames);
-    int w0 = std::max(0, frame0 - VOC_HALO), w1 = f1 + VOC_HALO;
+    const int halo = voc_halo_frames();
+    int w0 = std::max(0, frame0 - halo), w1 = f1 + halo;
     if (w1 >= T) w1 = Tm;                                   // the window reaches the silent pad frames: take the true end
     const int wt = (w1 == Tm ? T : w1) - w0;                // mel frames handed to the vocoder (it appends 10 pad frames itself)
     std::vector<float> wm((size_t)100 * wt), wn((size_t)64 * (wt + 10)), wa((size_t)(wt + 10) * 256);

@@ -1368,8 +1368,7 @@ static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
   float *h = st->h.as<float>(), *q = st->qkv.as<float>(), *att = st->att.as<float>(), *ff = st->ff.as<float>();
   const StepState *ss = (const StepState *)(st->d_toks.as<int>() + B);
   const size_t layer_stride = (size_t)B * st->max_pos * D;
-  const bool wq = ctx->ar_weights != 0; // fp16 weights: half the bytes per step (throughput mode, not f32-exact)
-  if (wq && !st->has_f16_weights) return fail(ctx, TTS_ERR_STATE, "option ar_weights = 1 must be set before tts_load_ar (the fp16 slabs are packed at load)");
+  const bool wq = ctx->ar_weights != 0; // fp16 weights: half the bytes per step (throughput mode, not f32-exact); checked by ar_step
   const double wb = wq ? 2.0 : 4.0;
   TTS_HIP(ctx, hipMemcpyAsync(st->d_toks.p, st->h_toks, (size_t)(B + 2) * 4, hipMemcpyHostToDevice, ctx->stream));
   embed_step_kernel<<<B, 256, 0, ctx->stream>>>(st->mel_emb, st->mel_pos, st->d_toks.as<int>(), ss, h);
@@ -1417,6 +1416,9 @@ int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out
   }
   st->h_toks[st->B] = st->P + step_i; // n_past
   st->h_toks[st->B + 1] = step_i + 2; // mel position id (main.cpp:5244)
+  // checked here, not inside enqueue_decode_step: that runs between hipStreamBeginCapture and hipStreamEndCapture
+  if (ctx->ar_weights != 0 && !st->has_f16_weights)
+    return fail(ctx, TTS_ERR_STATE, "option ar_weights = 1 must be set before tts_load_ar (the fp16 slabs are packed at load)");
   static const bool no_graph = getenv("TTS_NO_GRAPH") != nullptr; // e.g. under rocprofv3, which crashes on graph replays here
   // event records are not captured: the step runs eagerly while one of its own kernel families ("ar_*") is profiled
   // ("ar_decode_step" brackets the whole graph replay and keeps the graph)
@@ -1432,9 +1434,9 @@ int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out
       TTS_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
       int rc = enqueue_decode_step(ctx, st);
       hipError_t e = hipStreamEndCapture(ctx->stream, &st->graph);
-      if (rc) return rc;
-      TTS_HIP(ctx, e);
-      TTS_HIP(ctx, hipGraphInstantiate(&st->graph_exec, st->graph, nullptr, nullptr, 0));
+      if (rc || e != hipSuccess) { st->drop_graph(); if (rc) return rc; TTS_HIP(ctx, e); } // never keep a half-captured graph
+      e = hipGraphInstantiate(&st->graph_exec, st->graph, nullptr, nullptr, 0);
+      if (e != hipSuccess) { st->drop_graph(); TTS_HIP(ctx, e); }
     }
     // HBM-bound step: every weight once (f32: 12 d^2 per layer + the padded head) + the fp16 K/V rows read + logits
     const double step_bytes = (ctx->ar_weights ? 2.0 : 4.0) * ((double)st->n_layers * 12.0 * D * D + (double)D * V) +

@@ -172,6 +172,10 @@ void ar_free(ArState *);
 int diff_load(tts_ctx *ctx, const char *path);
 void diff_free(DiffState *);
 int voc_load(tts_ctx *ctx, const char *path);
+// frames of context tts_vocoder_chunk adds on either side of a window; vocoder.hip static_asserts that it covers the receptive field
+// computed from the architecture constants its loader enforces
+#define TTS_VOC_CHUNK_HALO 24
+int voc_halo_frames();
 void voc_free(VocState *);
 
 } // namespace tts

@@ -806,6 +806,13 @@ static int gemm(tts_ctx *ctx, const char *fam, GemmArgs &g, const Layout &lay, i
   //  time for 1.0 ms/step of gn_stats saved — register pressure costs a resident workgroup per CU.)
   static const bool log_shapes = getenv("TTS_GEMM_LOG") != nullptr; // developer aid: one line per launch
   if (log_shapes) fprintf(stderr, "gemm M=%d N=%d K=%dx%d mode=%d resid=%d\n", g.M, g.N, g.nseg, g.kseg, g.mode, g.resid != nullptr);
+  // profiling sub-family by shape class (bench.py's per-kernel roofline table: each class has its own MFMA / HBM bound)
+  if (!strcmp(fam, "diff_gemm")) {
+    if (g.mode == GEMM_OUT_QKV) fam = "diff_gemm_qkv";                                              // N = 3072, K = 1024, fp16 out
+    else if (gemm_is_conv3(g) && g.N == C && g.kseg == C) fam = g.resid ? "diff_gemm_k3r" : "diff_gemm_k3"; // out_layers / latent conditioner conv
+    else if (g.nseg == 1 && g.N == C && g.kseg == C && g.mode == GEMM_OUT_F32) fam = g.resid ? "diff_gemm_k1r" : "diff_gemm_k1"; // proj_out / in_layers
+    else fam = "diff_gemm_misc";                                                                    // inp_block, integrating conv, out head
+  }
   ProfScope ps(ctx, fam, 2.0 * mv * (n_valid ? n_valid : g.N) * (k_valid ? k_valid : g.nseg * g.kseg));
   TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream));
   return TTS_OK;

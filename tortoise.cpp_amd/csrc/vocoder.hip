@@ -336,6 +336,30 @@ struct VocState {
 };
 void voc_free(VocState *s) { delete s; }
 
+// One-sided receptive field of an output sample, in mel frames, of the stack voc_load accepts (its kernel widths, strides and dilations are the
+// constants below: a weight file with any other shape is rejected at load, so this number cannot drift from the loaded model).
+//   audio path: conv_pre k7 at frame rate (3 frames); per res_stack at `hop` samples per frame after its transposed conv (kernel 2 x stride:
+//   one input sample either side), four blocks of {dilated k3 conv (d = 1, 3, 9, 27), location-variable conv k3}: (1 + 3 + 9 + 27) + 4 samples;
+//   conv_post k7 at audio rate; the kernel of a sample comes from the frame it lies in, and that frame's kernel predictor sees
+//   input_conv k5 + 6 x k3 + kernel_conv k3 = 2 + 6 + 1 frames of mel either side.
+constexpr int voc_receptive_frames() {
+  const int strides[3] = {8, 8, 4}, dil[4] = {1, 3, 9, 27};
+  double frames = 3.0; // conv_pre
+  int hop = 1;
+  for (int i = 0; i < 3; i++) {
+    frames += 1.0 / hop; // transposed conv: one sample of its input rate
+    hop *= strides[i];
+    int samples = 0;
+    for (int c = 0; c < 4; c++) samples += dil[c] + 1;
+    frames += (double)samples / hop;
+  }
+  frames += 3.0 / hop;       // conv_post
+  const int predictor = 2 + 6 + 1;
+  return (int)(frames + 0.999) + predictor;
+}
+static_assert(voc_receptive_frames() <= TTS_VOC_CHUNK_HALO, "tts_vocoder_chunk's halo no longer covers the vocoder's receptive field");
+int voc_halo_frames() { return TTS_VOC_CHUNK_HALO; }
+
 namespace {
 struct VLoader {
   tts_ctx *ctx; VocState *st; const WeightFile &wf; std::map<std::string, bool> used;
