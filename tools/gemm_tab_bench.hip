@@ -11,6 +11,7 @@
 #undef GEMM_TR_FLUSH
 #include "gemm_f16.h"
 #include "gemm_tile_tables.h"
+#include "gemm_f16_big.h" // the rejected 256-column kernel: policy name "big"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -115,7 +116,7 @@ int main(int argc, char **argv) {
     std::vector<GemmPlan> plans(pols.size());
     std::vector<std::string> status(pols.size());
     for (size_t pi = 0; pi < pols.size(); pi++) {
-      const bool arith = pols[pi].name.rfind("arith", 0) == 0; // arithmetic tile walk of the product (th = first height, 0 = automatic)
+      const bool arith = pols[pi].name.rfind("arith", 0) == 0 || pols[pi].name == "big"; // arithmetic tile walk (th = first height, 0 = automatic) / 256-column kernel
       if (!arith) {
         gemm_plan_build(plans[pi], sh.M, sh.N, pols[pi].sp);
         CK(hipMalloc(&plans[pi].dev, plans[pi].host.size() * sizeof(int4)));
@@ -124,7 +125,9 @@ int main(int argc, char **argv) {
       CK(hipMemset(dC2, 0xff, cbytes)); CK(hipMemset(dH2, 0, hbytes)); CK(hipMemset(dVt2, 0, vbytes));
       GemmArgs g = mk(dC2, dH2, dVt2);
       g.tiles = plans[pi].dev; g.tab_len = plans[pi].len; g.th = arith ? pols[pi].sp.h[0] : 0;
-      CK(launch_gemm_f16(g, s)); CK(hipStreamSynchronize(s));
+      if (pols[pi].name == "big") { g.th = 0; if (!gemm_use_big(g)) { status[pi] = "n/a (problem too small for the 256-column kernel)"; continue; } CK(launch_gemm_f16_big(g, s)); }
+      else CK(launch_gemm_f16(g, s));
+      CK(hipStreamSynchronize(s));
       size_t bad = 0;
       if (sh.mode == GEMM_OUT_F32) {
         std::vector<float> c(refC.size());
@@ -149,7 +152,8 @@ int main(int argc, char **argv) {
         GemmArgs g = mk(dC2, dH2, dVt2);
         tts_r2::GemmArgs g2 = mk_r2(dC2, dH2, dVt2);
         if (v >= 0) { g.tiles = plans[v].dev; g.tab_len = plans[v].len; g.th = pols[v].name.rfind("arith", 0) == 0 ? pols[v].sp.h[0] : 0; }
-        auto go = [&]() { return v < 0 ? tts_r2::launch_gemm_f16(g2, s) : launch_gemm_f16(g, s); };
+        const bool big = v >= 0 && pols[v].name == "big" && gemm_use_big(g);
+        auto go = [&]() { return v < 0 ? tts_r2::launch_gemm_f16(g2, s) : big ? launch_gemm_f16_big(g, s) : launch_gemm_f16(g, s); };
         for (int i = 0; i < 2; i++) CK(go());
         CK(hipEventRecord(e0, s));
         for (int i = 0; i < iters; i++) CK(go());
@@ -165,7 +169,25 @@ int main(int argc, char **argv) {
              v < 0 ? "" : status[v].c_str());
     }
 #ifdef TTS_GEMM_TRACE
+    if (gemm_use_big(mk(dC2, dH2, dVt2))) { // per-phase shader-clock stamps of the 256-column kernel (two K tiles of workgroup 64)
+      GemmArgs g = mk(dC2, dH2, dVt2);
+      CK(launch_gemm_f16_big(g, s)); CK(hipStreamSynchronize(s));
+      std::vector<unsigned> bt(8 * 64);
+      CK(hipMemcpyFromSymbol(bt.data(), HIP_SYMBOL(tts_big_trace), bt.size() * 4));
+      printf("  [256-column kernel, workgroup 64, K tiles 4-5; cycles: load part | barrier | fragment wait | MFMA issue | barrier]\n");
+      for (int w : {0, 1, 4, 5}) {
+        printf("    wave %d:", w);
+        const unsigned *q = &bt[w * 64];
+        for (int ph = 0; ph < 8; ph++) {
+          const unsigned *c = q + ph * 5;
+          const unsigned prev_end = ph ? c[-1] : c[0];
+          printf("  %u|%u|%u|%u|%u", c[0] - prev_end, c[1] - c[0], c[2] - c[1], c[3] - c[2], c[4] - c[3]);
+        }
+        printf("   (8 phases: %u cycles)\n", q[7 * 5 + 4] - q[0]);
+      }
+    }
     for (size_t pi = 0; pi < pols.size(); pi++) {
+      if (pols[pi].name.rfind("arith", 0) == 0 || pols[pi].name == "big") continue;
       static std::vector<unsigned long long> tr(65536 * 8);
       std::fill(tr.begin(), tr.end(), 0ull);
       CK(hipMemcpyToSymbol(HIP_SYMBOL(tts_gemm_trace), tr.data(), tr.size() * 8));

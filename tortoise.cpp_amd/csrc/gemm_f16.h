@@ -23,7 +23,9 @@
 //    residual load under a runtime `ptr ? load : 0` select is branched around by hipcc and waited for with vmcnt(0) — which also
 //    waits for the previous block's stores (one in-order counter). Every epilogue load is now issued up front, unconditionally,
 //    and the stores follow back to back.
-// Measured-and-rejected variants: tools/ (gemm_f16_onetile.h = the round-2 kernels, gemm_f16_experiments.h, ...).
+// Measured-and-rejected variants: tools/ (gemm_f16_onetile.h = the round-2 kernels, gemm_f16_experiments.h, gemm_f16_big.h = the 256-column
+// 8-phase kernel of round 3: one workgroup per CU, two wave groups in strict alternation — 94 vs 78 us on in_layers, 238 vs 204 on the QKV
+// projection, per-phase timeline in profiles/r3_gemm_256col_kernel.txt).
 #pragma once
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
