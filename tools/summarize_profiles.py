@@ -82,8 +82,37 @@ def mfma(src, dst, note):
     json.dump(out, open(dst, "w"), indent=1)
 
 
+def lds(src, dst, note):
+    """LDS activity per kernel: SQ_LDS_IDX_ACTIVE (LDS-array cycles, summed over the CUs) against the CU-cycles of the dispatch
+    (GRBM_GUI_ACTIVE / 8 x 256 CUs), bank-conflict cycles, LDS instructions and the waves' LDS issue stalls."""
+    acc = defaultdict(lambda: defaultdict(float))
+    cnt, dur, seen = defaultdict(int), defaultdict(float), set()
+    for r in csv.DictReader(open(src)):
+        k = r["Kernel_Name"]
+        if not k.startswith(("void tts::", "tts::")):
+            continue
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if (k, r["Dispatch_Id"]) not in seen:
+            seen.add((k, r["Dispatch_Id"]))
+            cnt[k] += 1
+            dur[k] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+    out = {"_note": note, "kernels": {}}
+    for k in sorted(acc, key=lambda k: -dur[k])[:12]:
+        n, a = cnt[k], acc[k]
+        gui = a["GRBM_GUI_ACTIVE"] / n
+        row = {"dispatches": n, "avg_us": round(dur[k] / n / 1e3, 1)}
+        for c in sorted(a):
+            row[c] = int(a[c] / n)
+        if gui > 0 and a.get("SQ_LDS_IDX_ACTIVE", 0) > 0:
+            row["lds_active_frac_of_cu_cycles"] = round(a["SQ_LDS_IDX_ACTIVE"] / n / (gui / 8 * 256), 4)
+        out["kernels"][short(k)] = row
+    json.dump(out, open(dst, "w"), indent=1)
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "mfma":
+    if sys.argv[1] == "lds":
+        lds(*sys.argv[2:5])
+    elif sys.argv[1] == "mfma":
         mfma(*sys.argv[2:5])
     elif sys.argv[1] == "stats":
         stats(*sys.argv[2:5])

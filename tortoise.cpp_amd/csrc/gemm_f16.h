@@ -77,7 +77,13 @@ __device__ unsigned long long tts_gemm_trace[65536 * 8];
 #define GEMM_TR_ARG
 #endif
 
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// LDS image of an operand tile: 128-byte rows (64 halves), the eight 16-byte chunks of row r stored at chunk ^ lds_swz(r). A ds_read_b128 is
+// served in groups of 16 lanes = 16 CONSECUTIVE rows, eight of them reading chunk c (fq even) and eight chunk c + 1 (fq odd): the two sets differ in
+// chunk bit 0, which the swizzle never touches, and inside a set the four rows of one parity have four different values of bits 1-2 — for ANY first
+// row. (Round 2 xor-ed all three chunk bits with (row >> 1) & 7: conflict-free only for a first row that is a multiple of 4, i.e. not for the k = 3
+// kernel's tap-shifted reads at rows +1 and +2: SQ_LDS_BANK_CONFLICT was 25 % of its LDS-active cycles, profiles/r3_pmc_lds.json.)
+__device__ __forceinline__ int lds_swz(int row) { return ((row >> 1) & 3) << 1; }
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ lds_swz(row)) << 4); }
 
 // LDS stages are filled by direct global->LDS DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass.
 // The LDS image of a DMA is lane-linear (base + lane*16), so the XOR swizzle is applied to the per-lane
@@ -255,12 +261,12 @@ __device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, 
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int row = (wave + 4 * i) * 8 + prow;
-    aoff[i] = (m0 + row) * g.lda + (pslot ^ ((row >> 1) & 7)) * 8; // pieces past the tile are never issued
+    aoff[i] = (m0 + row) * g.lda + (pslot ^ lds_swz(row)) * 8; // pieces past the tile are never issued
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int row = (wave * 4 + i) * 8 + prow;
-    boff[i] = (n0 + row) * ldw + (pslot ^ ((row >> 1) & 7)) * 8;
+    boff[i] = (n0 + row) * ldw + (pslot ^ lds_swz(row)) * 8;
   }
   const int fr = lane & 15, fq = lane >> 4;
   // Accumulators START from the residual (F32 outputs, swapped operand order: acc[i][j] = 4 consecutive columns of one row): the
@@ -410,12 +416,12 @@ __device__ __forceinline__ void gemm_conv3_vh_body(const GemmArgs &g, int m0, in
 #pragma unroll
   for (int i = 0; i < 5; i++) {
     const int row = (wave + 4 * i) * 8 + prow;
-    aoff[i] = min(row, g.M - m0 + 1) * g.lda + (pslot ^ ((row >> 1) & 7)) * 8; // rows past the buffer end are never multiplied: clamp
+    aoff[i] = min(row, g.M - m0 + 1) * g.lda + (pslot ^ lds_swz(row)) * 8; // rows past the buffer end are never multiplied: clamp
   }
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const int row = (wave * 4 + i) * 8 + prow;
-    boff[i] = row * ldw + (pslot ^ ((row >> 1) & 7)) * 8;
+    boff[i] = row * ldw + (pslot ^ lds_swz(row)) * 8;
   }
   auto stageA = [&](int kc) {
     const __half *src = abase + (min(kc, nchunks - 1) << 6);
