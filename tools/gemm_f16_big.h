@@ -60,7 +60,7 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs &g, int m0, int n0,
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int lr = (2 * wave + i) * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((lr >> 1) & 7);
+      const int c = (lane & 7) ^ lds_swz(lr);
       // A-h1 pieces past the tile's last block re-read the wave's A-h0 rows (valid memory; their LDS rows are never multiplied): no branch
       // around a DMA, every wave issues the same count
       aoff[h][i] = (m0 + (h == 1 && !a1_valid ? 0 : h * 128) + lr) * g.lda + c * 8;
@@ -131,7 +131,12 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs &g, int m0, int n0,
   }
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+#ifndef BIG_STAGGER
+#define BIG_STAGGER 1
+#endif
+#if BIG_STAGGER
   if (wr == 1) __builtin_amdgcn_s_barrier(); // stagger: group 1 runs one barrier behind group 0
+#endif
 #ifdef TTS_GEMM_TRACE
   bool tr_on = false;
   int tr_slot = 0;
@@ -209,14 +214,98 @@ __device__ __forceinline__ void gemm_big_body(const GemmArgs &g, int m0, int n0,
       quad(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
       p1 = p2;
     };
+#ifndef BIG_PREFETCH
+#define BIG_PREFETCH 0
+#endif
+    // BIG_PREFETCH: the fragments of phase p + 1 are read while phase p's MFMAs run (into the register halves those MFMAs do not use), so only the 4 reads of
+    // bf[0] stay in front of a barrier: phase 0 prefetches bf[1](t), phase 1 af[1](t), phase 2 af[0](t+1) — whose half-tile is retired by an extra vmcnt(6) in phase 1.
+    auto quad_pf = [&](auto mh_c, auto nh_c, auto prefetch) {
+      constexpr int MH = decltype(mh_c)::value, NH = decltype(nh_c)::value, NI = MH == 0 ? 4 : MI2;
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // this phase's operands (read one phase ago, or bf[0] just now)
+      __builtin_amdgcn_sched_barrier(0);
+      prefetch();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) {
+            if (NAT) acc[MH * 4 + i][NH * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[MH][i][ks], bf[NH][j][ks], acc[MH * 4 + i][NH * 2 + j], 0, 0, 0);
+            else acc[MH * 4 + i][NH * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[NH][j][ks], af[MH][i][ks], acc[MH * 4 + i][NH * 2 + j], 0, 0, 0);
+          }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    };
+    auto ktile_pf = [&](int t, auto bufc) {
+      constexpr int BUF = decltype(bufc)::value;
+      const char *bA1 = smem + BUF * 65536 + 16384, *bB0 = smem + BUF * 65536 + 32768, *bB1 = bB0 + 16384;
+      const char *nA0 = smem + (BUF ^ 1) * 65536; // A-h0 of tile t+1
+      const TP p2 = advance(p1);
+      // phase 0: bf[0](t) in front of the barrier; bf[1](t) behind it
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) bf[0][j][ks] = *(const half8 *)(bB0 + brd[j][ks]);
+      asm volatile("" ::: "memory");
+      stageA(p1, 1, BUF ^ 1);
+      quad_pf(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, [&] {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) bf[1][j][ks] = *(const half8 *)(bB1 + brd[j][ks]);
+      });
+      // phase 1
+      stageB(p2, 0, BUF);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); // A-h0 / B-h0 / B-h1 of tile t+1 have landed (this wave's pieces): A-h0(t+1) is read in phase 2
+      quad_pf(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, [&] {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+          for (int i = 0; i < MI2; i++) af[1][i][ks] = *(const half8 *)(bA1 + ard[i][ks]);
+      });
+      // phase 2
+      stageA(p2, 0, BUF);
+      quad_pf(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, [&] {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) af[0][i][ks] = *(const half8 *)(nA0 + ard[i][ks]);
+      });
+      // phase 3
+      stageB(p2, 1, BUF);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); // all of tile t+1 has landed
+      quad_pf(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, [&] {});
+      p1 = p2;
+    };
+#if BIG_PREFETCH
+    { // af[0] of tile 0 (its half-tile was retired by the prologue's wait + barrier)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) af[0][i][ks] = *(const half8 *)(smem + ard[i][ks]);
+    }
+    for (int t = 0; t < nk; t += 2) {
+      ktile_pf(t, std::integral_constant<int, 0>{});
+      if (t + 1 < nk) ktile_pf(t + 1, std::integral_constant<int, 1>{});
+    }
+#else
     for (int t = 0; t < nk; t += 2) {
       ktile(t, std::integral_constant<int, 0>{});
       if (t + 1 < nk) ktile(t + 1, std::integral_constant<int, 1>{});
     }
+#endif
   };
   if (MODE == GEMM_OUT_QKV && natural) kloop(std::true_type{});
   else kloop(std::false_type{});
+#if BIG_STAGGER
   if (wr == 0) __builtin_amdgcn_s_barrier(); // re-align the two groups
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // trailing (dummy) DMA pieces must land before the LDS is released
 #ifdef TTS_GEMM_TRACE
   if (blockIdx.x == 64 && lane < 40) tts_big_trace[wave * 64 + lane] = ((unsigned *)(smem + 131072))[wave * 64 + lane];
