@@ -6,7 +6,8 @@ so the reduced-depth tests in test_ar_gpu.py / test_diffusion_gpu.py do not cove
 Gates: AR logits 1e-4 relative (f32 on both sides), latents and mel/audio of ONE evaluation 1e-3 relative (north star), the 80-/200-step
 sampling loop conftest.loop_gate = max(1e-3, 2 x the distance a faithful f32 emulation of the engine's arithmetic keeps from the oracle,
 tests/test_parity_floor.py): 2.3e-3 .. 5e-3 against the reference's own 0.01 (main.cpp:6223).
-configs[1] = test_config1_end_to_end, configs[2] = test_config2_batch16 (+ the two full-shape tests), configs[4] = test_config5_shape_200_steps."""
+configs[1] = test_config1_end_to_end, configs[2] = test_config2_batch16 (+ the two full-shape tests), configs[3] = test_config3_shape_64_candidates,
+configs[4] = test_config5_shape_200_steps."""
 import os
 
 import numpy as np
@@ -285,6 +286,43 @@ def test_config5_shape_200_steps(full_engine, oracle, full_models, pkg):
     err = np.abs(mel - want)
     print("configs[4] schedule at full depth, 200 steps, T=%d: max abs %.2e mean %.2e (gate %.1e)" % (T, err.max(), err.mean(), loop_gate("full")))
     assert err.max() <= loop_gate("full"), (err.max(), err.mean())
+
+
+def test_config3_shape_64_candidates(full_engine, pkg, voice):
+    """configs[3] on one GPU at its real shape: ONE batch of 64 candidates (four candidate tiles of 16 in every decode launch, 128 sequences of T = 870 in the
+    diffusion row space, full-size weights) against the shards the 8-GPU form deals out (8 candidates per rank, options rng_shard_offset / rng_shard_total): the
+    shard's AR codes are the batch's bit for bit, and a candidate's 80-step diffusion (device noise keyed by the global candidate id) and vocoder output equal the batch's."""
+    eng = full_engine
+    toks, B, S = bench_prompt(), 64, 24
+    eng.seed(7)
+    codes, rows, lats, steps = eng.autoregressive(toks, voice, B, S, mask_stop=True)
+    assert steps == S and codes.shape == (B, 502) and len(set(int(r) for r in rows)) == 1
+    rs = np.random.RandomState(64)
+    dl = [rs.randn(200, 1024).astype(np.float32) for _ in range(B)]
+    eng.seed(7)
+    mels = eng.diffusion(dl, n_steps=80, noise_mode=pkg.NOISE_DEVICE)
+    audio = eng.vocoder(mels, noise_mode=pkg.NOISE_DEVICE)
+    assert all(m.shape == (100, 870) and np.isfinite(m).all() for m in mels)
+    try:
+        for rank in (0, 5, 7):  # three of the eight ranks of the 8-GPU form
+            eng.set_option("rng_shard_offset", rank * 8)
+            eng.set_option("rng_shard_total", B)
+            eng.seed(7)
+            c8, r8, l8, _ = eng.autoregressive(toks, voice, 8, S, mask_stop=True)
+            assert (c8 == codes[rank * 8:(rank + 1) * 8]).all(), rank
+            for k in (0, 7):
+                assert np.abs(l8[k] - lats[rank * 8 + k]).max() <= 1e-5 * np.abs(lats[rank * 8 + k]).max()
+        c = 45
+        eng.set_option("rng_shard_offset", c)
+        eng.seed(7)
+        m1 = eng.diffusion([dl[c]], n_steps=80, noise_mode=pkg.NOISE_DEVICE)[0]
+        a1 = eng.vocoder([m1], noise_mode=pkg.NOISE_DEVICE)[0]
+        dm, da = float(np.abs(m1 - mels[c]).max()), float(np.abs(a1 - audio[c]).max() / np.abs(audio[c]).max())
+        print("configs[3] shape: candidate %d of the batch of 64 vs alone: mel max abs diff %.1e, audio rel diff %.1e" % (c, dm, da))
+        assert dm <= 1e-5 and da <= 1e-5
+    finally:
+        eng.set_option("rng_shard_offset", 0)
+        eng.set_option("rng_shard_total", 0)
 
 
 def test_full_size_ar_192_steps_teacher_forced(full_engine, oracle, full_models, voice):
