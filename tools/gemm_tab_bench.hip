@@ -1,8 +1,11 @@
-// Developer tool (round 3): the table-scheduled GEMM kernels (csrc/gemm_f16_tiles.h) against the one-tile-per-workgroup kernels on the
-// benchmark's shapes, for a list of tile-height / ordering policies. Every policy's output is compared bit for bit with the one-tile
-// kernel's; timings are interleaved rounds in one process (median and min).
+// Developer tool (round 3): the product GEMM kernels (csrc/gemm_f16.h) against the round-2 one-tile-per-workgroup kernels (tools/gemm_f16_onetile.h) on the
+// benchmark's shapes. Policies: `arith=<h>` = the product's arithmetic tile walk (h = tile height in 16-row blocks, 0 = automatic), `<name>=h,h,..[/cn][/order]` = an
+// explicit per-XCD tile table (tools/gemm_tile_tables.h) of cyclic heights, `big=0` = the rejected 256-column 8-phase kernel (tools/gemm_f16_big.h; build with
+// -DBIG_STAGGER=0/1 -DBIG_PREFETCH=0/1 for its variants). Every output is compared bit for bit with the round-2 kernel's; timings are interleaved rounds in one
+// process (median and min). -DTTS_GEMM_TRACE adds per-tile phase stamps (K loop / epilogue issue / store drain by tile height; per-phase cycles of the 256-column kernel).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I tortoise.cpp_amd/csrc -I tools [-DTTS_GEMM_TRACE] tools/gemm_tab_bench.hip -o tools/bin/gemm_tab_bench
-//   tools/bin/gemm_tab_bench [shape-filter] [policy ...]      policy = name=h,h,..[/cn][/order]   e.g.  u7=7  mix=8,6/8/0
+//   tools/bin/gemm_tab_bench [shape-filter] [policy ...]      e.g.  tools/bin/gemm_tab_bench conv3 arith=0 u7=7 mix=8,6/8/0 big=0
+//   results: profiles/r3_gemm_tile_tables.txt, r3_gemm_epilogue.txt, r3_gemm_256col_kernel.txt
 #define tts tts_r2 // the round-2 one-tile-per-workgroup kernels, for reference output and timing
 #include "gemm_f16_onetile.h"
 #undef tts
