@@ -21,6 +21,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <map>
 using namespace tts;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
@@ -190,7 +191,7 @@ int main(int argc, char **argv) {
       }
     }
     for (size_t pi = 0; pi < pols.size(); pi++) {
-      if (pols[pi].name.rfind("arith", 0) == 0 || pols[pi].name == "big") continue;
+      if (pols[pi].name == "big") continue;
       static std::vector<unsigned long long> tr(65536 * 8);
       std::fill(tr.begin(), tr.end(), 0ull);
       CK(hipMemcpyToSymbol(HIP_SYMBOL(tts_gemm_trace), tr.data(), tr.size() * 8));
@@ -208,6 +209,23 @@ int main(int argc, char **argv) {
         starts.push_back(p[0]); ends.push_back(p[3]);
         const int nb = (int)p[2];
         if (nb >= 0 && nb <= 8) { kl[nb] += (p[3] - p[1]) * 0.01; ep[nb] += (p[4] - p[3]) * 0.01; dr[nb] += (p[5] - p[4]) * 0.01; cnt[nb]++; }
+      }
+      { // which workgroups shared a CU (XCD 0 only): per CU the block ids / 8 in start order with (row tile, column tile)
+        std::map<int, std::vector<std::pair<unsigned long long, size_t>>> percu;
+        for (size_t w = 0; w < 65536; w++) {
+          const unsigned long long *p = &tr[w * 8];
+          if (!p[0] || !p[4] || (p[6] >> 32) != 0) continue;
+          const unsigned hw = (unsigned)p[6];
+          percu[((hw >> 13) & 7) * 32 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 0xf)].push_back({p[0], w});
+        }
+        int shown = 0;
+        for (auto &kv : percu) {
+          if (shown++ >= 6) break;
+          std::sort(kv.second.begin(), kv.second.end());
+          printf("    xcd0 cu %3d:", kv.first);
+          for (auto &e : kv.second) { const unsigned long long *p = &tr[e.second * 8]; printf(" %zu@%.0f(r%u,c%u)", e.second >> 3, (p[0] - tmin) * 0.01, (unsigned)(p[7] >> 32) >> 7, (unsigned)p[7] >> 7); }
+          printf("\n");
+        }
       }
       printf("  [trace %s] span %.1f us;", pols[pi].name.c_str(), (tmax - tmin) * 0.01);
       for (int nb = 2; nb <= 8; nb++) if (cnt[nb]) printf("  h%d: n=%d K-loop %.1f epilogue issue %.1f store drain %.1f us;", nb, cnt[nb], kl[nb] / cnt[nb], ep[nb] / cnt[nb], dr[nb] / cnt[nb]);

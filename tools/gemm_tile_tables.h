@@ -52,6 +52,30 @@ static inline void gemm_plan_build(GemmPlan &p, int M, int N, const GemmPlanSpec
       }
     }
   }
+  // order 3..6: WHICH tiles share a CU. On gfx950 the per-XCD workgroup indices j, j + 32, j + 64, j + 96 of the first round land on
+  // one CU (tools trace: HW_ID per workgroup); the row-order walk above therefore puts four tiles of ONE column (shared W tile, four
+  // different A tiles) on a CU. Re-deal each run of 128 uniform tiles so that a CU gets: 3 = one row tile x 4 columns (shared A),
+  // 4 = 2 row tiles x 2 columns, 5 = 4 different rows AND columns (nothing shared), 6 = the same tiles as order 0 (control).
+  if (sp.order >= 3 && sp.order <= 6 && cn >= 4 && cn % 4 == 0) {
+    for (int x = 0; x < 8; x++) {
+      auto &l = lists[x];
+      std::vector<int4> out(l.size());
+      size_t base = 0;
+      for (; base + 128 <= l.size(); base += 128) {
+        // the 128 tiles of this run, as 128 / cn row tiles x cn columns (row tile outer): tile (r, c) = l[base + r * cn + c]
+        const int R = 128 / cn; // requires cn | 128
+        std::vector<int4> grp; // 32 groups of 4, in CU order
+        auto T = [&](int r, int c) { return l[base + (size_t)r * cn + c]; };
+        if (sp.order == 3) { for (int r = 0; r < R; r++) for (int c = 0; c < cn; c += 4) for (int k = 0; k < 4; k++) grp.push_back(T(r, c + k)); }
+        else if (sp.order == 4) { for (int r = 0; r < R; r += 2) for (int c = 0; c < cn; c += 2) { grp.push_back(T(r, c)); grp.push_back(T(r, c + 1)); grp.push_back(T(r + 1, c)); grp.push_back(T(r + 1, c + 1)); } }
+        else if (sp.order == 5) { for (int r = 0; r < R; r += 4) for (int c = 0; c < cn; c++) for (int k = 0; k < 4; k++) grp.push_back(T(r + k, (c + k) % cn)); }
+        else { for (int g = 0; g < 32; g++) for (int k = 0; k < 4; k++) grp.push_back(l[base + g + 32 * k]); }
+        for (int g = 0; g < 32; g++) for (int k = 0; k < 4; k++) out[base + g + 32 * k] = grp[(size_t)g * 4 + k];
+      }
+      for (; base < l.size(); base++) out[base] = l[base];
+      l.swap(out);
+    }
+  }
   p.len = 0; p.tiles = 0;
   for (auto &l : lists) { p.len = std::max(p.len, (int)l.size()); p.tiles += (int)l.size(); }
   p.host.assign((size_t)8 * p.len, make_int4(0, 0, 0, 0));

@@ -108,6 +108,37 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
   else if (k == "diff_graph") c->diff_graph = value != 0;
   else if (k == "ar_weights") c->ar_weights = value != 0;
   else if (k == "prof_eager_every") c->prof_eager_every = value < 1 ? 1 : (int)value;
+  else if (k == "stream_cus") {
+    // Partition of the chip between two contexts of one process (INTEGRATION.md "two-context pipeline"): value n > 0 re-creates this
+    // context's stream on the n lowest CUs of every XCD, n < 0 on all BUT those, 0 on the whole chip again. The AR stage is a chain of
+    // 151 short dependent kernels per decode step that uses a fraction of the chip and cannot be interleaved with another stream's
+    // 1000-workgroup kernels (measured: its kernels then wait for the running GEMM to drain, 228 ms -> 1-1.9 s; stream priority
+    // changes nothing); on its own CUs it runs undisturbed while the other context's diffusion stage has the rest.
+    // hipExtStreamCreateWithCUMask on gfx950: bit i = XCD i % 8, CU slot i / 8 (tools/cu_mask_probe.hip); an XCD with no bit set is
+    // unrestricted, so every XCD keeps at least one CU. Only before any model is loaded / graph captured on the old stream.
+    if (c->device < 0) return fail(c, TTS_ERR_HIP, "host-only context: no stream");
+    if (c->ar || c->diff || c->voc) return fail(c, TTS_ERR_STATE, "stream_cus must be set before the models are loaded");
+    (void)hipSetDevice(c->device);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return fail(c, TTS_ERR_HIP, "hipGetDeviceProperties failed");
+    const int xcds = 8, per_xcd = prop.multiProcessorCount / xcds, n = (int)(value < 0 ? -value : value);
+    if (prop.multiProcessorCount % xcds || per_xcd > 32 || n >= per_xcd) return fail(c, TTS_ERR_ARG, "stream_cus %d: the device has %d CUs per XCD", (int)value, per_xcd);
+    hipStream_t s = nullptr;
+    if (n == 0) {
+      if (hipStreamCreate(&s) != hipSuccess) return fail(c, TTS_ERR_HIP, "hipStreamCreate failed");
+    } else {
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int slot = 0; slot < per_xcd; slot++)
+        if ((slot < n) == (value > 0))
+          for (int x = 0; x < xcds; x++) { const int bit = slot * xcds + x; mask[bit >> 5] |= 1u << (bit & 31); }
+      if (hipExtStreamCreateWithCUMask(&s, (uint32_t)((per_xcd * xcds + 31) / 32), mask) != hipSuccess)
+        return fail(c, TTS_ERR_HIP, "hipExtStreamCreateWithCUMask failed");
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamDestroy(c->stream);
+    c->stream = s;
+    c->stream_cus = (int)value;
+  }
   else if (k == "rng_shard_offset") { if (value < 0) return fail(c, TTS_ERR_ARG, "rng_shard_offset < 0"); c->rng_shard_offset = (int)value; }
   else if (k == "rng_shard_total") { if (value < 0) return fail(c, TTS_ERR_ARG, "rng_shard_total < 0"); c->rng_shard_total = (int)value; }
   else return fail(c, TTS_ERR_ARG, "unknown option '%s'", key);

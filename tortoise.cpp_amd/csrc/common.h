@@ -61,6 +61,7 @@ void sampler_pool_free(SamplerPool *p);
 struct tts_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  int stream_cus = 0; // option stream_cus: CUs per XCD this context's stream is confined to (> 0) / excluded from (< 0); 0 = whole chip
   std::string err;
   // options
   float gn_eps = 1e-6f;

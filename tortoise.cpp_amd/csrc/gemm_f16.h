@@ -380,6 +380,8 @@ static __global__ __launch_bounds__(256, WGS) void gemm_f16_vh_kernel(GemmArgs g
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // stamp 5: the epilogue's stores have been acknowledged
   GEMM_TR(5);
   tr_[2] = (unsigned long long)nblk;
+  tr_[6] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf) << 32); // HW_ID | XCC_ID << 32
+  tr_[7] = ((unsigned long long)(unsigned)m0 << 32) | (unsigned)n0;
 #endif
   GEMM_TR_FLUSH(blockIdx.x);
 }
