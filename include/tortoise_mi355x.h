@@ -66,7 +66,10 @@ const char *tts_last_error(const tts_ctx *ctx);
  * "rng_shard_offset" / "rng_shard_total" (0 / 0 default = unsharded): candidate-parallel multi-GPU runs. This context
  * holds candidates [offset, offset + n_candidates) of a batch of `total`: the sampler skips the uniforms of the other
  * ranks' candidates (the used uniform of (step s, candidate c) is output 2 (s total + c) + 1 of the mt19937 stream), and
- * TTS_NOISE_DEVICE streams are keyed by the global candidate id — so G ranks x B/G candidates reproduce one rank x B. */
+ * TTS_NOISE_DEVICE streams are keyed by the global candidate id — so G ranks x B/G candidates reproduce one rank x B,
+ * "stream_cus" (0 default = whole chip; set BEFORE any model is loaded): n > 0 puts this context's stream on the n lowest CUs of every
+ * XCD, n < 0 on all but those (hipExtStreamCreateWithCUMask), so that two contexts of one process can split the GPU. Results do not
+ * depend on it. Measured use: profiles/r3_stage_overlap_probe.txt (the AR stage does not tolerate a partition; kept as a tool). */
 int tts_set_option(tts_ctx *ctx, const char *key, double value);
 
 /* ---- weight files (drop-in format: magic 0x67676d6c + name-keyed F32 records) ------------- */

@@ -35,6 +35,31 @@ def test_decode_is_batch_invariant_and_deterministic(engine, mid_models, voice):
     assert (np.stack(solo)[:, 0] == a[:, 0]).all(), "batch of 1 differs from batch of 16"
 
 
+def test_stream_cus_partition_does_not_change_results(pkg, small_models, voice):
+    """Option stream_cus confines a context's stream to n CUs of every XCD (n > 0) or keeps it off them (n < 0): two contexts of one
+    process can split the chip. No kernel may depend on how many CUs it runs on: ids, latents and mel are bit-identical."""
+    lat = _latents(9, 3)
+    outs = []
+    for cus in (0, 2, -2):
+        e = pkg.Engine(0)
+        e.set_option("stream_cus", cus)
+        e.load(small_models)
+        with pytest.raises(pkg.TtsError, match="before the models are loaded"):
+            e.set_option("stream_cus", 1)
+        e.seed(11)
+        codes, rows, lats, _ = e.autoregressive(DEFAULT_TOKENS, voice, 3, 12, mask_stop=True)
+        mel = e.diffusion([lat], n_steps=4, noise_mode=pkg.NOISE_DEVICE)[0]
+        outs.append((codes, np.concatenate(lats), mel))
+        e.close()
+    for o in outs[1:]:
+        for x, y in zip(outs[0], o):
+            assert (x == y).all()
+    e = pkg.Engine(0)
+    with pytest.raises(pkg.TtsError, match="CUs per XCD"):
+        e.set_option("stream_cus", 32)
+    e.close()
+
+
 def test_autoregressive_driver_bench_shape(engine, mid_models, voice):
     """tts_autoregressive at the bench's shape (16 candidates, stop masked): reproducible for a fixed seed, different
     across candidates, and the latent rows follow the trim rule."""

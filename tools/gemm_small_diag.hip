@@ -4,6 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I tortoise.cpp_amd/csrc -I tools tools/gemm_small_diag.hip -o tools/bin/gemm_small_diag
 #define TTS_GEMM_DEEP 1
 #include "gemm_f16_onetile.h" // the round-2 one-tile-per-workgroup kernels these tools were written against
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +21,12 @@ __global__ void naive_kernel(const __half *A, int lda, const __half *W, int ldw,
     for (int k = 0; k < kseg; k++)
       acc += __half2float(A[(size_t)(m + (nseg == 3 ? s - 1 : 0)) * lda + k]) * __half2float(W[(size_t)n * ldw + s * kseg + k]);
   C[(size_t)m * N + n] = acc + (resid ? resid[(size_t)m * N + n] : 0.f);
+}
+
+__global__ void touch_kernel(const uint4 *p, size_t n, unsigned *sink) {
+  unsigned a = 0;
+  for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a ^= p[i].x;
+  if (a == 0x12345678u) *sink = a;
 }
 
 struct Shape { const char *name; int N, K, nseg, mode, resid; };
@@ -44,12 +51,13 @@ int main() {
   for (auto &v : res) v = (rand() % 2001 - 1000) / 500.f;
   for (auto &v : bias) v = (rand() % 2001 - 1000) / 2000.f;
   CK(hipMemcpy(dRes, res.data(), nC * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dBias, bias.data(), 3072 * 4, hipMemcpyHostToDevice));
+  char *dFlush; unsigned *dSink; CK(hipMalloc(&dFlush, (size_t)1 << 30)); CK(hipMalloc(&dSink, 4));
   hipStream_t s; CK(hipStreamCreate(&s));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   struct Var { const char *name; int deep; };
   const Var vars[4] = {{"large-kernels", -1}, {"deep auto", 0}, {"deep S=3", 3}, {"deep S=6", 6}};
   printf("%-34s %6s %-14s %9s %9s  %s\n", "shape", "M", "kernel", "us/launch", "TF/s", "check");
-  for (int M : {1792, 3584, 7040}) {
+  for (int M : {1792}) {
     std::vector<int> seq(M);
     for (int i = 0; i < M; i++) seq[i] = (i % 896 == 895) ? -1 : i / 896; // a guard row per sequence
     CK(hipMemcpy(dSeq, seq.data(), M * 4, hipMemcpyHostToDevice));
@@ -83,6 +91,25 @@ int main() {
           const bool same = !memcmp(c.data(), refC.data(), nC * 4) && !memcmp(h.data(), refH.data(), nH * 2) && !memcmp(vt.data(), refVt.data(), nVt * 2);
           snprintf(chk, sizeof chk, "%s", same ? "bit-identical to large-kernels" : "DIFFERS from large-kernels");
         }
+        // in-situ condition of the single-utterance diffusion step: the activations were just written (L2 / MALL warm), the weights were last
+        // touched a whole step ago (0.36 GB of fp16 weights cycle through a 256 MB memory-side cache: cold). Flush everything with a 1 GB fill,
+        // re-touch A, then time ONE launch between events; median of 15.
+        double cold_us = 0;
+        if (getenv("TTS_COLD")) {
+          std::vector<float> ts;
+          for (int it = 0; it < 15; it++) {
+            CK(hipMemsetAsync(dFlush, it, (size_t)1 << 30, s));
+            touch_kernel<<<512, 256, 0, s>>>((const uint4 *)(dA + 64 * Kmax), (size_t)M * Kmax / 8, dSink);
+            if (sh.resid) touch_kernel<<<512, 256, 0, s>>>((const uint4 *)dRes, (size_t)M * 1024 / 4, dSink);
+            CK(hipEventRecord(e0, s));
+            CK(launch_gemm_f16(g, s));
+            CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+            float ms1; CK(hipEventElapsedTime(&ms1, e0, e1));
+            ts.push_back(ms1 * 1000.f);
+          }
+          std::sort(ts.begin(), ts.end());
+          cold_us = ts[ts.size() / 2];
+        }
         const int iters = 50;
         for (int i = 0; i < 5; i++) CK(launch_gemm_f16(g, s));
         CK(hipEventRecord(e0, s));
@@ -90,7 +117,7 @@ int main() {
         CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         const double fl = 2.0 * M * sh.N * (double)sh.K * sh.nseg, us = 1000.0 * ms / iters;
-        printf("%-34s %6d %-14s %9.1f %9.1f  %s\n", sh.name, M, v.name, us, fl / (us * 1e-6) / 1e12, chk);
+        printf("%-34s %6d %-14s %9.1f %9.1f  cold-W %6.1f us  %s\n", sh.name, M, v.name, us, fl / (us * 1e-6) / 1e12, cold_us, chk);
       }
     }
   }

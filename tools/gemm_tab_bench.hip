@@ -25,6 +25,12 @@
 using namespace tts;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
+__global__ void touch_kernel(const uint4 *p, size_t n, unsigned *sink) {
+  unsigned a = 0;
+  for (size_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) a ^= p[i].x;
+  if (a == 0x12345678u) *sink = a;
+}
+
 struct Shape { const char *name; int M, N, K, nseg, mode, resid; };
 struct Policy { std::string name; GemmPlanSpec sp; };
 
@@ -83,6 +89,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < Mmax; i += 877) seq[i] = -1; // some guard rows
     CK(hipMemcpy(dSeq, seq.data(), Mmax * 4, hipMemcpyHostToDevice));
   }
+  char *dFlush; unsigned *dSink; CK(hipMalloc(&dFlush, (size_t)1 << 30)); CK(hipMalloc(&dSink, 4));
   hipStream_t s; CK(hipStreamCreate(&s));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   int4 *dTab; CK(hipMalloc(&dTab, (size_t)8 * 65536 * sizeof(int4)));
@@ -165,12 +172,36 @@ int main(int argc, char **argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         us[v + 1].push_back(1000.0 * ms / iters);
       }
+    // TTS_COLD=1: the in-situ condition of the single-utterance diffusion step — activations just written (re-touched after the flush),
+    // weights last read a whole step ago (flushed out of L2 and the memory-side cache by a 1 GB fill); ONE launch between events, median of 15
+    std::vector<double> cold(pols.size() + 1, 0.0);
+    if (getenv("TTS_COLD"))
+      for (int v = -1; v < (int)pols.size(); v++) {
+        GemmArgs g = mk(dC2, dH2, dVt2);
+        tts_r2::GemmArgs g2 = mk_r2(dC2, dH2, dVt2);
+        if (v >= 0) { g.tiles = plans[v].dev; g.tab_len = plans[v].len; g.th = pols[v].name.rfind("arith", 0) == 0 ? pols[v].sp.h[0] : 0; }
+        const bool big = v >= 0 && pols[v].name == "big" && gemm_use_big(g);
+        auto go = [&]() { return v < 0 ? tts_r2::launch_gemm_f16(g2, s) : big ? launch_gemm_f16_big(g, s) : launch_gemm_f16(g, s); };
+        std::vector<float> ts;
+        for (int it = 0; it < 15; it++) {
+          CK(hipMemsetAsync(dFlush, it, (size_t)1 << 30, s));
+          touch_kernel<<<512, 256, 0, s>>>((const uint4 *)dA, (size_t)(sh.M + 2) * sh.K / 8, dSink);
+          if (sh.resid) touch_kernel<<<512, 256, 0, s>>>((const uint4 *)dRes, (size_t)sh.M * 1024 / 4, dSink);
+          CK(hipEventRecord(e0, s));
+          CK(go());
+          CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+          float ms1; CK(hipEventElapsedTime(&ms1, e0, e1));
+          ts.push_back(ms1 * 1000.f);
+        }
+        std::sort(ts.begin(), ts.end());
+        cold[v + 1] = ts[ts.size() / 2];
+      }
     for (int v = -1; v < (int)pols.size(); v++) {
       auto &u = us[v + 1];
       std::sort(u.begin(), u.end());
       const double med = u[u.size() / 2];
-      printf("  %-12s med %8.1f us  min %8.1f  %7.1f TF/s   %s\n", v < 0 ? "round-2" : pols[v].name.c_str(), med, u[0], fl / (med * 1e-6) / 1e12,
-             v < 0 ? "" : status[v].c_str());
+      printf("  %-12s med %8.1f us  min %8.1f  %7.1f TF/s   cold-W %6.1f us   %s\n", v < 0 ? "round-2" : pols[v].name.c_str(), med, u[0], fl / (med * 1e-6) / 1e12,
+             cold[v + 1], v < 0 ? "" : status[v].c_str());
     }
 #ifdef TTS_GEMM_TRACE
     if (gemm_use_big(mk(dC2, dH2, dVt2))) { // per-phase shader-clock stamps of the 256-column kernel (two K tiles of workgroup 64)
