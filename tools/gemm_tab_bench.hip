@@ -15,6 +15,7 @@
 #include "gemm_f16.h"
 #include "gemm_tile_tables.h"
 #include "gemm_f16_big.h" // the rejected 256-column kernel: policy name "big"
+#include "gemm_f16_wide.h" // 128 x 256 tiles with 8 waves on the single-stage K loop: policy name "wide"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -51,12 +52,15 @@ static Policy parse_policy(const char *s) {
 }
 
 int main(int argc, char **argv) {
-  const int Mmax = 28032, Kmax = 1024;
+  const int Mmax = 28672, Kmax = 1024;
   std::vector<Shape> shapes = {
       {"in_layers k1 N1024 K1024", 28032, 1024, 1024, 1, GEMM_OUT_F32, 0},
       {"proj_out  k1 N1024 K1024 +resid", 28032, 1024, 1024, 1, GEMM_OUT_F32, 1},
       {"qkv       k1 N3072 K1024", 28032, 3072, 1024, 1, GEMM_OUT_QKV, 0},
       {"conv3     k3 N1024 K3x1024 +resid", 28032, 1024, 1024, 3, GEMM_OUT_F32, 1},
+      {"pad_in_layers k1 N1024 K1024 M28672", 28672, 1024, 1024, 1, GEMM_OUT_F32, 0},
+      {"pad_proj_out k1 N1024 K1024 M28672 +resid", 28672, 1024, 1024, 1, GEMM_OUT_F32, 1},
+      {"pad_qkv k1 N3072 K1024 M28672", 28672, 3072, 1024, 1, GEMM_OUT_QKV, 0},
       {"integ k1  N1024 K1024 M14848", 14848, 1024, 1024, 1, GEMM_OUT_F32, 0},
       {"integ k3  N1024 K3x1024 M14848 +resid", 14848, 1024, 1024, 3, GEMM_OUT_F32, 1},
       {"single k1 N1024 K1024 M1792", 1792, 1024, 1024, 1, GEMM_OUT_F32, 1},
@@ -127,7 +131,7 @@ int main(int argc, char **argv) {
     std::vector<GemmPlan> plans(pols.size());
     std::vector<std::string> status(pols.size());
     for (size_t pi = 0; pi < pols.size(); pi++) {
-      const bool arith = pols[pi].name.rfind("arith", 0) == 0 || pols[pi].name == "big"; // arithmetic tile walk (th = first height, 0 = automatic) / 256-column kernel
+      const bool arith = pols[pi].name.rfind("arith", 0) == 0 || pols[pi].name == "big" || pols[pi].name == "wide"; // arithmetic tile walk (th = first height, 0 = automatic) / 256-column kernel
       if (!arith) {
         gemm_plan_build(plans[pi], sh.M, sh.N, pols[pi].sp);
         CK(hipMalloc(&plans[pi].dev, plans[pi].host.size() * sizeof(int4)));
@@ -137,6 +141,7 @@ int main(int argc, char **argv) {
       GemmArgs g = mk(dC2, dH2, dVt2);
       g.tiles = plans[pi].dev; g.tab_len = plans[pi].len; g.th = arith ? pols[pi].sp.h[0] : 0;
       if (pols[pi].name == "big") { g.th = 0; if (!gemm_use_big(g)) { status[pi] = "n/a (problem too small for the 256-column kernel)"; continue; } CK(launch_gemm_f16_big(g, s)); }
+      else if (pols[pi].name == "wide") { g.th = 0; if (!gemm_use_wide(g)) { status[pi] = "n/a (M % 1024 != 0)"; continue; } CK(launch_gemm_f16_wide(g, s)); }
       else CK(launch_gemm_f16(g, s));
       CK(hipStreamSynchronize(s));
       size_t bad = 0;
@@ -164,7 +169,9 @@ int main(int argc, char **argv) {
         tts_r2::GemmArgs g2 = mk_r2(dC2, dH2, dVt2);
         if (v >= 0) { g.tiles = plans[v].dev; g.tab_len = plans[v].len; g.th = pols[v].name.rfind("arith", 0) == 0 ? pols[v].sp.h[0] : 0; }
         const bool big = v >= 0 && pols[v].name == "big" && gemm_use_big(g);
-        auto go = [&]() { return v < 0 ? tts_r2::launch_gemm_f16(g2, s) : big ? launch_gemm_f16_big(g, s) : launch_gemm_f16(g, s); };
+        const bool wide = v >= 0 && pols[v].name == "wide" && gemm_use_wide(g);
+        if (wide) { g.tiles = nullptr; }
+        auto go = [&]() { return v < 0 ? tts_r2::launch_gemm_f16(g2, s) : big ? launch_gemm_f16_big(g, s) : wide ? launch_gemm_f16_wide(g, s) : launch_gemm_f16(g, s); };
         for (int i = 0; i < 2; i++) CK(go());
         CK(hipEventRecord(e0, s));
         for (int i = 0; i < iters; i++) CK(go());
@@ -181,7 +188,9 @@ int main(int argc, char **argv) {
         tts_r2::GemmArgs g2 = mk_r2(dC2, dH2, dVt2);
         if (v >= 0) { g.tiles = plans[v].dev; g.tab_len = plans[v].len; g.th = pols[v].name.rfind("arith", 0) == 0 ? pols[v].sp.h[0] : 0; }
         const bool big = v >= 0 && pols[v].name == "big" && gemm_use_big(g);
-        auto go = [&]() { return v < 0 ? tts_r2::launch_gemm_f16(g2, s) : big ? launch_gemm_f16_big(g, s) : launch_gemm_f16(g, s); };
+        const bool wide = v >= 0 && pols[v].name == "wide" && gemm_use_wide(g);
+        if (wide) { g.tiles = nullptr; }
+        auto go = [&]() { return v < 0 ? tts_r2::launch_gemm_f16(g2, s) : big ? launch_gemm_f16_big(g, s) : wide ? launch_gemm_f16_wide(g, s) : launch_gemm_f16(g, s); };
         std::vector<float> ts;
         for (int it = 0; it < 15; it++) {
           CK(hipMemsetAsync(dFlush, it, (size_t)1 << 30, s));

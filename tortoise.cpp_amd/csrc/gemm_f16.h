@@ -33,6 +33,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef TTS_GEMM_ABLATE
+#define TTS_GEMM_ABLATE 0
+#endif
+
 namespace tts {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -303,13 +307,16 @@ __device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, 
       const __half *wseg = g.W + (g.custom_w ? g.w_off_[seg] : seg * g.kseg);
       for (int kt = 0; kt < tiles_per_seg; kt++) {
         const __half *abase = aseg + (kt << 6), *wbase = wseg + (kt << 6);
+#if TTS_GEMM_ABLATE != 1 // (developer ablation builds, tools/gemm_tab_bench.hip: 1 = no operand DMA, 2 = no MFMAs, 3 = DMA and barriers only)
 #pragma unroll
         for (int i = 0; i < 4; i++)
           if (i < my_pa) __builtin_amdgcn_global_load_lds((gptr_t)(abase + aoff[i]), (lptr_t)(sa + (wave + 4 * i) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; i++)
           __builtin_amdgcn_global_load_lds((gptr_t)(wbase + boff[i]), (lptr_t)(sb + (wave * 4 + i) * 1024), 16, 0, 0);
+#endif
         __syncthreads(); // waits vmcnt(0) for the DMA, then barrier
+#if TTS_GEMM_ABLATE != 3
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
           half8 af[MA], bf[4];
@@ -319,6 +326,12 @@ __device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, 
 #pragma unroll
             for (int i = 0; i < 4; i++) bf[i] = *(const half8 *)(sb + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
           }
+#if TTS_GEMM_ABLATE == 2
+#pragma unroll
+          for (int i = 0; i < MI; i++) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+          for (int i = 0; i < 4; i++) asm volatile("" ::"v"(bf[i]));
+#else
 #pragma unroll
           for (int i = 0; i < MI; i++)
 #pragma unroll
@@ -326,7 +339,9 @@ __device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, 
               if (NAT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
               else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
             }
+#endif
         }
+#endif
         __syncthreads();
       }
     }
