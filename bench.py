@@ -393,33 +393,40 @@ def main():
                  "stage_ms_per_step": o_stages}
     if not a.dry_engine:
         eng.prof_reset(False)
-    # throughput option ar_weights = f16 (0.77 GB instead of 1.54 GB of weights per decode step), measured beside the default
-    # f32 mode on the same prompt and seed: AR stage time, decode-step bandwidth, first sampled id that differs from the f32 run
-    f16 = None
+    # throughput options ar_weights = 1 (fp16: 0.77 GB instead of 1.54 GB of weights per decode step) and 2 (OCP fp8 e4m3 with a
+    # power-of-two scale per output column: 0.39 GB), measured beside the default f32 mode on the same prompt and seed:
+    # AR stage time, decode-step bandwidth, first sampled id that differs from the f32 run
+    f16 = fp8 = None
     if world == 1 and not a.no_ab and not a.dry_engine:
         eng.seed(4242)
         t0 = time.time()
         c32, _, _, _ = eng.autoregressive(prompts[0], voice, B, S, mask_stop=True)
         t32 = time.time() - t0
-        e2 = pkg.Engine(device)
-        e2.set_option("ar_weights", 1)
-        e2.load(ar=os.path.join(model_dir, "ggml-model.bin"))
-        e2.seed(4242)
-        e2.autoregressive(prompts[0], voice, B, S, mask_stop=True)  # warm-up (graph capture, pinned buffers)
-        e2.set_option("prof_only:ar_decode_step", 1)
-        e2.prof_reset(True)
-        e2.seed(4242)
-        t0 = time.time()
-        c16, _, _, _ = e2.autoregressive(prompts[0], voice, B, S, mask_stop=True)
-        t16 = time.time() - t0
-        q_ms, q_n, q_bytes = e2.prof_get("ar_decode_step")
-        e2.close()
-        diff = np.argwhere(c32[:, 1:1 + S] != c16[:, 1:1 + S])
-        first = int(diff[:, 1].min()) if len(diff) else None
-        f16 = {"ar_stage_ms_f32": round(1e3 * t32, 1), "ar_stage_ms_f16": round(1e3 * t16, 1), "decode_step_us_f16": round(1e3 * q_ms / max(q_n, 1), 1),
-               "decode_gbs_f16": round(q_bytes / max(q_ms, 1e-9) / 1e6, 1), "first_divergent_step_vs_f32": first,
-               "candidates_identical_through_all_steps": int((c32[:, 1:1 + S] == c16[:, 1:1 + S]).all(axis=1).sum()),
-               "note": "fp16 decode weights change the logits by ~1e-3: sampled ids follow the f32 run until the first draw that lands on the other side of a CDF edge"}
+        reports = {}
+        for mode, tag in ((1, "f16"), (2, "fp8")):
+            e2 = pkg.Engine(device)
+            e2.set_option("ar_weights", mode)
+            e2.load(ar=os.path.join(model_dir, "ggml-model.bin"))
+            e2.seed(4242)
+            e2.autoregressive(prompts[0], voice, B, S, mask_stop=True)  # warm-up (graph capture, pinned buffers)
+            e2.set_option("prof_only:ar_decode_step", 1)
+            e2.prof_reset(True)
+            e2.seed(4242)
+            t0 = time.time()
+            cq, _, _, _ = e2.autoregressive(prompts[0], voice, B, S, mask_stop=True)
+            tq = time.time() - t0
+            q_ms, q_n, q_bytes = e2.prof_get("ar_decode_step")
+            e2.close()
+            diff = np.argwhere(c32[:, 1:1 + S] != cq[:, 1:1 + S])
+            first = int(diff[:, 1].min()) if len(diff) else None
+            reports[tag] = {"ar_stage_ms_f32": round(1e3 * t32, 1), "ar_stage_ms_%s" % tag: round(1e3 * tq, 1),
+                            "decode_step_us_%s" % tag: round(1e3 * q_ms / max(q_n, 1), 1),
+                            "decode_gbs_%s" % tag: round(q_bytes / max(q_ms, 1e-9) / 1e6, 1), "first_divergent_step_vs_f32": first,
+                            "candidates_identical_through_all_steps": int((c32[:, 1:1 + S] == cq[:, 1:1 + S]).all(axis=1).sum()),
+                            "note": {"f16": "fp16 decode weights change the logits by ~1e-3",
+                                     "fp8": "fp8 e4m3 decode weights change the logits by ~5e-2"}[tag] +
+                                    ": sampled ids follow the f32 run until the first draw that lands on the other side of a CDF edge"}
+        f16, fp8 = reports["f16"], reports["fp8"]
     if rank != 0:
         if dist:
             dist.destroy_process_group()
@@ -466,6 +473,7 @@ def main():
         "stage_ms_per_step": stages,
         "other_share_uncond_setting": other,
         "ar_weights_f16_option": f16,
+        "ar_weights_fp8_option": fp8,
         "collective_ranks": collective_ranks,
         "roofline": {"kernel": "gemm_f16_vh_kernel + gemm_f16_conv3_vh_kernel (diffusion convs/projections)", "bound": "mfma",
                      "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4),

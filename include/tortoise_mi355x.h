@@ -59,7 +59,8 @@ const char *tts_last_error(const tts_ctx *ctx);
  * candidate; 0 = once per candidate. Same arithmetic per row either way),
  * "ar_weights" (0 default: the decode step streams the f32 weights, reference numerics; 1 — set BEFORE tts_load_ar — the decode
  * step streams fp16 copies (half the bytes; logits ~1e-3 off, so sampled ids diverge from the f32 mode after some steps: the
- * throughput mode of SURVEY 8d; prefill and latent pass stay f32-exact),
+ * throughput mode of SURVEY 8d; prefill and latent pass stay f32-exact); 2 — also BEFORE tts_load_ar — OCP fp8 (e4m3) copies with one
+ * power-of-two scale per output column (a quarter of the bytes, logits ~5e-2 off: SURVEY 8 f4),
  * "diff_graph" (1 default: tts_diffusion captures ONE sampling step — ~125 kernels, every per-step value read through a device-side step
  * counter — into a hipGraph and replays it; 0: every step is launched kernel by kernel), "prof_eager_every" (8: while a diff_* family is
  * being profiled every 8th step runs eagerly with its event pairs, the rest replay the graph),
@@ -194,6 +195,9 @@ void tts_host_timestep_embedding(int t, float *out1024);
 int tts_host_rel_bucket(int query, int key);
 int tts_host_pad_codes(const int32_t *codes, int n, int32_t *out502);
 int tts_host_trimmed_rows(const int32_t *codes502);
+/* The weight quantiser of option ar_weights = 2: OCP fp8 e4m3 (1-4-3, bias 7, largest finite 448, no infinities) code of v, round to
+ * nearest even, saturating; NaN -> 0x7f. No counterpart in the reference. */
+uint8_t tts_host_fp8_e4m3(float v);
 
 /* ---- measurement hooks (bench.py; not part of the reference seam) -------------------------- */
 /* Accumulated device time (ms; HIP event pairs recorded on the ctx stream around every launch, resolved

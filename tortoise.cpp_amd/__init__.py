@@ -66,6 +66,7 @@ def lib():
         "tts_write_wav": (ci, [C.c_char_p, _f32p, C.c_int64, ci]),
         "tts_host_schedule": (ci, [ci, _i32p] + [_f32p] * 7), "tts_host_timestep_embedding": (None, [ci, _f32p]),
         "tts_host_rel_bucket": (ci, [ci, ci]), "tts_host_pad_codes": (ci, [_i32p, ci, _i32p]), "tts_host_trimmed_rows": (ci, [_i32p]),
+        "tts_host_fp8_e4m3": (C.c_uint8, [cf]),
         "tts_prof_reset": (ci, [vp, ci]), "tts_prof_get": (ci, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
@@ -308,6 +309,13 @@ def host_pad_codes(codes):
 
 def host_trimmed_rows(codes502):
     return lib().tts_host_trimmed_rows(np.ascontiguousarray(codes502, np.int32))
+
+
+def host_fp8_e4m3(values):
+    """OCP fp8 e4m3 codes (uint8) of an array of floats: the quantiser of option ar_weights = 2."""
+    L = lib()
+    v = np.ascontiguousarray(values, np.float32).reshape(-1)
+    return np.array([L.tts_host_fp8_e4m3(float(x)) for x in v], np.uint8).reshape(np.shape(values))
 
 
 def write_wav(path, samples, rate=24000):

@@ -106,7 +106,10 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
   else if (k == "share_uncond") c->share_uncond = value != 0;
   else if (k == "prof_stride") c->prof_stride = value < 1 ? 1 : (int)value;
   else if (k == "diff_graph") c->diff_graph = value != 0;
-  else if (k == "ar_weights") c->ar_weights = value != 0;
+  else if (k == "ar_weights") {
+    if (value != 0 && value != 1 && value != 2) return fail(c, TTS_ERR_ARG, "ar_weights: 0 (f32), 1 (fp16) or 2 (fp8 e4m3)");
+    c->ar_weights = (int)value;
+  }
   else if (k == "prof_eager_every") c->prof_eager_every = value < 1 ? 1 : (int)value;
   else if (k == "stream_cus") {
     // Partition of the chip between two contexts of one process (INTEGRATION.md "two-context pipeline"): value n > 0 re-creates this

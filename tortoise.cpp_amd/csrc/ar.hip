@@ -349,7 +349,8 @@ struct DecLnArgs {
   const float *h;            // [rows][1024]
   const float *g1, *b1;      // DEC_LOGITS: ln_f (the LayerNorm feeding W is folded into W/bias at load)
   const float *W;            // pack_mfma16 of diag(gamma) W
-  const __half *Wh;          // SPLIT 1: pack_mfma16h, the same matrix x 64 as fp16 hi|lo pairs; SPLIT 2: pack_mfma16q, fp16 hi only (option ar_weights = 1)
+  const __half *Wh;          // SPLIT 1: pack_mfma16h, the same matrix x 64 as fp16 hi|lo pairs; SPLIT 2: pack_mfma16q, fp16 hi only (option ar_weights = 1);
+                             // SPLIT 3: pack_mfma16o, OCP fp8 e4m3 of W / wscale[column] (option ar_weights = 2)
   const float *bias;         // bias + beta . W
   int rows, n_valid, ldo;    // ldo: row stride of `out` for DEC_QKV (q) and DEC_LOGITS
   int prefill_B;             // DEC_QKV: 0 = decode (row = candidate, position n_past); > 0 = prompt pass (row = position,
@@ -358,6 +359,7 @@ struct DecLnArgs {
   __half *kc, *vc;           // layer's caches [cand][max_pos][1024]
   const StepState *ss;
   int max_pos, lut;
+  const float *wscale;       // SPLIT 3: per-output-column scale (a power of two) of the fp8 weights
 };
 
 // sum over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48): gfx950 half/row swap instructions
@@ -406,7 +408,9 @@ __device__ __forceinline__ void dec_layernorm(float4 (&x)[16], const float *__re
 }
 
 // SPLIT: 0 = fp32 MFMA on f32 weights, 1 = split-precision fp16 MFMA (f32-exact to 2^-22), 2 = fp16 WEIGHTS (rounded once at load:
-// half the bytes streamed; the activations keep their hi + lo split) — the throughput mode of SURVEY 8d, option "ar_weights".
+// half the bytes streamed; the activations keep their hi + lo split) — the throughput mode of SURVEY 8d, option "ar_weights";
+// 3 = OCP fp8 (e4m3) WEIGHTS with a power-of-two scale per output column (a quarter of the bytes): converted to fp16 in
+// registers (exact: every e4m3 value is an fp16 value), multiplied on the fp16 MFMA against the hi + lo split activations.
 template <int EPI, int SPLIT = 0, bool NTW = false>
 __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
   constexpr int SP = SPLIT ? 1 : 0;
@@ -418,6 +422,8 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
   // Everything the epilogue reads (bias, the step's n_past) is requested FIRST: loaded after the reduction they were one or two
   // dependent L2 round trips (~0.5 us each) at the end of every one of the step's 91 launches of this kernel.
   const float4 bi = *(const float4 *)(a.bias + cb * 16 + 4 * q);
+  float4 wsc = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (SPLIT == 3) wsc = *(const float4 *)(a.wscale + cb * 16 + 4 * q);
   int n_past = 0;
   if (EPI == DEC_QKV) n_past = a.prefill_B == 0 ? a.ss->n_past : 0;
   // activations next (L2 hits), then the weight slab (HBM): vmcnt retires in order, so the LayerNorm runs on
@@ -436,6 +442,10 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
       const float4 *wp = (const float4 *)a.Wh + ((size_t)(cb * 4 + wave) * 8) * 64;
 #pragma unroll
       for (int i = 0; i < 8; i++) w[2 * i] = ldw4<NTW>(wp + i * 64 + lane);
+    } else if (SPLIT == 3) { // 8 steps x 8 B per lane, two steps per 16-byte load: w[i] = steps 2 i, 2 i + 1
+      const float4 *wp = (const float4 *)a.Wh + ((size_t)(cb * 4 + wave) * 4) * 64;
+#pragma unroll
+      for (int i = 0; i < 4; i++) w[i] = ldw4<NTW>(wp + i * 64 + lane);
     } else {
       const float4 *wp = (SPLIT ? (const float4 *)a.Wh : (const float4 *)a.W) + ((size_t)(cb * 4 + wave) * 16) * 64;
 #pragma unroll
@@ -461,7 +471,14 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
         xh[e] = (_Float16)xs[e];
         xl[e] = (_Float16)(xs[e] - (float)xh[e]);
       }
-      const half8 wh = *(const half8 *)&w[2 * s];
+      half8 wh;
+      if (SPLIT == 3) {
+        const uint2 u = ((const uint2 *)&w[s >> 1])[s & 1];
+        const floatx2 f0 = __builtin_amdgcn_cvt_pk_f32_fp8(u.x, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(u.x, true);
+        const floatx2 f2 = __builtin_amdgcn_cvt_pk_f32_fp8(u.y, false), f3 = __builtin_amdgcn_cvt_pk_f32_fp8(u.y, true);
+        wh[0] = (_Float16)f0[0]; wh[1] = (_Float16)f0[1]; wh[2] = (_Float16)f1[0]; wh[3] = (_Float16)f1[1];
+        wh[4] = (_Float16)f2[0]; wh[5] = (_Float16)f2[1]; wh[6] = (_Float16)f3[0]; wh[7] = (_Float16)f3[1];
+      } else wh = *(const half8 *)&w[2 * s];
       a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, a0, 0, 0, 0);
       if (SPLIT == 1) {
         const half8 wl = *(const half8 *)&w[2 * s + 1];
@@ -469,7 +486,8 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
       }
       a2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, a2, 0, 0, 0);
     }
-    acc = ((a1 + a2) + a0) * (1.0f / 64.0f);
+    if (SPLIT == 3) { acc = a2 + a0; acc[0] *= wsc.x; acc[1] *= wsc.y; acc[2] *= wsc.z; acc[3] *= wsc.w; }
+    else acc = ((a1 + a2) + a0) * (1.0f / 64.0f);
   } else {
     // four independent accumulator chains keep the fp32 MFMA pipe issue-bound instead of latency-bound
     floatx4 ac0 = {0.f, 0.f, 0.f, 0.f}, ac1 = ac0, ac2 = ac0, ac3 = ac0;
@@ -528,9 +546,11 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
 // are in flight per CU — the c_proj of the MLP (K = 4096) reads 256 KB of activations per workgroup and is bound by how
 // many of those loads the CU keeps in flight.
 // WH: the slab holds fp16 weights (pack_cols4 order, 8 bytes per (k, 4 columns): option ar_weights = 1), converted to f32 in registers.
-template <int KG, int NT = 256, bool WH = false, bool NTW = false>
+// WH = 2: OCP fp8 (e4m3) weights, 4 bytes per (k, 4 columns), times the power-of-two wscale[column] after the reduction (option ar_weights = 2).
+template <int KG, int NT = 256, int WH = 0, bool NTW = false>
 __global__ __launch_bounds__(NT) void dec_gemv_resid_kernel(const float *__restrict__ X, int rows, const float *__restrict__ W,
-                                                            const float *__restrict__ bias, float *__restrict__ h) {
+                                                            const float *__restrict__ bias, float *__restrict__ h,
+                                                            const float *__restrict__ wscale = nullptr) {
   constexpr int K = 1024 * KG, NW = NT / 64, NG = K / (NT * 4); // NG K groups of NT*4 values per workgroup
   __shared__ float red[NW][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -540,13 +560,25 @@ __global__ __launch_bounds__(NT) void dec_gemv_resid_kernel(const float *__restr
   // first instead of after the reduction (a dependent L2 round trip at the end of 60 launches per step)
   const int er = min(row0 + ((tid & 63) >> 2), rows - 1), ecol = cb * 4 + (tid & 3);
   const float h_old = h[(size_t)er * D + ecol], b_old = bias[ecol];
+  float s_old = 1.0f;
+  if (WH == 2) s_old = wscale[ecol];
   float4 xa0[8]; // candidates 0-7 of K group 0: requested before the weight stream
 #pragma unroll
   for (int r = 0; r < 8; r++) xa0[r] = *(const float4 *)(X + (size_t)min(row0 + r, rows - 1) * K + 4 * tid);
   float4 w[NG][4];
   {
     // pack_cols4 order: float4 index ((k / 1024) * 4 + kk) * 256 + (k % 1024) / 4 for k = g * NT * 4 + 4 * tid + kk
-    if (WH) {
+    if (WH == 2) {
+      const unsigned *wp = (const unsigned *)W + (size_t)cb * KG * 1024 + (tid & 255);
+#pragma unroll
+      for (int i = 0; i < NG; i++)
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          const unsigned u = wp[((i * (NT / 256) + (tid >> 8)) * 4 + kk) * 256];
+          const floatx2 f0 = __builtin_amdgcn_cvt_pk_f32_fp8(u, false), f1 = __builtin_amdgcn_cvt_pk_f32_fp8(u, true);
+          w[i][kk] = make_float4(f0[0], f0[1], f1[0], f1[1]);
+        }
+    } else if (WH == 1) {
       const uint2 *wp = (const uint2 *)W + (size_t)cb * KG * 1024 + (tid & 255);
 #pragma unroll
       for (int i = 0; i < NG; i++)
@@ -637,7 +669,7 @@ __global__ __launch_bounds__(NT) void dec_gemv_resid_kernel(const float *__restr
       float t = red[0][tid];
 #pragma unroll
       for (int w2 = 1; w2 < NW; w2++) t += red[w2][tid];
-      h[(size_t)r * D + col] = h_old + (t + b_old);
+      h[(size_t)r * D + col] = h_old + ((WH == 2 ? t * s_old : t) + b_old);
     }
   }
 }
@@ -875,6 +907,9 @@ struct ArLayerDev {
   float *db_attn = nullptr, *db_fc = nullptr; // bias + ln beta . W
   float *d_proj = nullptr, *d_fc2 = nullptr;  // pack_cols4  (decode step)
   __half *q_attn = nullptr, *q_fc = nullptr, *q_proj = nullptr, *q_fc2 = nullptr; // fp16-weight decode slabs (option ar_weights = 1 at load)
+  // fp8-weight decode slabs (option ar_weights = 2 at load): e4m3 bytes in the same packing orders + one power-of-two scale per output column
+  uint8_t *o_attn = nullptr, *o_fc = nullptr, *o_proj = nullptr, *o_fc2 = nullptr;
+  float *os_attn = nullptr, *os_fc = nullptr, *os_proj = nullptr, *os_fc2 = nullptr;
 };
 
 struct ArState {
@@ -885,7 +920,9 @@ struct ArState {
   float *lm_w = nullptr /*[1024][VPAD] strip-major*/, *lm_b = nullptr /*[VPAD]*/, *d_lm = nullptr /*pack_mfma16, lm_head.0 folded*/, *d_lmb = nullptr;
   __half *dh_lm = nullptr; // pack_mfma16h
   __half *q_lm = nullptr;  // pack_mfma16q (option ar_weights = 1 at load)
-  bool has_f16_weights = false;
+  uint8_t *o_lm = nullptr; // pack_mfma16o (option ar_weights = 2 at load)
+  float *os_lm = nullptr;
+  int loaded_wmode = 0;    // the reduced-precision decode slabs this state was loaded with (0 = none, 1 = fp16, 2 = fp8)
   std::vector<void *> owned;
   // run state
   int B = 0, n_text = 0, P = 0, max_pos = 0;
@@ -1003,6 +1040,70 @@ static std::vector<__half> pack_mfma16q(const float *w, int K, int N) {
                 __float2half_rn(64.0f * w[(size_t)(wv * 256 + s2 * 32 + 8 * (lane >> 4) + e) * N + cb * 16 + (lane & 15)]);
   return t;
 }
+// ---- OCP fp8 e4m3 (1-4-3, bias 7, largest finite 448, no infinities): round to nearest even, saturating ----
+static uint8_t fp8_e4m3_encode(float f) {
+  const uint8_t sign = std::signbit(f) ? 0x80 : 0;
+  float a = std::fabs(f);
+  if (!(a == a)) return sign | 0x7f;
+  if (a >= 448.0f) return sign | 0x7e;
+  if (a < 0.0009765625f) return sign; // below half of the smallest subnormal (2^-9 / 2): rounds to zero (ties-to-even at exactly 2^-10 -> 0)
+  int e;
+  (void)std::frexp(a, &e);           // a = m 2^e, m in [0.5, 1)
+  int ex = e - 1;                    // a = 1.xxx 2^ex
+  if (ex < -6) ex = -6;              // subnormals share the exponent of the smallest normal
+  const float q = std::ldexp(1.0f, ex - 3); // spacing of representable values in this binade
+  float r = std::nearbyint(a / q) * q;      // default rounding mode: to nearest even
+  if (r >= 448.0f) return sign | 0x7e;
+  if (r < 0.015625f) return sign | (uint8_t)std::lrint(r / 0.001953125f); // subnormal: mantissa = r / 2^-9
+  (void)std::frexp(r, &e);
+  ex = e - 1;
+  const int mant = (int)std::lrint(r / std::ldexp(1.0f, ex - 3)) - 8;
+  return sign | (uint8_t)(((ex + 7) << 3) | mant);
+}
+extern "C" uint8_t tts_host_fp8_e4m3(float v) { return fp8_e4m3_encode(v); }
+// one power-of-two scale per output column, the smallest with max |w| / scale <= 448 (exact scaling: a matrix whose entries are
+// e4m3 values times a power of two per column survives the round trip unchanged)
+static std::vector<float> fp8_col_scales(const float *w, int K, int N) {
+  std::vector<float> sc(N, 1.0f);
+  for (int n = 0; n < N; n++) {
+    float amax = 0.f;
+    for (int k = 0; k < K; k++) amax = std::max(amax, std::fabs(w[(size_t)k * N + n]));
+    if (amax > 0.f) {
+      int e;
+      (void)std::frexp(amax / 448.0f, &e); // amax / 448 = m 2^e, m in [0.5, 1)  ->  2^e >= amax / 448
+      sc[n] = std::ldexp(1.0f, amax / 448.0f == std::ldexp(0.5f, e) ? e - 1 : e);
+    }
+  }
+  return sc;
+}
+// pack_mfma16o: pack_mfma16q's order with one BYTE per value (e4m3 of w / scale[column]); a lane's K steps 2 i and 2 i + 1 share one
+// 16-byte load: byte ((((cb 4 + wv) 4 + i) 64 + lane) 2 + (s & 1)) 8 + e
+static std::vector<uint8_t> pack_mfma16o(const float *w, int K, int N, const std::vector<float> &sc) {
+  std::vector<uint8_t> t((size_t)K * N);
+  for (int cb = 0; cb < N / 16; cb++)
+    for (int wv = 0; wv < 4; wv++)
+      for (int s2 = 0; s2 < 8; s2++)
+        for (int lane = 0; lane < 64; lane++)
+          for (int e = 0; e < 8; e++) {
+            const int n = cb * 16 + (lane & 15);
+            t[(((((size_t)cb * 4 + wv) * 4 + (s2 >> 1)) * 64 + lane) * 2 + (s2 & 1)) * 8 + e] =
+                fp8_e4m3_encode(w[(size_t)(wv * 256 + s2 * 32 + 8 * (lane >> 4) + e) * N + n] / sc[n]);
+          }
+  return t;
+}
+// pack_cols4o: pack_cols4's order with one byte per value: 4 bytes (the 4 columns) per (k, workgroup)
+static std::vector<uint8_t> pack_cols4o(const float *w, int K, int N, const std::vector<float> &sc) {
+  std::vector<uint8_t> t((size_t)K * N);
+  const int KG = K / 1024;
+  for (int cb = 0; cb < N / 4; cb++)
+    for (int i = 0; i < KG; i++)
+      for (int kk = 0; kk < 4; kk++)
+        for (int tid = 0; tid < 256; tid++)
+          for (int c = 0; c < 4; c++)
+            t[((((size_t)cb * KG + i) * 4 + kk) * 256 + tid) * 4 + c] =
+                fp8_e4m3_encode(w[(size_t)(i * 1024 + 4 * tid + kk) * N + cb * 4 + c] / sc[cb * 4 + c]);
+  return t;
+}
 static std::vector<__half> to_half(const std::vector<float> &v) {
   std::vector<__half> t(v.size());
   for (size_t i = 0; i < v.size(); i++) t[i] = __float2half_rn(v[i]);
@@ -1097,7 +1198,31 @@ int ar_load(tts_ctx *ctx, const char *path) {
     if ((r = upload(ctx, st.get(), cfold, &l.db_fc))) return r;
     if ((r = upload(ctx, st.get(), pack_cols4(wf.t.at(p + ".attn.c_proj.weight").data.data(), D, D), &l.d_proj))) return r;
     if ((r = upload(ctx, st.get(), pack_cols4(wf.t.at(p + ".mlp.c_proj.weight").data.data(), FF, D), &l.d_fc2))) return r;
-    if (ctx->ar_weights) { // fp16-weight decode slabs (same packing orders)
+    if (ctx->ar_weights == 2) { // fp8-weight decode slabs
+      auto up8 = [&](const std::vector<uint8_t> &src, uint8_t **dst) {
+        void *q = nullptr;
+        TTS_HIP(ctx, hipMalloc(&q, src.size()));
+        st->owned.push_back(q);
+        TTS_HIP(ctx, hipMemcpy(q, src.data(), src.size(), hipMemcpyHostToDevice));
+        *dst = (uint8_t *)q;
+        return (int)TTS_OK;
+      };
+      std::vector<float> sc;
+      fold_layernorm(wf.t.at(p + ".attn.c_attn.weight").data.data(), D, 3 * D, wf.t.at(p + ".ln_1.weight").data.data(),
+                     wf.t.at(p + ".ln_1.bias").data.data(), wf.t.at(p + ".attn.c_attn.bias").data.data(), wfold, cfold);
+      sc = fp8_col_scales(wfold.data(), D, 3 * D);
+      if ((r = up8(pack_mfma16o(wfold.data(), D, 3 * D, sc), &l.o_attn)) || (r = upload(ctx, st.get(), sc, &l.os_attn))) return r;
+      fold_layernorm(wf.t.at(p + ".mlp.c_fc.weight").data.data(), D, FF, wf.t.at(p + ".ln_2.weight").data.data(),
+                     wf.t.at(p + ".ln_2.bias").data.data(), wf.t.at(p + ".mlp.c_fc.bias").data.data(), wfold, cfold);
+      sc = fp8_col_scales(wfold.data(), D, FF);
+      if ((r = up8(pack_mfma16o(wfold.data(), D, FF, sc), &l.o_fc)) || (r = upload(ctx, st.get(), sc, &l.os_fc))) return r;
+      const float *wp = wf.t.at(p + ".attn.c_proj.weight").data.data(), *w2 = wf.t.at(p + ".mlp.c_proj.weight").data.data();
+      sc = fp8_col_scales(wp, D, D);
+      if ((r = up8(pack_cols4o(wp, D, D, sc), &l.o_proj)) || (r = upload(ctx, st.get(), sc, &l.os_proj))) return r;
+      sc = fp8_col_scales(w2, FF, D);
+      if ((r = up8(pack_cols4o(w2, FF, D, sc), &l.o_fc2)) || (r = upload(ctx, st.get(), sc, &l.os_fc2))) return r;
+    }
+    if (ctx->ar_weights == 1) { // fp16-weight decode slabs (same packing orders)
       fold_layernorm(wf.t.at(p + ".attn.c_attn.weight").data.data(), D, 3 * D, wf.t.at(p + ".ln_1.weight").data.data(),
                      wf.t.at(p + ".ln_1.bias").data.data(), wf.t.at(p + ".attn.c_attn.bias").data.data(), wfold, cfold);
       if ((r = upload_h(ctx, st.get(), pack_mfma16q(wfold.data(), D, 3 * D), &l.q_attn))) return r;
@@ -1141,12 +1266,22 @@ int ar_load(tts_ctx *ctx, const char *path) {
                      wf.t.at("inference_model.lm_head.0.bias").data.data(), bt.data(), wfold, cfold);
       if (dec_f32_mfma) { r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, VPAD), &st->d_lm); if (r) return r; }
       r = upload_h(ctx, st.get(), pack_mfma16h(wfold.data(), D, VPAD), &st->dh_lm); if (r) return r;
-      if (ctx->ar_weights) { r = upload_h(ctx, st.get(), pack_mfma16q(wfold.data(), D, VPAD), &st->q_lm); if (r) return r; }
+      if (ctx->ar_weights == 1) { r = upload_h(ctx, st.get(), pack_mfma16q(wfold.data(), D, VPAD), &st->q_lm); if (r) return r; }
+      if (ctx->ar_weights == 2) {
+        const std::vector<float> sc = fp8_col_scales(wfold.data(), D, VPAD);
+        const std::vector<uint8_t> o = pack_mfma16o(wfold.data(), D, VPAD, sc);
+        void *q = nullptr;
+        TTS_HIP(ctx, hipMalloc(&q, o.size()));
+        st->owned.push_back(q);
+        TTS_HIP(ctx, hipMemcpy(q, o.data(), o.size(), hipMemcpyHostToDevice));
+        st->o_lm = (uint8_t *)q;
+        r = upload(ctx, st.get(), sc, &st->os_lm); if (r) return r;
+      }
       r = upload(ctx, st.get(), cfold, &st->d_lmb); if (r) return r;
     }
     r = upload(ctx, st.get(), bt, &st->lm_b); if (r) return r;
   }
-  st->has_f16_weights = ctx->ar_weights != 0;
+  st->loaded_wmode = ctx->ar_weights;
   if (ctx->ar) ar_free(ctx->ar);
   ctx->ar = st.release();
   return TTS_OK;
@@ -1368,37 +1503,44 @@ static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
   float *h = st->h.as<float>(), *q = st->qkv.as<float>(), *att = st->att.as<float>(), *ff = st->ff.as<float>();
   const StepState *ss = (const StepState *)(st->d_toks.as<int>() + B);
   const size_t layer_stride = (size_t)B * st->max_pos * D;
-  const bool wq = ctx->ar_weights != 0; // fp16 weights: half the bytes per step (throughput mode, not f32-exact); checked by ar_step
-  const double wb = wq ? 2.0 : 4.0;
+  const int wm = ctx->ar_weights; // 1 / 2: fp16 / fp8 weights, a half / a quarter of the bytes per step (throughput modes, not f32-exact); checked by ar_step
+  const double wb = wm == 2 ? 1.0 : wm == 1 ? 2.0 : 4.0;
   TTS_HIP(ctx, hipMemcpyAsync(st->d_toks.p, st->h_toks, (size_t)(B + 2) * 4, hipMemcpyHostToDevice, ctx->stream));
   embed_step_kernel<<<B, 256, 0, ctx->stream>>>(st->mel_emb, st->mel_pos, st->d_toks.as<int>(), ss, h);
   for (int l = 0; l < st->n_layers; l++) {
     const ArLayerDev &w = st->L[l];
     __half *kc = st->kcache.as<__half>() + l * layer_stride, *vc = st->vcache.as<__half>() + l * layer_stride;
     { ProfScope ps(ctx, "ar_gemv", 3.0 * D * D * wb * tiles);
-      DecLnArgs a{h, nullptr, nullptr, w.d_attn, wq ? w.q_attn : w.dh_attn, w.db_attn, B, 3 * D, D, 0, q, kc, vc, ss, st->max_pos, ctx->ggml_lut};
-      if (wq) dec_ln_gemv_kernel<DEC_QKV, 2><<<dim3(3 * D / 16, tiles), 256, 0, ctx->stream>>>(a);
+      DecLnArgs a{h, nullptr, nullptr, w.d_attn, wm == 2 ? (const __half *)w.o_attn : wm == 1 ? w.q_attn : w.dh_attn, w.db_attn, B, 3 * D, D, 0, q, kc, vc, ss,
+                  st->max_pos, ctx->ggml_lut, w.os_attn};
+      if (wm == 2) dec_ln_gemv_kernel<DEC_QKV, 3, true><<<dim3(3 * D / 16, tiles), 256, 0, ctx->stream>>>(a);
+      else if (wm == 1) dec_ln_gemv_kernel<DEC_QKV, 2><<<dim3(3 * D / 16, tiles), 256, 0, ctx->stream>>>(a);
       else DEC_LN_LAUNCH(DEC_QKV, dim3(3 * D / 16, tiles)); }
     { ProfScope ps(ctx, "ar_attention");
       if (ctx->ggml_lut) attn_decode_kernel<<<dim3(B, NH), 256, 0, ctx->stream>>>(q, kc, vc, ss, st->max_pos, att, 1);
       else attn_decode_fast_kernel<<<dim3(B, NH), 256, 0, ctx->stream>>>(q, kc, vc, ss, st->max_pos, att); }
     { ProfScope ps(ctx, "ar_gemv", 1.0 * D * D * wb * tiles);
-      if (wq) dec_gemv_resid_kernel<1, 256, true><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, (const float *)w.q_proj, w.b_proj, h);
-      else if (dec_nt) dec_gemv_resid_kernel<1, 256, false, true><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, w.d_proj, w.b_proj, h);
+      if (wm == 2) dec_gemv_resid_kernel<1, 256, 2><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, (const float *)w.o_proj, w.b_proj, h, w.os_proj);
+      else if (wm == 1) dec_gemv_resid_kernel<1, 256, 1><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, (const float *)w.q_proj, w.b_proj, h);
+      else if (dec_nt) dec_gemv_resid_kernel<1, 256, 0, true><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, w.d_proj, w.b_proj, h);
       else dec_gemv_resid_kernel<1><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, w.d_proj, w.b_proj, h); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * wb * tiles);
-      DecLnArgs a{h, nullptr, nullptr, w.d_fc, wq ? w.q_fc : w.dh_fc, w.db_fc, B, FF, 0, 0, ff, nullptr, nullptr, ss, 0, ctx->ggml_lut};
-      if (wq) dec_ln_gemv_kernel<DEC_GELU, 2><<<dim3(FF / 16, tiles), 256, 0, ctx->stream>>>(a);
+      DecLnArgs a{h, nullptr, nullptr, w.d_fc, wm == 2 ? (const __half *)w.o_fc : wm == 1 ? w.q_fc : w.dh_fc, w.db_fc, B, FF, 0, 0, ff, nullptr, nullptr, ss, 0,
+                  ctx->ggml_lut, w.os_fc};
+      if (wm == 2) dec_ln_gemv_kernel<DEC_GELU, 3, true><<<dim3(FF / 16, tiles), 256, 0, ctx->stream>>>(a);
+      else if (wm == 1) dec_ln_gemv_kernel<DEC_GELU, 2><<<dim3(FF / 16, tiles), 256, 0, ctx->stream>>>(a);
       else DEC_LN_LAUNCH(DEC_GELU, dim3(FF / 16, tiles)); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * wb * tiles);
-      if (wq) dec_gemv_resid_kernel<4, 512, true><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, (const float *)w.q_fc2, w.b_fc2, h);
-      else if (dec_nt) dec_gemv_resid_kernel<4, 512, false, true><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, w.d_fc2, w.b_fc2, h);
+      if (wm == 2) dec_gemv_resid_kernel<4, 512, 2><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, (const float *)w.o_fc2, w.b_fc2, h, w.os_fc2);
+      else if (wm == 1) dec_gemv_resid_kernel<4, 512, 1><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, (const float *)w.q_fc2, w.b_fc2, h);
+      else if (dec_nt) dec_gemv_resid_kernel<4, 512, 0, true><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, w.d_fc2, w.b_fc2, h);
       else dec_gemv_resid_kernel<4, 512><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, w.d_fc2, w.b_fc2, h); }
   }
   { ProfScope ps(ctx, "ar_gemv", (double)D * VPAD * wb * tiles);
-    DecLnArgs a{h, st->lnf_g, st->lnf_b, st->d_lm, wq ? st->q_lm : st->dh_lm, st->d_lmb, B, V, V, 0, st->logits.as<float>(),
-                nullptr, nullptr, ss, 0, ctx->ggml_lut};
-    if (wq) dec_ln_gemv_kernel<DEC_LOGITS, 2><<<dim3(VPAD / 16, tiles), 256, 0, ctx->stream>>>(a);
+    DecLnArgs a{h, st->lnf_g, st->lnf_b, st->d_lm, wm == 2 ? (const __half *)st->o_lm : wm == 1 ? st->q_lm : st->dh_lm, st->d_lmb, B, V, V, 0, st->logits.as<float>(),
+                nullptr, nullptr, ss, 0, ctx->ggml_lut, st->os_lm};
+    if (wm == 2) dec_ln_gemv_kernel<DEC_LOGITS, 3, true><<<dim3(VPAD / 16, tiles), 256, 0, ctx->stream>>>(a);
+    else if (wm == 1) dec_ln_gemv_kernel<DEC_LOGITS, 2><<<dim3(VPAD / 16, tiles), 256, 0, ctx->stream>>>(a);
     else DEC_LN_LAUNCH(DEC_LOGITS, dim3(VPAD / 16, tiles)); }
   TTS_HIP(ctx, hipMemcpyAsync(st->h_logits, st->logits.p, (size_t)B * V * 4, hipMemcpyDeviceToHost, ctx->stream));
   TTS_HIP(ctx, hipGetLastError());
@@ -1417,8 +1559,8 @@ int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out
   st->h_toks[st->B] = st->P + step_i; // n_past
   st->h_toks[st->B + 1] = step_i + 2; // mel position id (main.cpp:5244)
   // checked here, not inside enqueue_decode_step: that runs between hipStreamBeginCapture and hipStreamEndCapture
-  if (ctx->ar_weights != 0 && !st->has_f16_weights)
-    return fail(ctx, TTS_ERR_STATE, "option ar_weights = 1 must be set before tts_load_ar (the fp16 slabs are packed at load)");
+  if (ctx->ar_weights != 0 && ctx->ar_weights != st->loaded_wmode)
+    return fail(ctx, TTS_ERR_STATE, "option ar_weights = %d must be set before tts_load_ar (the fp16 / fp8 slabs are packed at load)", ctx->ar_weights);
   static const bool no_graph = getenv("TTS_NO_GRAPH") != nullptr; // e.g. under rocprofv3, which crashes on graph replays here
   // event records are not captured: the step runs eagerly while one of its own kernel families ("ar_*") is profiled
   // ("ar_decode_step" brackets the whole graph replay and keeps the graph)
@@ -1439,7 +1581,7 @@ int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out
       if (e != hipSuccess) { st->drop_graph(); TTS_HIP(ctx, e); }
     }
     // HBM-bound step: every weight once (f32: 12 d^2 per layer + the padded head) + the fp16 K/V rows read + logits
-    const double step_bytes = (ctx->ar_weights ? 2.0 : 4.0) * ((double)st->n_layers * 12.0 * D * D + (double)D * V) +
+    const double step_bytes = (ctx->ar_weights == 2 ? 1.0 : ctx->ar_weights == 1 ? 2.0 : 4.0) * ((double)st->n_layers * 12.0 * D * D + (double)D * V) +
                               (double)st->B * st->n_layers * 2.0 * (st->P + step_i + 1) * D * 2.0 + (double)st->B * V * 4.0;
     ProfScope ps(ctx, "ar_decode_step", step_bytes);
     TTS_HIP(ctx, hipGraphLaunch(st->graph_exec, ctx->stream));
