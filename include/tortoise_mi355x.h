@@ -81,6 +81,10 @@ int tts_load_diffusion(tts_ctx *ctx, const char *path);
 /* vocoder_model_load, main.cpp:1665-2021 */
 int tts_load_vocoder(tts_ctx *ctx, const char *path);
 /* number of transformer / main diffusion layers found in the file (30 / 10 for real weights) */
+/* CLVP candidate re-ranker. NOT in the reference, which writes candidate 0 (main.cpp:6575): upstream tortoise-tts
+ * scores every candidate's codes against the text with CLVP (tortoise/models/clvp.py, use_xformers=True) and keeps the best.
+ * File: the reference's container format, tensor names of the upstream state dict (tortoise.cpp_amd/synth_weights.py: write_clvp). */
+int tts_load_clvp(tts_ctx *ctx, const char *path);
 int tts_ar_layers(const tts_ctx *ctx);
 int tts_diffusion_layers(const tts_ctx *ctx);
 
@@ -137,6 +141,15 @@ int tts_autoregressive(tts_ctx *ctx, const int32_t *text_ids, int n_text, const 
 /* Per candidate of the last tts_autoregressive call: 1 = the sequence ends in a sampled stop token (what main.cpp:5214-5222
  * waits for), 0 = it was cut at max_steps (TTS_AR_RETIRE / TTS_AR_MASK_STOP) and padded like a finished one. */
 int tts_ar_stop_status(tts_ctx *ctx, int32_t *stopped_out, int n_candidates);
+
+/* ---- candidate re-ranking (not in the reference) -------------------------------------------- */
+/* Score of every candidate = cosine similarity of the text latent and the candidate's speech-code latent x exp(temperature); the
+ * caller keeps the arg-max (upstream tortoise-tts api.py; the reference keeps candidate 0, main.cpp:6575).
+ * text_ids[n_text]: tokenizer output (ids < 256). codes: candidate c's sampled mel codes at codes[c * code_stride .. + code_len[c]),
+ * every one < 8192 — the start token 8192 and the stop token 8193 are not scored (with the [B][502] output of tts_autoregressive:
+ * codes + 1, code_stride = 502, code_len[c] = number of sampled codes before the stop token). scores_out[n_candidates]. */
+int tts_clvp_score(tts_ctx *ctx, const int32_t *text_ids, int n_text, const int32_t *codes, const int32_t *code_len,
+                   int n_candidates, int code_stride, float *scores_out);
 
 /* ---- diffusion stage ----------------------------------------------------------------------- */
 /* T = L*4*24000/22050 (main.cpp:5616-5617) */

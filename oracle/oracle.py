@@ -333,6 +333,83 @@ class Vocoder:
 _ref = None
 
 
+class Clvp:
+    """CLVP re-ranker (SURVEY section 8 f2), numpy restatement of the UPSTREAM tortoise-tts model (tortoise/models/clvp.py, use_xformers=True;
+    its vendored x-transformers Encoder: RMSNorm pre-norm `x / max(|x| d^-1/2, 1e-8) * g`, bias-free q/k/v projections, rotary embedding on
+    the first 32 of the 64 head dims (half-split rotate, base 10000), softmax(q k^T / 8) v, to_out with bias, GEGLU feed-forward with
+    ff_mult = 2 (erf GELU), final LayerNorm; mean over the sequence, bias-free latent projection, L2 normalise, dot x exp(temperature)).
+    The reference has NO CLVP (main.cpp:6575 takes candidate 0), so there is no reference file:line to cite and no fixture: PARITY UNPINNED —
+    this class is pinned only against the torch restatement of the same equations (tests/torch_ref.py: TorchCLVP)."""
+    ENC = ("text_transformer", "speech_transformer")
+
+    def __init__(self, model, dtype=np.float32):
+        self.m, self.dt = model, dtype
+        te = model.tensor("text_emb.weight")
+        self.dim = te.size // 256
+        self.depth = 0
+        while True:
+            try:
+                model.tensor("text_transformer.transformer.attn_layers.layers.%d.0.g" % (2 * self.depth))
+            except KeyError:
+                break
+            self.depth += 1
+        self.inner = model.tensor("text_transformer.transformer.attn_layers.layers.0.1.to_q.weight").size // self.dim
+        self.heads = self.inner // 64
+        self.ff = model.tensor("text_transformer.transformer.attn_layers.layers.1.1.net.3.weight").size // self.dim
+
+    def _t(self, name, *shape):
+        return self.m.tensor(name).reshape(shape).astype(self.dt)
+
+    def encode(self, enc, x):
+        from scipy.special import erf
+        d, H, n = self.dim, self.heads, x.shape[0]
+        inv = 1.0 / (10000.0 ** (np.arange(0, 32, 2, dtype=self.dt) / self.dt(32.0)))
+        fr = np.outer(np.arange(n, dtype=self.dt), inv).astype(self.dt)
+        fr = np.concatenate([fr, fr], axis=-1)
+        cs, sn = np.cos(fr), np.sin(fr)
+
+        def rms(t, g):
+            nrm = np.sqrt((t * t).sum(-1, keepdims=True)) * self.dt(d ** -0.5)
+            return t / np.maximum(nrm, self.dt(1e-8)) * g
+
+        def rope(t):  # [H, n, 64]
+            tl = t[..., :32]
+            rot = np.concatenate([-tl[..., 16:], tl[..., :16]], axis=-1)
+            return np.concatenate([tl * cs + rot * sn, t[..., 32:]], axis=-1)
+
+        for i in range(self.depth):
+            a = "%s.transformer.attn_layers.layers.%d." % (enc, 2 * i)
+            f = "%s.transformer.attn_layers.layers.%d." % (enc, 2 * i + 1)
+            y = rms(x, self._t(a + "0.g", d))
+            q, k, v = ((y @ self._t(a + "1.%s.weight" % nm, self.inner, d).T).reshape(n, H, 64).transpose(1, 0, 2) for nm in ("to_q", "to_k", "to_v"))
+            q, k = rope(q), rope(k)
+            sc = (q @ k.transpose(0, 2, 1)) * self.dt(0.125)
+            sc = np.exp(sc - sc.max(-1, keepdims=True))
+            att = sc / sc.sum(-1, keepdims=True)
+            o = (att @ v).transpose(1, 0, 2).reshape(n, self.inner)
+            x = x + o @ self._t(a + "1.to_out.weight", d, self.inner).T + self._t(a + "1.to_out.bias", d)
+            y = rms(x, self._t(f + "0.g", d))
+            u = y @ self._t(f + "1.net.0.proj.weight", 2 * self.ff, d).T + self._t(f + "1.net.0.proj.bias", 2 * self.ff)
+            val, gate = u[:, :self.ff], u[:, self.ff:]
+            gl = (gate * self.dt(0.5) * (self.dt(1.0) + erf(gate / np.sqrt(self.dt(2.0))))).astype(self.dt)
+            x = x + (val * gl) @ self._t(f + "1.net.3.weight", d, self.ff).T + self._t(f + "1.net.3.bias", d)
+        mu = x.mean(-1, keepdims=True)
+        var = ((x - mu) ** 2).mean(-1, keepdims=True)
+        return (x - mu) / np.sqrt(var + self.dt(1e-5)) * self._t(enc + ".transformer.norm.weight", d) + self._t(enc + ".transformer.norm.bias", d)
+
+    def latent(self, which, tokens):
+        enc = self.ENC[which]
+        emb = self._t("text_emb.weight" if which == 0 else "speech_emb.weight", -1, self.dim)
+        proj = self._t("to_text_latent.weight" if which == 0 else "to_speech_latent.weight", -1, self.dim)
+        z = self.encode(enc, emb[np.asarray(tokens, np.int64)]).mean(0) @ proj.T
+        return z / max(float(np.sqrt((z * z).sum())), 1e-12)
+
+    def score(self, text, speech_list):
+        zt = self.latent(0, text)
+        t = float(np.exp(self.m.tensor("temperature")[0]))
+        return np.array([float((zt * self.latent(1, sp)).sum()) * t for sp in speech_list])
+
+
 def ref():
     global _ref
     if _ref is None:

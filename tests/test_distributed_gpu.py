@@ -146,3 +146,44 @@ def test_cli_devices_shards_reproduce_the_single_process_batch(small_models, tmp
     for c in range(4):
         a, b = outs["one"][c], outs["two"][c]
         assert a.shape == b.shape and np.abs(a - b).max() <= 1e-4 * max(1e-6, np.abs(a).max()), c
+
+
+def test_cli_clvp_reranking_single_process_and_shards(small_models, tmp_path):
+    """`tortoise --clvp <file>` (extension): the candidates are scored with CLVP, only the best one is carried through diffusion +
+    vocoder and written to --output. A single process and two --devices workers (both on device 0) must keep the SAME candidate (the codes of
+    a sharded batch are the single batch's) and write the same audio; that audio is the plain run's WAV of that candidate."""
+    import re
+    import shutil
+    exe = os.path.join(ROOT, "tortoise.cpp_amd", "tortoise")
+    if not os.path.exists(exe):
+        pytest.skip("CLI binary not built")
+    from tortoise_cpp_amd import synth_weights as sw
+    d = tmp_path / "models"
+    d.mkdir()
+    for f in ("ggml-model.bin", "ggml-diffusion-model.bin", "ggml-vocoder-model.bin"):
+        os.symlink(os.path.join(small_models, f), d / f)
+    shutil.copy(os.path.join(ROOT, "models", "tokenizer.json"), d / "tokenizer.json")
+    clvp = str(tmp_path / "ggml-clvp-model.bin")
+    sw.write_clvp(clvp, depth=2, seed=5)
+    base = [exe, "--models", str(d), "--message", "this is a test message.", "--voice", os.path.join(ROOT, "models", "mol.bin"), "--seed", "3",
+            "--codes", "16", "--steps", "4", "--candidates", "4"]
+    plain = tmp_path / "plain.wav"
+    r = subprocess.run(base + ["--output", str(plain)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    kept, audio = {}, {}
+    for tag, extra in (("one", []), ("two", ["--devices", "2", "--device-map", "0,0"])):
+        out = tmp_path / (tag + ".wav")
+        r = subprocess.run(base + ["--clvp", clvp, "--output", str(out)] + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        m = re.findall(r"clvp: candidate (\d+) kept", r.stdout)
+        assert m, r.stdout
+        kept[tag] = int(m[-1])
+        audio[tag] = np.frombuffer(out.read_bytes()[44:], np.float32)
+        leftovers = [f.name for f in tmp_path.iterdir() if f.name.startswith(tag + ".wav.")]
+        assert not leftovers, leftovers  # no sidecar score files, no losing workers' WAVs
+    assert kept["one"] == kept["two"]
+    c = kept["one"]
+    ref = np.frombuffer((plain if c == 0 else tmp_path / ("plain.wav.%d.wav" % c)).read_bytes()[44:], np.float32)
+    for tag in ("one", "two"):
+        a = audio[tag]
+        assert a.shape == ref.shape and np.abs(a - ref).max() <= 1e-4 * max(1e-6, np.abs(ref).max()), tag

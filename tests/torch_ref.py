@@ -270,3 +270,69 @@ class TorchAR:
         """Latent pass (main.cpp:2053-2519): mel positions 0 .. n_mel-1; returns the n_mel mel rows after both LayerNorms."""
         x = self.inputs(tokens, voice, codes[:n_mel], np.arange(n_mel))
         return self.final_norms(self.stack(x))[1 + len(tokens):].float().numpy()
+
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# CLVP re-ranker (SURVEY section 8 f2). No reference code exists for it (main.cpp:6575 takes candidate 0): this is the upstream
+# tortoise-tts architecture (tortoise/models/clvp.py, use_xformers=True; vendored x-transformers Encoder with use_rmsnorm, ff_glu,
+# rotary_pos_emb, ff_mult=2) written with torch ops, used to pin the numpy oracle (oracle.Clvp) — "parity unpinned" against upstream weights.
+# ------------------------------------------------------------------------------------------------------------------------------
+class TorchCLVP:
+    def __init__(self, path, dtype=torch.float32):
+        from tortoise_cpp_amd import synth_weights as sw
+        self.w = {k: torch.from_numpy(v).to(dtype) for k, v in sw.read_ggml(path).items()}
+        self.dtype = dtype
+        self.dim = self.w["text_emb.weight"].shape[1]
+        self.depth = 0
+        while "text_transformer.transformer.attn_layers.layers.%d.0.g" % (2 * self.depth) in self.w:
+            self.depth += 1
+        self.heads = self.w["text_transformer.transformer.attn_layers.layers.0.1.to_q.weight"].shape[0] // 64
+
+    def _rotary(self, n):
+        inv = 1.0 / (10000.0 ** (torch.arange(0, 32, 2, dtype=self.dtype) / 32.0))
+        fr = torch.einsum("i,j->ij", torch.arange(n, dtype=self.dtype), inv)
+        return torch.cat((fr, fr), dim=-1)  # [n, 32]
+
+    @staticmethod
+    def _rot_half(x):
+        x1, x2 = x[..., :16], x[..., 16:]
+        return torch.cat((-x2, x1), dim=-1)
+
+    def encode(self, enc, x):
+        w, n, H = self.w, x.shape[0], self.heads
+        fr = self._rotary(n)
+        for i in range(self.depth):
+            a = "%s.transformer.attn_layers.layers.%d." % (enc, 2 * i)
+            f = "%s.transformer.attn_layers.layers.%d." % (enc, 2 * i + 1)
+            def rms(t, g):
+                nrm = torch.linalg.vector_norm(t, dim=-1, keepdim=True) * (self.dim ** -0.5)
+                return t / nrm.clamp(min=1e-8) * g
+            y = rms(x, w[a + "0.g"])
+            q = (y @ w[a + "1.to_q.weight"].T).reshape(n, H, 64).transpose(0, 1)
+            k = (y @ w[a + "1.to_k.weight"].T).reshape(n, H, 64).transpose(0, 1)
+            v = (y @ w[a + "1.to_v.weight"].T).reshape(n, H, 64).transpose(0, 1)
+            def rope(t):
+                tl, tr = t[..., :32], t[..., 32:]
+                return torch.cat((tl * fr.cos() + self._rot_half(tl) * fr.sin(), tr), dim=-1)
+            q, k = rope(q), rope(k)
+            att = torch.softmax((q @ k.transpose(-1, -2)) * 0.125, dim=-1)
+            o = (att @ v).transpose(0, 1).reshape(n, H * 64)
+            x = x + o @ w[a + "1.to_out.weight"].T + w[a + "1.to_out.bias"]
+            y = rms(x, w[f + "0.g"])
+            u = y @ w[f + "1.net.0.proj.weight"].T + w[f + "1.net.0.proj.bias"]
+            val, gate = u.chunk(2, dim=-1)
+            x = x + (val * torch.nn.functional.gelu(gate)) @ w[f + "1.net.3.weight"].T + w[f + "1.net.3.bias"]
+        return torch.nn.functional.layer_norm(x, (self.dim,), w[enc + ".transformer.norm.weight"], w[enc + ".transformer.norm.bias"], 1e-5)
+
+    def latent(self, enc, emb, proj, tokens):
+        x = self.w[emb][torch.as_tensor(np.asarray(tokens), dtype=torch.long)]
+        z = self.encode(enc, x).mean(dim=0) @ self.w[proj].T
+        return torch.nn.functional.normalize(z, p=2, dim=-1)
+
+    def score(self, text, speech_list):
+        """cosine similarity x exp(temperature) of the text with every speech-code sequence."""
+        zt = self.latent("text_transformer", "text_emb.weight", "to_text_latent.weight", text)
+        t = self.w["temperature"].reshape(()).exp()
+        return np.array([float((zt * self.latent("speech_transformer", "speech_emb.weight", "to_speech_latent.weight", sp)).sum() * t)
+                         for sp in speech_list])

@@ -48,7 +48,8 @@ def lib():
         "tts_create": (vp, [ci]), "tts_destroy": (None, [vp]), "tts_last_error": (C.c_char_p, [vp]),
         "tts_set_option": (ci, [vp, C.c_char_p, C.c_double]),
         "tts_load_ar": (ci, [vp, C.c_char_p]), "tts_load_diffusion": (ci, [vp, C.c_char_p]),
-        "tts_load_vocoder": (ci, [vp, C.c_char_p]), "tts_ar_layers": (ci, [vp]), "tts_diffusion_layers": (ci, [vp]),
+        "tts_load_vocoder": (ci, [vp, C.c_char_p]), "tts_load_clvp": (ci, [vp, C.c_char_p]),
+        "tts_clvp_score": (ci, [vp, _i32p, ci, _i32p, _i32p, ci, ci, _f32p]), "tts_ar_layers": (ci, [vp]), "tts_diffusion_layers": (ci, [vp]),
         "tts_seed": (None, [vp, C.c_uint32]), "tts_rng_load_state": (ci, [vp, C.c_char_p]), "tts_rng_save_state": (ci, [vp, C.c_char_p]),
         "tts_rng_uniform": (cf, [vp]), "tts_rng_normal": (None, [vp, _f32p, C.c_int64]),
         "tts_tokenizer_load": (ci, [vp, C.c_char_p]), "tts_tokenize": (ci, [vp, C.c_char_p, _i32p, ci]),
@@ -206,6 +207,21 @@ class Engine:
         """Per candidate of the last autoregressive() call: 1 = ended in a sampled stop token, 0 = cut at max_steps."""
         out = np.zeros(B, np.int32)
         self._ck(self.L.tts_ar_stop_status(self.h, out, B))
+        return out
+
+    # ---- candidate re-ranking (not in the reference) ----
+    def load_clvp(self, path):
+        self._ck(self.L.tts_load_clvp(self.h, path.encode()))
+
+    def clvp_score(self, text_ids, codes_list):
+        """codes_list: per candidate its sampled mel codes (< 8192, no start / stop token). Returns scores [n_candidates]."""
+        lens = np.array([len(c) for c in codes_list], np.int32)
+        stride = int(lens.max())
+        codes = np.zeros((len(codes_list), stride), np.int32)
+        for i, c in enumerate(codes_list):
+            codes[i, :len(c)] = c
+        out = np.empty(len(codes_list), np.float32)
+        self._ck(self.L.tts_clvp_score(self.h, np.ascontiguousarray(text_ids, np.int32), len(text_ids), codes.reshape(-1), lens, len(codes_list), stride, out))
         return out
 
     # ---- diffusion ----

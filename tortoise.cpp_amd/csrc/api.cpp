@@ -78,6 +78,7 @@ void tts_destroy(tts_ctx *c) {
   if (c->ar) ar_free(c->ar);
   if (c->diff) diff_free(c->diff);
   if (c->voc) voc_free(c->voc);
+  if (c->clvp) clvp_free(c->clvp);
   delete c->tok;
   for (auto &kv : c->prof)
     for (auto &pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -120,7 +121,7 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
     // hipExtStreamCreateWithCUMask on gfx950: bit i = XCD i % 8, CU slot i / 8 (tools/cu_mask_probe.hip); an XCD with no bit set is
     // unrestricted, so every XCD keeps at least one CU. Only before any model is loaded / graph captured on the old stream.
     if (c->device < 0) return fail(c, TTS_ERR_HIP, "host-only context: no stream");
-    if (c->ar || c->diff || c->voc) return fail(c, TTS_ERR_STATE, "stream_cus must be set before the models are loaded");
+    if (c->ar || c->diff || c->voc || c->clvp) return fail(c, TTS_ERR_STATE, "stream_cus must be set before the models are loaded");
     (void)hipSetDevice(c->device);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return fail(c, TTS_ERR_HIP, "hipGetDeviceProperties failed");
@@ -158,6 +159,12 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
 int tts_load_ar(tts_ctx *c, const char *path) { NEED_CTX(c); return guarded(c, [&] { return ar_load(c, path); }); }
 int tts_load_diffusion(tts_ctx *c, const char *path) { NEED_CTX(c); return guarded(c, [&] { return diff_load(c, path); }); }
 int tts_load_vocoder(tts_ctx *c, const char *path) { NEED_CTX(c); return guarded(c, [&] { return voc_load(c, path); }); }
+int tts_load_clvp(tts_ctx *c, const char *path) { NEED_CTX(c); return guarded(c, [&] { return clvp_load(c, path); }); }
+int tts_clvp_score(tts_ctx *c, const int32_t *text_ids, int n_text, const int32_t *codes, const int32_t *code_len, int n_candidates,
+                   int code_stride, float *scores_out) {
+  NEED_CTX(c);
+  return guarded(c, [&] { return clvp_score(c, text_ids, n_text, codes, code_len, n_candidates, code_stride, scores_out); });
+}
 int tts_ar_layers(const tts_ctx *c) { return c ? ar_layers(c) : 0; }
 int tts_diffusion_layers(const tts_ctx *c) { return c ? diff_layers(c) : 0; }
 

@@ -11,6 +11,9 @@
 // Extensions (not in the reference): --models <dir>, --candidates <n> (all candidates are carried
 // through; candidate 0 is written to --output like the reference, others to <output>.<c>.wav),
 // --steps <n> diffusion steps (default 80), --device <ordinal>, --codes <n>,
+// --clvp <file>: re-rank the candidates with CLVP (not in the reference, which keeps candidate 0, main.cpp:6575; upstream tortoise-tts
+//   does this): every candidate's codes are scored against the text, only the best one goes through diffusion + vocoder and is written
+//   to --output. With --devices every worker scores its own shard and the parent keeps the best of the workers' winners.
 // --devices <N> [--device-map a,b,...]: candidate-parallel multi-GPU run. The process re-executes itself once per GPU
 //   (one process per device, replicated weights); worker r takes candidates [r B/N, (r+1) B/N) of the ONE batch: the RNG stream
 //   partition (options rng_shard_offset / rng_shard_total) makes the N x B/N codes identical to a single-GPU run of B candidates,
@@ -40,7 +43,7 @@ int main(int argc, char **argv) {
   std::string modelsDir = "../models";
   bool have_seed = false;
   int seed = 0, candidates = 1, steps = 80, device = 0, fixed_codes = 0, devices = 1, shard = -1, nshards = 1;
-  std::string device_map;
+  std::string device_map, clvpPath;
   for (int i = 1; i < argc - 1; ++i) {
     std::string a(argv[i]);
     if (a == "--voice") voicePath = argv[i + 1];
@@ -54,6 +57,7 @@ int main(int argc, char **argv) {
     else if (a == "--codes") fixed_codes = std::stoi(argv[i + 1]); // exactly N sampled codes, stop token masked (synthetic weights never stop)
     else if (a == "--devices") devices = std::stoi(argv[i + 1]);
     else if (a == "--device-map") device_map = argv[i + 1];
+    else if (a == "--clvp") clvpPath = argv[i + 1];
     else if (a == "--shard") { // worker mode (set by the parent): "r/N"
       std::string v(argv[i + 1]);
       const size_t sl = v.find('/');
@@ -94,6 +98,27 @@ int main(int argc, char **argv) {
       int st = 0;
       if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1;
     }
+    if (rc == 0 && !clvpPath.empty()) { // every worker left "<output>.shard<r>.score" = "<global candidate> <score>" and that candidate's WAV
+      int best_gc = -1;
+      double best_score = 0;
+      std::vector<int> winners;
+      for (int r = 0; r < devices; r++) {
+        const std::string sp = outputPath + ".shard" + std::to_string(r) + ".score";
+        std::ifstream f(sp);
+        int gc; double sc;
+        if (!(f >> gc >> sc)) { fprintf(stderr, "missing CLVP score of worker %d\n", r); return 1; }
+        winners.push_back(gc);
+        if (best_gc < 0 || sc > best_score) { best_gc = gc; best_score = sc; }
+        std::remove(sp.c_str());
+      }
+      for (int gc : winners) {
+        const std::string wp = outputPath + "." + std::to_string(gc) + ".wav";
+        if (gc == best_gc) { if (std::rename(wp.c_str(), outputPath.c_str())) { perror("rename"); return 1; } }
+        else std::remove(wp.c_str());
+      }
+      printf("clvp: candidate %d kept (score %.5f)\n", best_gc, best_score);
+      std::cout << "WAV file saved successfully. :^)" << std::endl;
+    }
     return rc;
   }
   const int total_candidates = candidates;
@@ -121,22 +146,50 @@ int main(int argc, char **argv) {
     f.read((char *)voice.data(), 1024 * sizeof(float));
   }
   if (tts_load_ar(ctx, (modelsDir + "/ggml-model.bin").c_str())) return die(ctx, "autoregressive_model_load");
-  const int B = candidates;
-  std::vector<int32_t> codes((size_t)B * 502), rows(B);
-  std::vector<float> latents((size_t)B * 500 * 1024);
+  const int B_ar = candidates;
+  std::vector<int32_t> codes((size_t)B_ar * 502), rows(B_ar);
+  std::vector<float> latents((size_t)B_ar * 500 * 1024);
   int32_t nsteps = 0;
   // More than one candidate (in this process or across --devices shards): the throughput stop rule. The reference's "all B samples of ONE
   // step are 8193" practically never fires for B > 1 (and would need a per-step exchange between shards); every sequence is the same.
   const unsigned ar_flags = (fixed_codes > 0 ? TTS_AR_MASK_STOP : 0) | (total_candidates > 1 ? TTS_AR_RETIRE : 0);
-  if (tts_autoregressive(ctx, tokens.data(), n, voice.data(), B, fixed_codes > 0 ? fixed_codes : 500, ar_flags,
+  if (tts_autoregressive(ctx, tokens.data(), n, voice.data(), B_ar, fixed_codes > 0 ? fixed_codes : 500, ar_flags,
                          codes.data(), rows.data(), latents.data(), &nsteps))
     return die(ctx, "autoregressive");
   printf("tokens sampled: %d\n", nsteps);
   if (fixed_codes <= 0) {
-    std::vector<int32_t> stopped(B);
-    if (tts_ar_stop_status(ctx, stopped.data(), B) == 0)
-      for (int c = 0; c < B; c++)
-        if (!stopped[c]) fprintf(stderr, "warning: candidate %d sampled no stop token within 500 codes (sequence cut)\n", (shard >= 0 ? shard * B : 0) + c);
+    std::vector<int32_t> stopped(B_ar);
+    if (tts_ar_stop_status(ctx, stopped.data(), B_ar) == 0)
+      for (int c = 0; c < B_ar; c++)
+        if (!stopped[c]) fprintf(stderr, "warning: candidate %d sampled no stop token within 500 codes (sequence cut)\n", (shard >= 0 ? shard * B_ar : 0) + c);
+  }
+
+  // CLVP re-ranking (extension): keep the candidate whose codes (the rows the diffusion stage would consume) score best against the text
+  int B = B_ar, kept_gc = -1;
+  const float *lat_in = latents.data();
+  double kept_score = 0;
+  if (!clvpPath.empty()) {
+    if (tts_load_clvp(ctx, clvpPath.c_str())) return die(ctx, "clvp_model_load");
+    std::vector<float> scores(B_ar);
+    if (tts_clvp_score(ctx, tokens.data(), n, codes.data() + 1, rows.data(), B_ar, 502, scores.data())) return die(ctx, "clvp");
+    int best = 0;
+    for (int c = 1; c < B_ar; c++)
+      if (scores[c] > scores[best]) best = c;
+    printf("clvp scores:");
+    for (int c = 0; c < B_ar; c++) printf(" %.5f", scores[c]);
+    printf("\n");
+    size_t off_rows = 0;
+    for (int c = 0; c < best; c++) off_rows += (size_t)rows[c];
+    lat_in = latents.data() + off_rows * 1024;
+    rows[0] = rows[best];
+    B = 1;
+    kept_gc = (shard >= 0 ? shard * B_ar : 0) + best;
+    kept_score = scores[best];
+    if (total_candidates > 1) { // device noise stays keyed by the kept candidate's global id
+      tts_set_option(ctx, "rng_shard_offset", (double)kept_gc);
+      tts_set_option(ctx, "rng_shard_total", (double)total_candidates);
+    }
+    if (shard < 0) printf("clvp: candidate %d kept (score %.5f)\n", kept_gc, kept_score);
   }
 
   if (tts_load_diffusion(ctx, (modelsDir + "/ggml-diffusion-model.bin").c_str())) return die(ctx, "diffusion_model_load");
@@ -150,20 +203,26 @@ int main(int argc, char **argv) {
   std::vector<float> mel(mel_total), audio(audio_total);
   // B == 1: the reference's exact RNG order (AR uniforms, x_T, per-step noise, vocoder noise)
   const int noise_mode = (total_candidates == 1) ? TTS_NOISE_REFERENCE : TTS_NOISE_DEVICE;
-  if (tts_diffusion(ctx, latents.data(), rows.data(), B, steps, nullptr, noise_mode, mel.data())) return die(ctx, "diffusion");
+  if (tts_diffusion(ctx, lat_in, rows.data(), B, steps, nullptr, noise_mode, mel.data())) return die(ctx, "diffusion");
   if (tts_load_vocoder(ctx, (modelsDir + "/ggml-vocoder-model.bin").c_str())) return die(ctx, "vocoder_model_load");
   if (tts_vocoder(ctx, mel.data(), frames.data(), B, nullptr, noise_mode, audio.data())) return die(ctx, "vocoder");
   size_t off = 0;
   for (int c = 0; c < B; c++) {
     size_t ns = (size_t)tts_vocoder_samples(frames[c]);
-    const int gc = (shard >= 0 ? shard * B : 0) + c; // global candidate index
-    std::string path = (gc == 0) ? outputPath : outputPath + "." + std::to_string(gc) + ".wav";
+    const int gc = kept_gc >= 0 ? kept_gc : (shard >= 0 ? shard * B_ar : 0) + c; // global candidate index
+    // the re-ranked winner of a single process IS the output; a worker's winner waits for the parent's pick under its candidate name
+    const bool is_output = kept_gc >= 0 ? shard < 0 : gc == 0;
+    std::string path = is_output ? outputPath : outputPath + "." + std::to_string(gc) + ".wav";
     if (tts_write_wav(path.c_str(), audio.data() + off, (int64_t)ns, 24000)) {
       std::cerr << "Error opening output file." << std::endl;
-    } else if (gc == 0) {
+    } else if (is_output) {
       std::cout << "WAV file saved successfully. :^)" << std::endl;
     }
     off += ns;
+  }
+  if (kept_gc >= 0 && shard >= 0) {
+    std::ofstream f(outputPath + ".shard" + std::to_string(shard) + ".score");
+    f << kept_gc << " " << kept_score << "\n";
   }
   tts_destroy(ctx);
   return 0;

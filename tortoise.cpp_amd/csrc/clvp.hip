@@ -1,0 +1,347 @@
+// CLVP candidate re-ranking on MI355X (gfx950) — SURVEY section 8 f2.
+//
+// The reference has no CLVP: main.cpp:6575 writes candidate 0. Upstream tortoise-tts scores every autoregressive candidate with CLVP
+// (tortoise/models/clvp.py, use_xformers=True) and keeps the best; this file is that scorer behind tts_load_clvp / tts_clvp_score, for a
+// weight file in the reference's container format whose tensor names are the upstream state dict's (tortoise.cpp_amd/synth_weights.py:
+// write_clvp lists them). Checked against oracle.Clvp (numpy, pinned against a torch restatement): no upstream weights or fixtures exist
+// offline, so its parity is "unpinned" in the sense of the task statement.
+//
+// Model: two encoders (text, speech codes) of `depth` x [RMSNorm -> attention (bias-free q/k/v, rotary on the first 32 of 64 head dims,
+// softmax(q k^T / 8) v, to_out + bias) -> residual; RMSNorm -> GEGLU feed-forward (ff = 2 dim) -> residual], final LayerNorm, mean over the
+// sequence, bias-free latent projection, L2 normalise; score = <text latent, speech latent> exp(temperature).
+//
+// Device layout: all sequences of a call are packed into ONE row-major activation matrix x[rows][dim] (f32 residual stream, rows padded
+// to a multiple of 128); every projection is one launch of the fp16-MFMA GEMM of gemm_f16.h (fp16 operands, f32 accumulate, bias and
+// residual fused into the epilogue) over all rows; attention runs per (sequence, head) with K/V staged through LDS in chunks of 128 keys.
+// The scorer runs once per utterance on <= 16 x ~200 rows: it is 1-2 ms of work, the kernels are written for clarity.
+#include "common.h"
+#include "gemm_f16.h"
+#include <cmath>
+
+namespace tts {
+
+namespace {
+constexpr int CLVP_DH = 64, CLVP_KCHUNK = 128; // head dim (the first 32 carry the rotary embedding), keys per LDS stage
+
+__global__ __launch_bounds__(256) void clvp_embed_kernel(const float *__restrict__ emb, const int *__restrict__ tok, int dim, float *__restrict__ x) {
+  const float *src = emb + (size_t)tok[blockIdx.x] * dim;
+  for (int c = threadIdx.x; c < dim; c += 256) x[(size_t)blockIdx.x * dim + c] = src[c];
+}
+
+__device__ __forceinline__ float block_sum(float v, float *red) { // 256 threads
+  for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// y = x / max(|x| dim^-1/2, 1e-8) * g, rounded to fp16 (the A operand of the next GEMM)
+__global__ __launch_bounds__(256) void clvp_rmsnorm_kernel(const float *__restrict__ x, const float *__restrict__ g, int dim, __half *__restrict__ y) {
+  __shared__ float red[4];
+  const float *xr = x + (size_t)blockIdx.x * dim;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < dim; c += 256) ss += xr[c] * xr[c];
+  ss = block_sum(ss, red);
+  const float inv = 1.0f / fmaxf(sqrtf(ss) * rsqrtf((float)dim), 1e-8f);
+  for (int c = threadIdx.x; c < dim; c += 256) y[(size_t)blockIdx.x * dim + c] = __float2half_rn(xr[c] * inv * g[c]);
+}
+
+// One workgroup = 256 queries of one (sequence, head); a thread owns one query (q and the output row in registers, f32), the keys stream
+// through LDS in chunks of 128 (K rotated on the way in). qkv: fp16 [row][3 inner] = q | k | v, head h at columns h*64.
+__global__ __launch_bounds__(256) void clvp_attn_kernel(const __half *__restrict__ qkv, const int *__restrict__ seq_start, const int *__restrict__ seq_len,
+                                                        int inner, __half *__restrict__ out) {
+  __shared__ __half sk[CLVP_KCHUNK][CLVP_DH], sv[CLVP_KCHUNK][CLVP_DH];
+  const int s = blockIdx.x, h = blockIdx.y, n = seq_len[s], r0 = seq_start[s];
+  const int qi = blockIdx.z * 256 + threadIdx.x;
+  if (blockIdx.z * 256 >= n) return;
+  const int ld = 3 * inner;
+  auto rot = [](float *t, int pos) { // rotary embedding on dims 0..31: pairs (d, d + 16), angle pos * 10000^(-2 d / 32)
+#pragma unroll
+    for (int d = 0; d < 16; d++) {
+      const float ang = (float)pos * exp2f(-(float)d * (13.287712379549449f / 16.0f)); // 10000^(-d/16)
+      const float c = cosf(ang), sn = sinf(ang), a = t[d], b = t[d + 16];
+      t[d] = a * c - b * sn;
+      t[d + 16] = b * c + a * sn;
+    }
+  };
+  float q[CLVP_DH], acc[CLVP_DH];
+  const bool live = qi < n;
+  {
+    const __half *qp = qkv + (size_t)(r0 + (live ? qi : 0)) * ld + h * CLVP_DH;
+#pragma unroll
+    for (int d = 0; d < CLVP_DH; d++) { q[d] = __half2float(qp[d]); acc[d] = 0.f; }
+    rot(q, live ? qi : 0);
+  }
+  float m = -INFINITY, l = 0.f;
+  for (int k0 = 0; k0 < n; k0 += CLVP_KCHUNK) {
+    __syncthreads();
+    { // 256 threads stage 128 keys: thread t -> key t >> 1, dims (t & 1) * 32 .. + 31 (the rotated half is dims 0..31: one thread owns it)
+      const int kj = threadIdx.x >> 1, half = threadIdx.x & 1, key = k0 + kj;
+      if (key < n) {
+        const __half *kp = qkv + (size_t)(r0 + key) * ld + inner + h * CLVP_DH + half * 32;
+        const __half *vp = qkv + (size_t)(r0 + key) * ld + 2 * inner + h * CLVP_DH + half * 32;
+        float t[32];
+#pragma unroll
+        for (int d = 0; d < 32; d++) t[d] = __half2float(kp[d]);
+        if (half == 0) rot(t, key);
+#pragma unroll
+        for (int d = 0; d < 32; d++) { sk[kj][half * 32 + d] = __float2half_rn(t[d]); sv[kj][half * 32 + d] = vp[d]; }
+      }
+    }
+    __syncthreads();
+    const int kn = min(CLVP_KCHUNK, n - k0);
+    for (int j = 0; j < kn; j++) {
+      float sc = 0.f;
+#pragma unroll
+      for (int d = 0; d < CLVP_DH; d++) sc += q[d] * __half2float(sk[j][d]);
+      sc *= 0.125f;
+      const float mn = fmaxf(m, sc), a = expf(m - mn), p = expf(sc - mn);
+      l = l * a + p;
+#pragma unroll
+      for (int d = 0; d < CLVP_DH; d++) acc[d] = acc[d] * a + p * __half2float(sv[j][d]);
+      m = mn;
+    }
+  }
+  if (live) {
+    const float inv = 1.0f / l;
+    __half *op = out + (size_t)(r0 + qi) * inner + h * CLVP_DH;
+#pragma unroll
+    for (int d = 0; d < CLVP_DH; d++) op[d] = __float2half_rn(acc[d] * inv);
+  }
+}
+
+// GEGLU: y = u[:, :ff] * gelu(u[:, ff:]) (erf GELU), fp16
+__global__ __launch_bounds__(256) void clvp_geglu_kernel(const float *__restrict__ u, int ff, __half *__restrict__ y) {
+  const float *ur = u + (size_t)blockIdx.x * 2 * ff;
+  for (int c = threadIdx.x; c < ff; c += 256) {
+    const float g = ur[ff + c];
+    y[(size_t)blockIdx.x * ff + c] = __float2half_rn(ur[c] * (0.5f * g * (1.0f + erff(g * 0.70710678118654752f))));
+  }
+}
+
+// final LayerNorm of every row of a sequence, then the mean over its rows: pooled[seq][dim]
+__global__ __launch_bounds__(256) void clvp_pool_kernel(const float *__restrict__ x, const int *__restrict__ seq_start, const int *__restrict__ seq_len,
+                                                        const float *__restrict__ w, const float *__restrict__ b, int dim, float *__restrict__ pooled) {
+  __shared__ float red[4];
+  const int s = blockIdx.x, n = seq_len[s], r0 = seq_start[s];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f}; // dim <= 1024: columns threadIdx.x + 256 i
+  for (int r = 0; r < n; r++) {
+    const float *xr = x + (size_t)(r0 + r) * dim;
+    float sum = 0.f;
+    for (int c = threadIdx.x; c < dim; c += 256) sum += xr[c];
+    const float mean = block_sum(sum, red) / dim;
+    float sq = 0.f;
+    for (int c = threadIdx.x; c < dim; c += 256) sq += (xr[c] - mean) * (xr[c] - mean);
+    const float rstd = rsqrtf(block_sum(sq, red) / dim + 1e-5f);
+    for (int i = 0, c = threadIdx.x; c < dim; c += 256, i++) acc[i] += (xr[c] - mean) * rstd * w[c] + b[c];
+  }
+  for (int i = 0, c = threadIdx.x; c < dim; c += 256, i++) pooled[(size_t)s * dim + c] = acc[i] / n;
+}
+} // namespace
+
+struct ClvpLayer {
+  float *g_attn = nullptr, *g_ff = nullptr, *b_out = nullptr, *b_ff1 = nullptr, *b_ff2 = nullptr;
+  __half *w_qkv = nullptr, *w_out = nullptr, *w_ff1 = nullptr, *w_ff2 = nullptr;
+};
+struct ClvpState {
+  int dim = 0, depth = 0, inner = 0, ff = 0, n_text = 0, n_speech = 0;
+  float temperature = 0.f;
+  float *emb[2] = {nullptr, nullptr}, *norm_w[2] = {nullptr, nullptr}, *norm_b[2] = {nullptr, nullptr};
+  std::vector<ClvpLayer> L[2];
+  std::vector<float> proj[2]; // to_text_latent / to_speech_latent [latent][dim] (host: 16 x dim x latent multiply-adds per call)
+  int latent = 0;
+  std::vector<void *> owned;
+  DevBuf x, y16, qkv16, att16, u32, pooled, meta;
+  ~ClvpState() { for (void *p : owned) (void)hipFree(p); }
+};
+void clvp_free(ClvpState *s) { delete s; }
+
+static int clvp_up(tts_ctx *ctx, ClvpState *st, const std::vector<float> &src, float **dst) {
+  void *p = nullptr;
+  TTS_HIP(ctx, hipMalloc(&p, src.size() * 4));
+  st->owned.push_back(p);
+  TTS_HIP(ctx, hipMemcpy(p, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+  *dst = (float *)p;
+  return TTS_OK;
+}
+static int clvp_up16(tts_ctx *ctx, ClvpState *st, const std::vector<const std::vector<float> *> &parts, __half **dst) {
+  std::vector<__half> h;
+  for (auto *v : parts)
+    for (float f : *v) h.push_back(__float2half_rn(f));
+  void *p = nullptr;
+  TTS_HIP(ctx, hipMalloc(&p, h.size() * 2));
+  st->owned.push_back(p);
+  TTS_HIP(ctx, hipMemcpy(p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  *dst = (__half *)p;
+  return TTS_OK;
+}
+
+int clvp_load(tts_ctx *ctx, const char *path) {
+  WeightFile wf;
+  std::string err;
+  int rc = read_weight_file(path, wf, err);
+  if (rc != TTS_OK) return fail(ctx, rc, "clvp_load: %s", err.c_str());
+  std::unique_ptr<ClvpState> st(new ClvpState());
+  auto need = [&](const std::string &name, int64_t n0, int64_t n1) -> const HostTensor * {
+    auto it = wf.t.find(name);
+    if (it == wf.t.end()) { fail(ctx, TTS_ERR_FORMAT, "tensor '%s' missing from CLVP model file", name.c_str()); return nullptr; }
+    if (it->second.ne[0] != n0 || it->second.ne[1] != n1 || it->second.nelem() != n0 * n1) {
+      fail(ctx, TTS_ERR_FORMAT, "tensor '%s' has wrong shape in CLVP model file: got [%d, %d], expected [%d, %d]", name.c_str(),
+           (int)it->second.ne[0], (int)it->second.ne[1], (int)n0, (int)n1);
+      return nullptr;
+    }
+    return &it->second;
+  };
+  if (!wf.has("text_emb.weight") || !wf.has("speech_emb.weight")) return fail(ctx, TTS_ERR_FORMAT, "'%s' is not a CLVP model file", path);
+  st->dim = (int)wf.t.at("text_emb.weight").ne[0];
+  st->n_text = (int)wf.t.at("text_emb.weight").ne[1];
+  st->n_speech = (int)wf.t.at("speech_emb.weight").ne[1];
+  const std::string lp = ".transformer.attn_layers.layers.";
+  while (wf.has("text_transformer" + lp + std::to_string(2 * st->depth) + ".0.g")) st->depth++;
+  if (st->depth == 0) return fail(ctx, TTS_ERR_FORMAT, "no encoder layers in '%s'", path);
+  st->inner = (int)wf.t.at("text_transformer" + lp + "0.1.to_q.weight").ne[1];
+  st->ff = (int)wf.t.at("text_transformer" + lp + "1.1.net.3.weight").ne[0];
+  st->latent = (int)wf.t.at("to_text_latent.weight").ne[1];
+  const int d = st->dim, in = st->inner, ff = st->ff;
+  if (d % 128 || d > 1024 || in % 128 || ff % 128 || in % CLVP_DH)
+    return fail(ctx, TTS_ERR_FORMAT, "CLVP dims %d / %d / %d: multiples of 128 (dim <= 1024) expected", d, in, ff);
+  const HostTensor *t;
+  if (!(t = need("temperature", 1, 1))) return TTS_ERR_FORMAT;
+  st->temperature = t->data[0];
+  const char *encs[2] = {"text_transformer", "speech_transformer"}, *embs[2] = {"text_emb.weight", "speech_emb.weight"},
+             *projs[2] = {"to_text_latent.weight", "to_speech_latent.weight"};
+  size_t known = 5; // embeddings, projections, temperature
+  for (int e = 0; e < 2; e++) {
+    if (!(t = need(embs[e], d, e ? st->n_speech : st->n_text))) return TTS_ERR_FORMAT;
+    if ((rc = clvp_up(ctx, st.get(), t->data, &st->emb[e]))) return rc;
+    if (!(t = need(projs[e], d, st->latent))) return TTS_ERR_FORMAT;
+    st->proj[e] = t->data;
+    st->L[e].resize(st->depth);
+    for (int i = 0; i < st->depth; i++) {
+      ClvpLayer &l = st->L[e][i];
+      const std::string a = std::string(encs[e]) + lp + std::to_string(2 * i) + ".", f = std::string(encs[e]) + lp + std::to_string(2 * i + 1) + ".";
+      const HostTensor *q, *k, *v;
+      if (!(t = need(a + "0.g", d, 1)) || (rc = clvp_up(ctx, st.get(), t->data, &l.g_attn))) return rc ? rc : TTS_ERR_FORMAT;
+      if (!(q = need(a + "1.to_q.weight", d, in)) || !(k = need(a + "1.to_k.weight", d, in)) || !(v = need(a + "1.to_v.weight", d, in))) return TTS_ERR_FORMAT;
+      if ((rc = clvp_up16(ctx, st.get(), {&q->data, &k->data, &v->data}, &l.w_qkv))) return rc; // [3 inner][dim]: one projection launch
+      if (!(t = need(a + "1.to_out.weight", in, d)) || (rc = clvp_up16(ctx, st.get(), {&t->data}, &l.w_out))) return rc ? rc : TTS_ERR_FORMAT;
+      if (!(t = need(a + "1.to_out.bias", d, 1)) || (rc = clvp_up(ctx, st.get(), t->data, &l.b_out))) return rc ? rc : TTS_ERR_FORMAT;
+      if (!(t = need(f + "0.g", d, 1)) || (rc = clvp_up(ctx, st.get(), t->data, &l.g_ff))) return rc ? rc : TTS_ERR_FORMAT;
+      if (!(t = need(f + "1.net.0.proj.weight", d, 2 * ff)) || (rc = clvp_up16(ctx, st.get(), {&t->data}, &l.w_ff1))) return rc ? rc : TTS_ERR_FORMAT;
+      if (!(t = need(f + "1.net.0.proj.bias", 2 * ff, 1)) || (rc = clvp_up(ctx, st.get(), t->data, &l.b_ff1))) return rc ? rc : TTS_ERR_FORMAT;
+      if (!(t = need(f + "1.net.3.weight", ff, d)) || (rc = clvp_up16(ctx, st.get(), {&t->data}, &l.w_ff2))) return rc ? rc : TTS_ERR_FORMAT;
+      if (!(t = need(f + "1.net.3.bias", d, 1)) || (rc = clvp_up(ctx, st.get(), t->data, &l.b_ff2))) return rc ? rc : TTS_ERR_FORMAT;
+      known += 11;
+    }
+    if (!(t = need(std::string(encs[e]) + ".transformer.norm.weight", d, 1)) || (rc = clvp_up(ctx, st.get(), t->data, &st->norm_w[e]))) return rc ? rc : TTS_ERR_FORMAT;
+    if (!(t = need(std::string(encs[e]) + ".transformer.norm.bias", d, 1)) || (rc = clvp_up(ctx, st.get(), t->data, &st->norm_b[e]))) return rc ? rc : TTS_ERR_FORMAT;
+    known += 2;
+  }
+  // every tensor in the file must be known (the loaders of the three reference models do the same, main.cpp:834-838); the rotary
+  // inv_freq buffers of the upstream state dict are recomputed here and may be present
+  size_t extra = 0;
+  for (auto &kv : wf.t)
+    if (kv.first.find("rotary_pos_emb.inv_freq") != std::string::npos) extra++;
+  if (wf.t.size() != known + extra) return fail(ctx, TTS_ERR_FORMAT, "unknown tensors in CLVP model file '%s' (%d tensors, %d expected)", path, (int)wf.t.size(), (int)(known + extra));
+  if (ctx->clvp) clvp_free(ctx->clvp);
+  ctx->clvp = st.release();
+  return TTS_OK;
+}
+
+// pooled latent of every sequence of one encoder: lens[n_seq] token counts, tokens concatenated
+static int clvp_encode(tts_ctx *ctx, ClvpState *st, int e, const std::vector<int> &tokens, const std::vector<int> &lens, std::vector<float> &lat_out) {
+  const int d = st->dim, in = st->inner, ff = st->ff, nseq = (int)lens.size();
+  int rows = 0, maxlen = 0;
+  std::vector<int> meta(2 * nseq);
+  for (int s = 0; s < nseq; s++) { meta[s] = rows; meta[nseq + s] = lens[s]; rows += lens[s]; maxlen = std::max(maxlen, lens[s]); }
+  const int M = (rows + 127) / 128 * 128;
+  TTS_HIP(ctx, st->x.reserve((size_t)M * d * 4));
+  TTS_HIP(ctx, st->y16.reserve((size_t)M * std::max(d, ff) * 2));
+  TTS_HIP(ctx, st->qkv16.reserve((size_t)M * 3 * in * 2));
+  TTS_HIP(ctx, st->att16.reserve((size_t)M * in * 2));
+  TTS_HIP(ctx, st->u32.reserve((size_t)M * 2 * ff * 4));
+  TTS_HIP(ctx, st->pooled.reserve((size_t)nseq * d * 4));
+  TTS_HIP(ctx, st->meta.reserve((size_t)(2 * nseq + rows) * 4));
+  int *d_start = st->meta.as<int>(), *d_len = d_start + nseq, *d_tok = d_len + nseq;
+  TTS_HIP(ctx, hipMemcpyAsync(d_start, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  TTS_HIP(ctx, hipMemcpyAsync(d_tok, tokens.data(), (size_t)rows * 4, hipMemcpyHostToDevice, ctx->stream));
+  // rows past the last token are multiplied like the others (the GEMM works on 128-row tiles) and never read back: keep them finite
+  TTS_HIP(ctx, hipMemsetAsync(st->x.p, 0, (size_t)M * d * 4, ctx->stream));
+  TTS_HIP(ctx, hipMemsetAsync(st->y16.p, 0, (size_t)M * std::max(d, ff) * 2, ctx->stream));
+  TTS_HIP(ctx, hipMemsetAsync(st->att16.p, 0, (size_t)M * in * 2, ctx->stream));
+  TTS_HIP(ctx, hipMemsetAsync(st->u32.p, 0, (size_t)M * 2 * ff * 4, ctx->stream));
+  float *x = st->x.as<float>(), *u = st->u32.as<float>();
+  __half *y = st->y16.as<__half>(), *qkv = st->qkv16.as<__half>(), *att = st->att16.as<__half>();
+  clvp_embed_kernel<<<rows, 256, 0, ctx->stream>>>(st->emb[e], d_tok, d, x);
+  auto gemm = [&](const __half *A, int K, const __half *W, int N, const float *bias) {
+    GemmArgs g{};
+    for (int i = 0; i < 3; i++) { g.A[i] = A; g.row_off[i] = 0; }
+    g.nseg = 1; g.kseg = K; g.lda = K; g.W = W; g.M = M; g.N = N; g.bias = bias;
+    return g;
+  };
+  for (int i = 0; i < st->depth; i++) {
+    const ClvpLayer &l = st->L[e][i];
+    ProfScope ps(ctx, "clvp_layer", 2.0 * rows * ((double)d * 3 * in + (double)in * d + (double)d * 2 * ff + (double)ff * d));
+    clvp_rmsnorm_kernel<<<rows, 256, 0, ctx->stream>>>(x, l.g_attn, d, y);
+    { GemmArgs g = gemm(y, d, l.w_qkv, 3 * in, nullptr); g.mode = GEMM_OUT_F16; g.outH = qkv; g.ldh = 3 * in; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
+    clvp_attn_kernel<<<dim3(nseq, in / CLVP_DH, (maxlen + 255) / 256), 256, 0, ctx->stream>>>(qkv, d_start, d_len, in, att);
+    { GemmArgs g = gemm(att, in, l.w_out, d, l.b_out); g.mode = GEMM_OUT_F32; g.outF = x; g.ldo = d; g.resid = x; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
+    clvp_rmsnorm_kernel<<<rows, 256, 0, ctx->stream>>>(x, l.g_ff, d, y);
+    { GemmArgs g = gemm(y, d, l.w_ff1, 2 * ff, l.b_ff1); g.mode = GEMM_OUT_F32; g.outF = u; g.ldo = 2 * ff; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
+    clvp_geglu_kernel<<<rows, 256, 0, ctx->stream>>>(u, ff, y);
+    { GemmArgs g = gemm(y, ff, l.w_ff2, d, l.b_ff2); g.mode = GEMM_OUT_F32; g.outF = x; g.ldo = d; g.resid = x; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
+  }
+  clvp_pool_kernel<<<nseq, 256, 0, ctx->stream>>>(x, d_start, d_len, st->norm_w[e], st->norm_b[e], d, st->pooled.as<float>());
+  TTS_HIP(ctx, hipGetLastError());
+  std::vector<float> pooled((size_t)nseq * d);
+  TTS_HIP(ctx, hipMemcpyAsync(pooled.data(), st->pooled.p, pooled.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // latent projection (bias-free) + L2 normalisation on the host: nseq x latent x dim multiply-adds
+  lat_out.assign((size_t)nseq * st->latent, 0.f);
+  for (int s = 0; s < nseq; s++) {
+    double nn = 0;
+    std::vector<double> z(st->latent);
+    for (int o = 0; o < st->latent; o++) {
+      double a = 0;
+      const float *w = &st->proj[e][(size_t)o * d], *p = &pooled[(size_t)s * d];
+      for (int c = 0; c < d; c++) a += (double)w[c] * p[c];
+      z[o] = a; nn += a * a;
+    }
+    const double inv = 1.0 / std::max(std::sqrt(nn), 1e-12);
+    for (int o = 0; o < st->latent; o++) lat_out[(size_t)s * st->latent + o] = (float)(z[o] * inv);
+  }
+  return TTS_OK;
+}
+
+int clvp_score(tts_ctx *ctx, const int32_t *text_ids, int n_text, const int32_t *codes, const int32_t *code_len, int n_candidates, int code_stride,
+               float *scores_out) {
+  ClvpState *st = ctx->clvp;
+  if (!st) return fail(ctx, TTS_ERR_STATE, "tts_load_clvp not called");
+  if (n_text < 1 || n_candidates < 1 || !text_ids || !codes || !code_len || !scores_out) return fail(ctx, TTS_ERR_ARG, "tts_clvp_score: bad arguments");
+  std::vector<int> tt(text_ids, text_ids + n_text), tl{n_text}, st_tok, sl;
+  for (int t : tt)
+    if (t < 0 || t >= st->n_text) return fail(ctx, TTS_ERR_ARG, "text id %d out of range", t);
+  for (int c = 0; c < n_candidates; c++) {
+    if (code_len[c] < 1 || code_len[c] > code_stride) return fail(ctx, TTS_ERR_ARG, "candidate %d: %d codes (1 .. %d expected)", c, code_len[c], code_stride);
+    for (int j = 0; j < code_len[c]; j++) {
+      const int v = codes[(size_t)c * code_stride + j];
+      if (v < 0 || v >= st->n_speech) return fail(ctx, TTS_ERR_ARG, "candidate %d: mel code %d out of range (start / stop tokens are not scored)", c, v);
+      st_tok.push_back(v);
+    }
+    sl.push_back(code_len[c]);
+  }
+  std::vector<float> zt, zs;
+  int rc = clvp_encode(ctx, st, 0, tt, tl, zt);
+  if (rc) return rc;
+  if ((rc = clvp_encode(ctx, st, 1, st_tok, sl, zs))) return rc;
+  const double temp = std::exp((double)st->temperature);
+  for (int c = 0; c < n_candidates; c++) {
+    double a = 0;
+    for (int o = 0; o < st->latent; o++) a += (double)zt[o] * zs[(size_t)c * st->latent + o];
+    scores_out[c] = (float)(a * temp);
+  }
+  return TTS_OK;
+}
+
+} // namespace tts

@@ -164,6 +164,38 @@ def write_vocoder(path, seed=1236):
     w.close()
 
 
+CLVP_ENCODERS = ("text_transformer", "speech_transformer")
+
+
+def write_clvp(path, depth=20, dim=768, heads=12, ff_mult=2, seed=1237):
+    """ggml-clvp-model.bin: the CLVP re-ranker of upstream tortoise-tts (tortoise/models/clvp.py with use_xformers=True: two x-transformers
+    encoders of `depth` (attention, GEGLU feed-forward) pairs with RMSNorm pre-norm and rotary position embedding, masked mean, latent
+    projection, cosine similarity x exp(temperature)), tensor names = the upstream state dict's. The reference has no CLVP (main.cpp:6575
+    takes candidate 0): the container is this repository's, in the reference's file format."""
+    g = _Gen(seed)
+    w = GgmlWriter(path)
+    inner, ff = heads * 64, dim * ff_mult
+    w.add("text_emb.weight", g.normal((256, dim), 0.5))
+    w.add("speech_emb.weight", g.normal((8192, dim), 0.5))
+    w.add("to_text_latent.weight", g.lecun((dim, dim), dim))
+    w.add("to_speech_latent.weight", g.lecun((dim, dim), dim))
+    w.add("temperature", np.array([1.0], np.float32))
+    rs = 1.0 / np.sqrt(2.0 * depth)
+    for enc in CLVP_ENCODERS:
+        for i in range(depth):
+            a = "%s.transformer.attn_layers.layers.%d." % (enc, 2 * i)
+            f = "%s.transformer.attn_layers.layers.%d." % (enc, 2 * i + 1)
+            w.add(a + "0.g", g.gamma(dim))
+            for nm in ("to_q", "to_k", "to_v"):
+                w.add(a + "1.%s.weight" % nm, g.lecun((inner, dim), dim, 1.5))
+            w.add(a + "1.to_out.weight", g.lecun((dim, inner), inner, rs)); w.add(a + "1.to_out.bias", g.normal((dim,), 0.02))
+            w.add(f + "0.g", g.gamma(dim))
+            w.add(f + "1.net.0.proj.weight", g.lecun((2 * ff, dim), dim)); w.add(f + "1.net.0.proj.bias", g.normal((2 * ff,), 0.02))
+            w.add(f + "1.net.3.weight", g.lecun((dim, ff), ff, rs)); w.add(f + "1.net.3.bias", g.normal((dim,), 0.02))
+        w.add(enc + ".transformer.norm.weight", g.gamma(dim)); w.add(enc + ".transformer.norm.bias", g.beta(dim))
+    w.close()
+
+
 def write_all(out_dir, ar_layers=30, diff_main=10, diff_tail=3, diff_integ=3, diff_lc=4, seed=1234):
     import os
     os.makedirs(out_dir, exist_ok=True)
