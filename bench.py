@@ -200,6 +200,8 @@ def main():
     ap.add_argument("--no-ab", action="store_true", help="skip the extra pass that measures the other share_uncond setting")
     ap.add_argument("--no-diff-graph", action="store_true", help="A/B: launch every diffusion step eagerly instead of replaying the captured step graph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU plumbing test with --dry-engine)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (and run every collective of the N > 1 path) even for ONE rank: "
+                                                               "RCCL init, broadcast, all_gather, gather and all_reduce on a one-GPU box")
     ap.add_argument("--dry-engine", action="store_true", help="no device work: host-only contexts, fake stage outputs (tests of the launch / collective plumbing)")
     ap.add_argument("--models", default=None)
     ap.add_argument("--device-map", default=None, help="comma list: HIP device of each local rank (default: LOCAL_RANK). `--backend gloo --device-map 0,0` "
@@ -228,9 +230,12 @@ def main():
     dist = None
     dev = None
     collective_ranks = 1
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch
         import torch.distributed as dist
+        if a.force_dist and "RANK" not in os.environ:  # plain `python bench.py --force-dist`: a one-rank rendezvous of its own
+            s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_))
         if a.backend == "nccl":
             torch.cuda.set_device(device)
             dev = torch.device("cuda", device)
@@ -474,7 +479,8 @@ def main():
         "other_share_uncond_setting": other,
         "ar_weights_f16_option": f16,
         "ar_weights_fp8_option": fp8,
-        "collective_ranks": collective_ranks,
+        # the collective backend has seen this many ranks (all_reduce of ones) and rank 0 has gathered this many audio samples in the last pass
+        "collective_ranks": collective_ranks, "collective_backend": (a.backend if dist else None), "gathered_samples": shape.get("gathered_samples"),
         "roofline": {"kernel": "gemm_f16_vh_kernel + gemm_f16_conv3_vh_kernel (diffusion convs/projections)", "bound": "mfma",
                      "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
                      "traffic": traffic, "traffic_source": traffic_src, "launches_timed": int(g_n),

@@ -187,3 +187,20 @@ def test_cli_clvp_reranking_single_process_and_shards(small_models, tmp_path):
     for tag in ("one", "two"):
         a = audio[tag]
         assert a.shape == ref.shape and np.abs(a - ref).max() <= 1e-4 * max(1e-6, np.abs(ref).max()), tag
+
+
+def test_bench_rccl_one_rank():
+    """RCCL itself, on the one GPU the box has: `bench.py --force-dist` initialises torch.distributed with backend nccl (= RCCL) for a single
+    rank and runs every collective of the N > 1 path on the device — all_reduce (rank count), broadcast (prompt ids, voice), all_gather
+    (sizes), gather (audio), the timing all_reduces and the barrier. What a one-GPU box cannot show is xGMI traffic; what it does show is that
+    the RCCL code path of the bench initialises and completes on this software stack."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--quick", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-ab"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["collective_backend"] == "nccl" and out["collective_ranks"] == 1 and out["n_gpus"] == 1
+    assert out["gathered_samples"] and out["gathered_samples"] > 16 * 1000
+    assert out["value"] > 0
