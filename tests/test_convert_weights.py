@@ -89,3 +89,32 @@ def test_checkpoint_round_trip(small_models, tmp_path, oracle):
     a0 = oracle.Vocoder(oracle.Model(os.path.join(small_models, "ggml-vocoder-model.bin"))).run(mel, noise=nz)
     a1 = oracle.Vocoder(oracle.Model(os.path.join(out, "ggml-vocoder-model.bin"))).run(mel, noise=nz)
     assert np.abs(a0 - a1).max() <= 1e-3 * np.abs(a0).max()
+
+
+def test_clvp_checkpoint_round_trip(tmp_path, oracle):
+    """--clvp: a state dict shaped like upstream's clvp2.pth (0-dim temperature, rotary inv_freq buffers) -> the CLVP container; the
+    oracle scores identically from the original and the converted file; a checkpoint with foreign keys is refused."""
+    import tortoise_cpp_amd_loader
+    tortoise_cpp_amd_loader.load()
+    from tortoise_cpp_amd import synth_weights as sw
+    src = str(tmp_path / "src.bin")
+    sw.write_clvp(src, depth=2, seed=11)
+    sd = {k: torch.from_numpy(v) for k, v in sw.read_ggml(src).items()}
+    sd["temperature"] = sd["temperature"].reshape(())
+    for enc in sw.CLVP_ENCODERS:
+        sd[enc + ".transformer.attn_layers.rotary_pos_emb.inv_freq"] = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    torch.save(sd, str(tmp_path / "clvp2.pth"))
+    out = str(tmp_path / "out")
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "convert_weights.py"), "--clvp", str(tmp_path / "clvp2.pth"), "--out", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "2 encoder layers" in r.stdout, r.stdout + r.stderr
+    rs = np.random.RandomState(0)
+    text, sp = rs.randint(0, 256, 12), [rs.randint(0, 8192, n) for n in (9, 21)]
+    a = oracle.Clvp(oracle.Model(src)).score(text, sp)
+    b = oracle.Clvp(oracle.Model(out + "/ggml-clvp-model.bin")).score(text, sp)
+    assert (a == b).all()
+    sd["text_pos_emb.weight"] = torch.zeros(4, 4)  # the non-xformers CLVP flavour
+    torch.save(sd, str(tmp_path / "other.pth"))
+    cmd[cmd.index("--clvp") + 1] = str(tmp_path / "other.pth")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "unexpected tensor" in r.stdout + r.stderr

@@ -166,6 +166,28 @@ def convert_vocoder(sd, path):
     return i
 
 
+def convert_clvp(sd, path):
+    """ggml-clvp-model.bin for tts_load_clvp: upstream tortoise-tts CLVP (clvp2.pth, use_xformers=True), tensors under their state-dict names.
+    Kept: embeddings, latent projections, temperature (0-dim -> [1]), every `*.attn_layers.layers.N.{0.g, 1.*}` parameter and the final norms;
+    the rotary inv_freq buffers are recomputed by the loader (kept if present); anything else (e.g. positional embeddings of the non-xformers
+    variant) is an error, so that a checkpoint of the other CLVP flavour is not silently mis-read."""
+    w = GgmlWriter(path)
+    depth = 0
+    for k in sorted(sd):
+        v = _np(sd[k])
+        known = (k in ("text_emb.weight", "speech_emb.weight", "to_text_latent.weight", "to_speech_latent.weight", "temperature")
+                 or ".attn_layers.layers." in k or k.endswith((".transformer.norm.weight", ".transformer.norm.bias", "rotary_pos_emb.inv_freq")))
+        if not known:
+            raise SystemExit("convert_clvp: unexpected tensor '%s' (not the use_xformers=True CLVP of tortoise-tts?)" % k)
+        if k == "temperature":
+            v = v.reshape(1)
+        if k.startswith("text_transformer.") and k.endswith(".0.g"):
+            depth += 1
+        w.add(k, v)
+    w.close()
+    return depth // 2
+
+
 def main():
     import torch
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
@@ -173,6 +195,7 @@ def main():
     ap.add_argument("--diffusion")
     ap.add_argument("--diffusion-conditioning-latent", help=".pth / .npy / raw f32 file holding the voice's [1, 2048] diffusion conditioning latent")
     ap.add_argument("--vocoder")
+    ap.add_argument("--clvp", help="clvp2.pth of upstream tortoise-tts -> ggml-clvp-model.bin (candidate re-ranking, tts_load_clvp; not in the reference)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
@@ -186,6 +209,8 @@ def main():
         lat = np.load(p) if p.endswith(".npy") else load(p) if p.endswith((".pth", ".pt")) else np.fromfile(p, np.float32)
         print("ggml-diffusion-model.bin: blocks (latent conditioner, integrator, main, tail) = %s"
               % (convert_diffusion(load(a.diffusion), lat, os.path.join(a.out, "ggml-diffusion-model.bin")),))
+    if a.clvp:
+        print("ggml-clvp-model.bin: %d encoder layers" % convert_clvp(load(a.clvp), os.path.join(a.out, "ggml-clvp-model.bin")))
     if a.vocoder:
         print("ggml-vocoder-model.bin: %d res stacks" % convert_vocoder(load(a.vocoder), os.path.join(a.out, "ggml-vocoder-model.bin")))
 
