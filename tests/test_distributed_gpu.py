@@ -204,3 +204,46 @@ def test_bench_rccl_one_rank():
     assert out["collective_backend"] == "nccl" and out["collective_ranks"] == 1 and out["n_gpus"] == 1
     assert out["gathered_samples"] and out["gathered_samples"] > 16 * 1000
     assert out["value"] > 0
+
+
+def test_cli_rccl_exchange_one_worker(small_models, tmp_path):
+    """`tortoise --exchange rccl`: the worker processes form an RCCL communicator (csrc/cli_rccl.h: librccl.so through dlopen) — rank 0
+    broadcasts the conditioning, sizes / CLVP scores are all-gathered, the audio is sent to rank 0, which writes every WAV. The GPU box has
+    one device and RCCL wants a distinct GPU per rank, so what runs here is ONE worker: communicator init from the parent's unique id,
+    broadcast, all-gather, the rank-0 writer — and the files must be the plain run's."""
+    import re
+    import shutil
+    exe = os.path.join(ROOT, "tortoise.cpp_amd", "tortoise")
+    if not os.path.exists(exe):
+        pytest.skip("CLI binary not built")
+    from tortoise_cpp_amd import synth_weights as sw
+    d = tmp_path / "models"
+    d.mkdir()
+    for f in ("ggml-model.bin", "ggml-diffusion-model.bin", "ggml-vocoder-model.bin"):
+        os.symlink(os.path.join(small_models, f), d / f)
+    shutil.copy(os.path.join(ROOT, "models", "tokenizer.json"), d / "tokenizer.json")
+    clvp = str(tmp_path / "ggml-clvp-model.bin")
+    sw.write_clvp(clvp, depth=2, seed=5)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base = [exe, "--models", str(d), "--message", "this is a test message.", "--voice", os.path.join(ROOT, "models", "mol.bin"), "--seed", "3",
+            "--codes", "16", "--steps", "4", "--candidates", "2"]
+    for tag, extra in (("plain", []), ("rccl", ["--devices", "1", "--exchange", "rccl"])):
+        r = subprocess.run(base + ["--output", str(tmp_path / (tag + ".wav"))] + extra, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+    for suffix in ("", ".1.wav"):
+        a, b = (tmp_path / ("plain.wav" + suffix)).read_bytes(), (tmp_path / ("rccl.wav" + suffix)).read_bytes()
+        assert a == b, suffix
+    kept = {}
+    for tag, extra in (("plainc", []), ("rcclc", ["--devices", "1", "--exchange", "rccl"])):
+        r = subprocess.run(base + ["--clvp", clvp, "--output", str(tmp_path / (tag + ".wav"))] + extra, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        kept[tag] = re.findall(r"clvp: candidate (\d+) kept", r.stdout)[-1]
+    assert kept["plainc"] == kept["rcclc"]
+    assert (tmp_path / "plainc.wav").read_bytes() == (tmp_path / "rcclc.wav").read_bytes()
+    # an unknown exchange is an error; two workers on ONE device cannot form an RCCL communicator and say so instead of hanging
+    r = subprocess.run(base + ["--output", str(tmp_path / "x.wav"), "--exchange", "mpi"], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode != 0 and "files or rccl" in r.stderr
+    r = subprocess.run(base + ["--output", str(tmp_path / "y.wav"), "--devices", "2", "--device-map", "0,0", "--exchange", "rccl"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0

@@ -18,9 +18,13 @@
 //   (one process per device, replicated weights); worker r takes candidates [r B/N, (r+1) B/N) of the ONE batch: the RNG stream
 //   partition (options rng_shard_offset / rng_shard_total) makes the N x B/N codes identical to a single-GPU run of B candidates,
 //   device noise is keyed by the global candidate id, and the throughput stop rule (TTS_AR_RETIRE) needs no per-step exchange.
-//   Nothing is exchanged between workers — candidates never interact — each writes its own candidates' WAV files
-//   (<output> for candidate 0, <output>.<c>.wav for the others, c = global candidate index).
+//   --exchange files (default): nothing is exchanged between workers — candidates never interact — each writes its own candidates' WAV
+//   files (<output> for candidate 0, <output>.<c>.wav for the others, c = global candidate index).
+//   --exchange rccl: the workers form one RCCL communicator (cli_rccl.h; distinct GPUs per worker): rank 0 broadcasts the conditioning
+//   (text ids + voice latent), the result sizes / CLVP scores are all-gathered, the audio is sent to rank 0, which writes every WAV file.
 #include "tortoise_mi355x.h"
+#include "cli_rccl.h"
+#include <csignal>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -43,7 +47,7 @@ int main(int argc, char **argv) {
   std::string modelsDir = "../models";
   bool have_seed = false;
   int seed = 0, candidates = 1, steps = 80, device = 0, fixed_codes = 0, devices = 1, shard = -1, nshards = 1;
-  std::string device_map, clvpPath;
+  std::string device_map, clvpPath, exchange = "files", rccl_id;
   for (int i = 1; i < argc - 1; ++i) {
     std::string a(argv[i]);
     if (a == "--voice") voicePath = argv[i + 1];
@@ -58,13 +62,16 @@ int main(int argc, char **argv) {
     else if (a == "--devices") devices = std::stoi(argv[i + 1]);
     else if (a == "--device-map") device_map = argv[i + 1];
     else if (a == "--clvp") clvpPath = argv[i + 1];
+    else if (a == "--exchange") exchange = argv[i + 1];
+    else if (a == "--rccl-id") rccl_id = argv[i + 1]; // worker mode (set by the parent)
     else if (a == "--shard") { // worker mode (set by the parent): "r/N"
       std::string v(argv[i + 1]);
       const size_t sl = v.find('/');
       if (sl != std::string::npos) { shard = std::stoi(v.substr(0, sl)); nshards = std::stoi(v.substr(sl + 1)); }
     }
   }
-  if (devices > 1 && shard < 0) { // parent: one worker process per GPU
+  if (exchange != "files" && exchange != "rccl") { fprintf(stderr, "--exchange %s: files or rccl\n", exchange.c_str()); return 1; }
+  if ((devices > 1 || exchange == "rccl") && shard < 0) { // parent: one worker process per GPU
     if (candidates % devices) { fprintf(stderr, "--candidates %d does not divide over --devices %d\n", candidates, devices); return 1; }
     std::vector<int> map;
     for (size_t p = 0; p < device_map.size();) {
@@ -75,6 +82,15 @@ int main(int argc, char **argv) {
     }
     if (!have_seed) // every worker must draw from the same stream
       seed = (int)(std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count() & 0x7fffffff);
+    std::string id_hex;
+    if (exchange == "rccl") { // the communicator's id is created here and handed to every worker
+      RcclApi api;
+      ncclUniqueId id;
+      if (!api.open()) return 1;
+      const ncclResult_t rr = api.GetUniqueId(&id);
+      if (rr != ncclSuccess) { fprintf(stderr, "ncclGetUniqueId: %s\n", api.GetErrorString(rr)); return 1; }
+      id_hex = rccl_id_to_hex(id);
+    }
     std::vector<pid_t> pids;
     for (int r = 0; r < devices; r++) {
       const pid_t pid = fork();
@@ -83,6 +99,7 @@ int main(int argc, char **argv) {
         std::vector<std::string> args(argv, argv + argc);
         const std::string extra[] = {"--shard", std::to_string(r) + "/" + std::to_string(devices), "--device",
                                      std::to_string(r < (int)map.size() ? map[r] : r), "--seed", std::to_string(seed), "--end", "-"};
+        if (!id_hex.empty()) { args.push_back("--rccl-id"); args.push_back(id_hex); }
         args.insert(args.end(), std::begin(extra), std::end(extra)); // later flags override earlier ones; "--end -" keeps the last pair inside i < argc-1
         std::vector<char *> av;
         for (auto &x : args) av.push_back(&x[0]);
@@ -94,11 +111,16 @@ int main(int argc, char **argv) {
       pids.push_back(pid);
     }
     int rc = 0;
-    for (pid_t pid : pids) {
+    for (size_t left = pids.size(); left > 0; left--) {
       int st = 0;
-      if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1;
+      const pid_t pid = wait(&st);
+      if (pid < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+        if (rc == 0 && exchange == "rccl")  // the other workers would wait in a collective for ever
+          for (pid_t p : pids) if (p != pid) kill(p, SIGTERM);
+        rc = 1;
+      }
     }
-    if (rc == 0 && !clvpPath.empty()) { // every worker left "<output>.shard<r>.score" = "<global candidate> <score>" and that candidate's WAV
+    if (rc == 0 && !clvpPath.empty() && exchange == "files") { // every worker left "<output>.shard<r>.score" = "<global candidate> <score>" and that candidate's WAV
       int best_gc = -1;
       double best_score = 0;
       std::vector<int> winners;
@@ -144,6 +166,19 @@ int main(int argc, char **argv) {
     std::ifstream f(voicePath, std::ios::binary);
     if (!f) { std::cerr << "Error: Unable to open file " << voicePath << std::endl; return 1; }
     f.read((char *)voice.data(), 1024 * sizeof(float));
+  }
+  RcclWorld world;
+  const bool use_rccl = shard >= 0 && !rccl_id.empty();
+  if (use_rccl) {
+    if (!world.init(rccl_id, shard, nshards)) { fprintf(stderr, "rccl: %s\n", world.err.c_str()); return 1; }
+    // conditioning from rank 0: number of text ids, the ids, the voice latent (what SURVEY 8e's ncclBroadcast carries)
+    struct { int32_t n; int32_t ids[4096]; float voice[1024]; } cond;
+    memset(&cond, 0, sizeof cond);
+    if (shard == 0) { cond.n = n; memcpy(cond.ids, tokens.data(), (size_t)n * 4); memcpy(cond.voice, voice.data(), 4096); }
+    if (!world.broadcast(&cond, sizeof cond, 0)) { fprintf(stderr, "rccl: %s\n", world.err.c_str()); return 1; }
+    n = cond.n;
+    tokens.assign(cond.ids, cond.ids + n);
+    memcpy(voice.data(), cond.voice, 4096);
   }
   if (tts_load_ar(ctx, (modelsDir + "/ggml-model.bin").c_str())) return die(ctx, "autoregressive_model_load");
   const int B_ar = candidates;
@@ -206,23 +241,62 @@ int main(int argc, char **argv) {
   if (tts_diffusion(ctx, lat_in, rows.data(), B, steps, nullptr, noise_mode, mel.data())) return die(ctx, "diffusion");
   if (tts_load_vocoder(ctx, (modelsDir + "/ggml-vocoder-model.bin").c_str())) return die(ctx, "vocoder_model_load");
   if (tts_vocoder(ctx, mel.data(), frames.data(), B, nullptr, noise_mode, audio.data())) return die(ctx, "vocoder");
-  size_t off = 0;
-  for (int c = 0; c < B; c++) {
-    size_t ns = (size_t)tts_vocoder_samples(frames[c]);
-    const int gc = kept_gc >= 0 ? kept_gc : (shard >= 0 ? shard * B_ar : 0) + c; // global candidate index
-    // the re-ranked winner of a single process IS the output; a worker's winner waits for the parent's pick under its candidate name
-    const bool is_output = kept_gc >= 0 ? shard < 0 : gc == 0;
-    std::string path = is_output ? outputPath : outputPath + "." + std::to_string(gc) + ".wav";
-    if (tts_write_wav(path.c_str(), audio.data() + off, (int64_t)ns, 24000)) {
-      std::cerr << "Error opening output file." << std::endl;
-    } else if (is_output) {
-      std::cout << "WAV file saved successfully. :^)" << std::endl;
+  auto write_one = [&](const float *samples, int64_t ns, int gc, bool is_output) {
+    const std::string path = is_output ? outputPath : outputPath + "." + std::to_string(gc) + ".wav";
+    if (tts_write_wav(path.c_str(), samples, ns, 24000)) std::cerr << "Error opening output file." << std::endl;
+    else if (is_output) std::cout << "WAV file saved successfully. :^)" << std::endl;
+  };
+  if (use_rccl) {
+    auto bail = [&]() { fprintf(stderr, "rccl: %s\n", world.err.c_str()); return 1; };
+    std::vector<char> g;
+    if (kept_gc >= 0) { // every rank's winner: (score, global candidate, samples); the best one's audio goes to rank 0
+      const double mine[3] = {kept_score, (double)kept_gc, (double)audio.size()};
+      if (!world.all_gather(mine, sizeof mine, g)) return bail();
+      const double *all = (const double *)g.data();
+      int win = 0;
+      for (int r = 1; r < nshards; r++)
+        if (all[3 * r] > all[3 * win]) win = r;
+      std::vector<int64_t> counts(nshards);
+      for (int r = 0; r < nshards; r++) counts[r] = (int64_t)all[3 * r + 2];
+      std::vector<float> got;
+      if (!world.send_floats(audio.data(), counts, win, 0, got)) return bail();
+      if (shard == 0) {
+        printf("clvp: candidate %d kept (score %.5f)\n", (int)all[3 * win + 1], all[3 * win]);
+        write_one(got.data(), (int64_t)got.size(), (int)all[3 * win + 1], true);
+      }
+    } else { // all candidates of all ranks: rank 0 writes <output> (candidate 0) and <output>.<c>.wav
+      std::vector<int32_t> fr(frames.begin(), frames.end());
+      if (!world.all_gather(fr.data(), (size_t)B * 4, g)) return bail();
+      const int32_t *allf = (const int32_t *)g.data();
+      std::vector<int64_t> counts(nshards, 0);
+      for (int r = 0; r < nshards; r++)
+        for (int c = 0; c < B; c++) counts[r] += tts_vocoder_samples(allf[r * B + c]);
+      for (int r = 0; r < nshards; r++) {
+        std::vector<float> got;
+        if (!world.send_floats(audio.data(), counts, r, 0, got)) return bail();
+        if (shard == 0) {
+          size_t off = 0;
+          for (int c = 0; c < B; c++) {
+            const int64_t ns = tts_vocoder_samples(allf[r * B + c]);
+            write_one(got.data() + off, ns, r * B + c, r * B + c == 0);
+            off += (size_t)ns;
+          }
+        }
+      }
     }
-    off += ns;
-  }
-  if (kept_gc >= 0 && shard >= 0) {
-    std::ofstream f(outputPath + ".shard" + std::to_string(shard) + ".score");
-    f << kept_gc << " " << kept_score << "\n";
+  } else {
+    size_t off = 0;
+    for (int c = 0; c < B; c++) {
+      size_t ns = (size_t)tts_vocoder_samples(frames[c]);
+      const int gc = kept_gc >= 0 ? kept_gc : (shard >= 0 ? shard * B_ar : 0) + c; // global candidate index
+      // the re-ranked winner of a single process IS the output; a worker's winner waits for the parent's pick under its candidate name
+      write_one(audio.data() + off, (int64_t)ns, gc, kept_gc >= 0 ? shard < 0 : gc == 0);
+      off += ns;
+    }
+    if (kept_gc >= 0 && shard >= 0) {
+      std::ofstream f(outputPath + ".shard" + std::to_string(shard) + ".score");
+      f << kept_gc << " " << kept_score << "\n";
+    }
   }
   tts_destroy(ctx);
   return 0;
