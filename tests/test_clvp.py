@@ -62,6 +62,15 @@ def test_clvp_engine_vs_oracle(pkg, oracle, clvp_models, which):
     # a candidate's score does not depend on who shares the batch
     solo = e.clvp_score(text, [sp[1]])
     assert abs(float(solo[0]) - float(got[1])) < 1e-6
+    if which == "full":  # the bench's shape: 16 candidates x 200 codes against a 66-id prompt (printed for DESIGN.md section 3; no gate)
+        import time
+        rs = np.random.RandomState(9)
+        t66, c16 = rs.randint(0, 256, 66).astype(np.int32), [rs.randint(0, 8192, 200).astype(np.int32) for _ in range(16)]
+        e.clvp_score(t66, c16)
+        t0 = time.time()
+        for _ in range(3):
+            e.clvp_score(t66, c16)
+        print("CLVP re-ranking of 16 candidates x 200 codes, depth 20: %.1f ms per call" % ((time.time() - t0) / 3 * 1e3))
     e.close()
 
 
