@@ -842,9 +842,11 @@ template <int NT, int NJ>
 __global__ __launch_bounds__(NT) void gn_reg_kernel(int getenv_gn_xcd, const float *__restrict__ x, const int *__restrict__ seq_start,
                                                     const int *__restrict__ seq_len, int rows_total, int ns, float eps,
                                                     const float *__restrict__ g, const float *__restrict__ b,
-                                                    const float *__restrict__ ss, int do_silu, int lut, __half *__restrict__ y) {
+                                                    const float *__restrict__ ss, int do_silu, int lut, __half *__restrict__ y,
+                                                    const char *__restrict__ pf0, int pf0_lines, const char *__restrict__ pf1, int pf1_lines) {
   constexpr int NW = NT / 64, SWEEP = NT / 8;
   __shared__ float sh[2][NW];
+  __shared__ unsigned pf_sink[NW][64]; // landing zone of the weight touch below
   // workgroup b runs on XCD b % 8: give each XCD whole sequences (all 32 groups of a row = the full 4 KB row go
   // through one L2) instead of 128-byte slices of every row
   int grp = blockIdx.x, s = blockIdx.y;
@@ -861,6 +863,17 @@ __global__ __launch_bounds__(NT) void gn_reg_kernel(int getenv_gn_xcd, const flo
   for (int j = 0; j < NJ; j++) {
     const int t = t0 + j * SWEEP;
     v[j] = *(const float4 *)(base + (size_t)min(t, T - 1) * C); // clamped rows are masked out of the sums below
+  }
+  // Weight touch for the GEMM(s) that consume this kernel's output: one dword of every 128-byte line of their weight matrices, spread
+  // over all threads of the launch, requested right behind the slab (LDS-DMA into a sink: no register is waiting for the data). The
+  // 0.36 GB of fp16 weights cycle through the 256 MB memory-side cache once per sampling step, so without it every K tile of the next
+  // GEMM is a miss to HBM for all of its workgroups at once (they walk K in lockstep): a k = 1 GEMM of one utterance takes 24 us with
+  // cold weights against 14 us when they sit in the memory-side cache (profiles/r2_gemm_small_problems.txt, round-3 addendum).
+  {
+    const int gi = (blockIdx.y * 32 + blockIdx.x) * NT + threadIdx.x, tt = 32 * ns * NT;
+    unsigned *sink = &pf_sink[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0];
+    for (int l = gi; l < pf0_lines; l += tt) __builtin_amdgcn_global_load_lds((gptr_t)(pf0 + (size_t)l * 128), (lptr_t)sink, 4, 0, 0);
+    for (int l = gi; l < pf1_lines; l += tt) __builtin_amdgcn_global_load_lds((gptr_t)(pf1 + (size_t)l * 128), (lptr_t)sink, 4, 0, 0);
   }
   const float4 gg = *(const float4 *)(g + c), bb = *(const float4 *)(b + c);
   float sc4[4] = {1.f, 1.f, 1.f, 1.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -930,15 +943,22 @@ __global__ __launch_bounds__(NT) void gn_reg_kernel(int getenv_gn_xcd, const flo
   for (int r = r0 + T + t0; r < gend; r += SWEEP) *(uint2 *)(y + (size_t)r * C + c) = make_uint2(0u, 0u);
   if (s == 0)
     for (int r = t0; r < r0; r += SWEEP) *(uint2 *)(y + (size_t)r * C + c) = make_uint2(0u, 0u);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the sink belongs to this workgroup until its last weight touch has landed
 }
 
-// stats + apply in one launch (see gn_fused_kernel)
+// stats + apply in one launch (see gn_fused_kernel). wa / wb: weight matrices (bytes) of the GEMMs that follow, touched into the
+// memory-side cache by the register-resident kernel (see there); nullptr / 0: none.
 static int gn_fused(tts_ctx *ctx, const Layout &lay, const float *x, const float *g, const float *b, const float *ss, int do_silu,
-                    __half *y) {
+                    __half *y, const void *wa = nullptr, size_t wa_bytes = 0, const void *wb = nullptr, size_t wb_bytes = 0) {
   ProfScope ps(ctx, "diff_gn_fused");
   const int tmax = lay.max_len();
   static const int gn_xcd = getenv("TTS_GN_NOXCD") ? 0 : 1; // A/B switch
-#define GN_ARGS gn_xcd, x, lay.d_start.as<int>(), lay.d_len.as<int>(), lay.rows, lay.ns, ctx->gn_eps, g, b, ss, do_silu, ctx->ggml_lut, y
+  // measured (tools/gn_touch_ab.sh): one utterance 165.2 -> 156.6 ms per diffusion stage with the touch; the 16-candidate batch 864.8 -> 874.0 ms
+  // (its GEMMs re-use every weight line from thousands of tiles: the touch only adds requests) -> small problems only
+  static const bool touch = getenv("TTS_GN_NOTOUCH") == nullptr; // A/B switch
+  if (!touch || lay.rows > 4096) { wa_bytes = 0; wb_bytes = 0; }
+#define GN_ARGS gn_xcd, x, lay.d_start.as<int>(), lay.d_len.as<int>(), lay.rows, lay.ns, ctx->gn_eps, g, b, ss, do_silu, ctx->ggml_lut, y, \
+                (const char *)wa, (int)(wa_bytes >> 7), (const char *)wb, (int)(wb_bytes >> 7)
   if (tmax <= 14 * 64) gn_reg_kernel<512, 14><<<dim3(32, lay.ns), 512, 0, ctx->stream>>>(GN_ARGS);
   else if (tmax <= 18 * 128) gn_reg_kernel<1024, 18><<<dim3(32, lay.ns), 1024, 0, ctx->stream>>>(GN_ARGS);
   else gn_fused_kernel<0><<<dim3(32, lay.ns), 256, 0, ctx->stream>>>(x, lay.d_start.as<int>(), lay.d_len.as<int>(), lay.rows, lay.ns, ctx->gn_eps, g, b, ss,
@@ -950,7 +970,7 @@ static int gn_fused(tts_ctx *ctx, const Layout &lay, const float *x, const float
 
 // in_layers of a ResBlock (GroupNorm, SiLU, conv k=1): H = conv(silu(gn(x))). No timestep dependence.
 static int res_in_layers(tts_ctx *ctx, const Layout &lay, Work &wk, const float *x, const ResDev &w, float *H) {
-  CHECK(gn_fused(ctx, lay, x, w.in_g, w.in_b, nullptr, 1, wk.A16()));
+  CHECK(gn_fused(ctx, lay, x, w.in_g, w.in_b, nullptr, 1, wk.A16(), w.in_w, (size_t)C * C * 2));
   GemmArgs g = gemm_base(lay, wk.A16(), C, 1, C, w.in_w, C, w.in_bias);
   g.mode = GEMM_OUT_F32; g.outF = H; g.ldo = C; g.resid = nullptr;
   return gemm(ctx, "diff_gemm", g, lay);
@@ -958,7 +978,7 @@ static int res_in_layers(tts_ctx *ctx, const Layout &lay, Work &wk, const float 
 
 // AttentionBlock on X (in place).
 static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, float *X, const AttnDev &w) {
-  CHECK(gn_fused(ctx, lay, X, w.norm_g, w.norm_b, nullptr, 0, wk.A16()));
+  CHECK(gn_fused(ctx, lay, X, w.norm_g, w.norm_b, nullptr, 0, wk.A16(), w.qkv_w, (size_t)3 * C * C * 2, w.proj_w, (size_t)C * C * 2));
   GemmArgs g = gemm_base(lay, wk.A16(), C, 1, C, w.qkv_w, 3 * C, w.qkv_b);
   g.mode = GEMM_OUT_QKV; g.outH = wk.qk16.as<__half>(); g.ldh = 2048; g.outVt = wk.vt16.as<__half>(); g.ldvt = wk.rows + 128;
   CHECK(gemm(ctx, "diff_gemm", g, lay));
@@ -991,7 +1011,7 @@ static int res_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, f
     CHECK(res_in_layers(ctx, lay, wk, xin, w, wk.H()));
     Hpre = wk.H();
   }
-  CHECK(gn_fused(ctx, lay, Hpre, w.out_g, w.out_b, ss, 1, wk.A16()));
+  CHECK(gn_fused(ctx, lay, Hpre, w.out_g, w.out_b, ss, 1, wk.A16(), w.out_w, (size_t)3 * C * C * 2));
   GemmArgs c3 = gemm_base(lay, wk.A16(), C, 3, C, w.out_w, C, w.out_bias);
   c3.mode = GEMM_OUT_F32; c3.outF = X; c3.ldo = C; c3.resid = xin;
   return gemm(ctx, "diff_gemm", c3, lay);
