@@ -943,7 +943,7 @@ __global__ __launch_bounds__(NT) void gn_reg_kernel(int getenv_gn_xcd, const flo
   for (int r = r0 + T + t0; r < gend; r += SWEEP) *(uint2 *)(y + (size_t)r * C + c) = make_uint2(0u, 0u);
   if (s == 0)
     for (int r = t0; r < r0; r += SWEEP) *(uint2 *)(y + (size_t)r * C + c) = make_uint2(0u, 0u);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the sink belongs to this workgroup until its last weight touch has landed
+  if (pf0_lines | pf1_lines) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the sink belongs to this workgroup until its last weight touch has landed
 }
 
 // stats + apply in one launch (see gn_fused_kernel). wa / wb: weight matrices (bytes) of the GEMMs that follow, touched into the
