@@ -85,6 +85,14 @@ int tts_load_vocoder(tts_ctx *ctx, const char *path);
  * scores every candidate's codes against the text with CLVP (tortoise/models/clvp.py, use_xformers=True) and keeps the best.
  * File: the reference's container format, tensor names of the upstream state dict (tortoise.cpp_amd/synth_weights.py: write_clvp). */
 int tts_load_clvp(tts_ctx *ctx, const char *path);
+/* Voice-conditioning encoder. NOT in the reference, which reads the finished 1024-float latent from --voice
+ * (main.cpp:5179-5184; README.md:54-72 is an offline PyTorch recipe): upstream tortoise-tts' UnifiedVoice.get_conditioning =
+ * ConditioningEncoder(80 mel bands -> 1024, 6 attention blocks, 16 heads), position 0 of every clip, mean over the clips.
+ * File: the reference's container format with the upstream state dict's `conditioning_encoder.*` tensors (tools/convert_weights.py
+ * --conditioning-encoder). tts_voice_latent: mel = the clips' 80-band log-mel spectrograms [80][frames[c]] one after the other (the audio
+ * front-end — STFT, mel filterbank, normalisation — stays with the caller); out1024 = what a --voice file holds. */
+int tts_load_voice_encoder(tts_ctx *ctx, const char *path);
+int tts_voice_latent(tts_ctx *ctx, const float *mel, const int32_t *frames, int n_clips, float *out1024);
 int tts_ar_layers(const tts_ctx *ctx);
 int tts_diffusion_layers(const tts_ctx *ctx);
 

@@ -410,6 +410,48 @@ class Clvp:
         return np.array([float((zt * self.latent(1, sp)).sum()) * t for sp in speech_list])
 
 
+class VoiceEncoder:
+    """Voice-conditioning encoder, numpy restatement of UPSTREAM tortoise-tts (tortoise/models/autoregressive.py:
+    UnifiedVoice.get_conditioning -> ConditioningEncoder(80, 1024, 6 blocks, 16 heads); arch_util.py: AttentionBlock = GroupNorm(32, eps 1e-5)
+    -> Conv1d qkv (k = 1) -> QKVAttentionLegacy (channel = head * 192 + {q, k, v}, both q and k scaled by 64^-1/4) -> Conv1d proj_out -> + x;
+    output = position 0 of every clip, mean over the clips). The reference only READS the finished 1024-float latent (main.cpp:5179-5184),
+    so there is nothing in it to cite or to pin against: PARITY UNPINNED, pinned against the torch restatement (tests/torch_ref.py)."""
+
+    def __init__(self, model, dtype=np.float32):
+        self.m, self.dt, self.blocks = model, dtype, 0
+        while True:
+            try:
+                model.tensor("conditioning_encoder.attn.%d.norm.weight" % self.blocks)
+            except KeyError:
+                break
+            self.blocks += 1
+
+    def _t(self, name, *shape):
+        return self.m.tensor(name).reshape(shape).astype(self.dt)
+
+    def clip(self, mel):  # [80, T] -> [1024]
+        D, H = 1024, 16
+        x = np.asarray(mel, self.dt).T  # [T, 80]
+        T = x.shape[0]
+        h = x @ self._t("conditioning_encoder.init.weight", D, 80).T + self._t("conditioning_encoder.init.bias", D)
+        for i in range(self.blocks):
+            p = "conditioning_encoder.attn.%d." % i
+            g = h.reshape(T, 32, 32)
+            mu = g.mean(axis=(0, 2), keepdims=True)
+            var = ((g - mu) ** 2).mean(axis=(0, 2), keepdims=True)
+            y = ((g - mu) / np.sqrt(var + self.dt(1e-5))).reshape(T, D) * self._t(p + "norm.weight", D) + self._t(p + "norm.bias", D)
+            qkv = (y @ self._t(p + "qkv.weight", 3 * D, D).T + self._t(p + "qkv.bias", 3 * D)).reshape(T, H, 3, 64)
+            q, k, v = (qkv[:, :, j].transpose(1, 0, 2) for j in range(3))  # [H, T, 64]
+            sc = (q * self.dt(64 ** -0.25)) @ (k * self.dt(64 ** -0.25)).transpose(0, 2, 1)
+            sc = np.exp(sc - sc.max(-1, keepdims=True))
+            a = ((sc / sc.sum(-1, keepdims=True)) @ v).transpose(1, 0, 2).reshape(T, D)
+            h = h + a @ self._t(p + "proj_out.weight", D, D).T + self._t(p + "proj_out.bias", D)
+        return h[0]
+
+    def latent(self, mels):
+        return np.mean([self.clip(m).astype(np.float64) for m in mels], axis=0)
+
+
 def ref():
     global _ref
     if _ref is None:

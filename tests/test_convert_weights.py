@@ -118,3 +118,28 @@ def test_clvp_checkpoint_round_trip(tmp_path, oracle):
     cmd[cmd.index("--clvp") + 1] = str(tmp_path / "other.pth")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "unexpected tensor" in r.stdout + r.stderr
+
+
+def test_conditioning_encoder_from_the_ar_checkpoint(small_models, tmp_path, oracle):
+    """--conditioning-encoder: the conditioning_encoder.* tensors that ride in upstream's autoregressive.pth (and that the reference's
+    ggml-model.bin leaves out) become ggml-conditioning-model.bin; the oracle computes the same voice latent from the converted file."""
+    import tortoise_cpp_amd_loader
+    tortoise_cpp_amd_loader.load()
+    from tortoise_cpp_amd import synth_weights as sw
+    src = str(tmp_path / "venc.bin")
+    sw.write_voice_encoder(src, blocks=2, seed=3)
+    ar = sw.read_ggml(os.path.join(small_models, "ggml-model.bin"))
+    sd = {(k.replace("inference_model.transformer.h.", "gpt.h.").replace("inference_model.transformer.ln_f.", "gpt.ln_f.")
+            .replace("inference_model.lm_head.0.", "final_norm.").replace("inference_model.lm_head.1.", "mel_head.")): torch.from_numpy(v) for k, v in ar.items()}
+    sd.update({k: torch.from_numpy(v) for k, v in sw.read_ggml(src).items()})
+    torch.save(sd, str(tmp_path / "autoregressive.pth"))
+    out = str(tmp_path / "out")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "convert_weights.py"), "--ar", str(tmp_path / "autoregressive.pth"),
+                        "--conditioning-encoder", "--out", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "2 attention blocks" in r.stdout, r.stdout + r.stderr
+    got = sw.read_ggml(out + "/ggml-model.bin")
+    assert sorted(got) == sorted(ar)  # the AR container is unchanged by the extra tensors
+    mels = [np.random.RandomState(1).randn(80, 21).astype(np.float32)]
+    a = oracle.VoiceEncoder(oracle.Model(src)).latent(mels)
+    b = oracle.VoiceEncoder(oracle.Model(out + "/ggml-conditioning-model.bin")).latent(mels)
+    assert (a == b).all()

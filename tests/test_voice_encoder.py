@@ -1,0 +1,73 @@
+"""Voice-conditioning encoder: 80-band mel of the reference clips -> the 1024-float latent a --voice file holds.
+The reference only reads the finished latent (main.cpp:5179-5184; README.md:54-72 is an offline PyTorch recipe), so, as for CLVP, the chain is
+  torch restatement of upstream tortoise-tts (tests/torch_ref.py: TorchVoiceEncoder, f64)  ==  numpy oracle (oracle.VoiceEncoder)  [CPU]
+  numpy oracle  ~  HIP engine (tts_load_voice_encoder / tts_voice_latent) on synthetic weights                                   [GPU]
+— parity UNPINNED against upstream weights. The audio front-end (STFT, mel filterbank, normalisation) is the caller's."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import torch_ref as TR
+
+
+@pytest.fixture(scope="session")
+def venc_models(pkg):
+    d = os.path.join(os.environ.get("TTS_SYNTH_DIR", "/tmp/tts_synth"), "venc")
+    os.makedirs(d, exist_ok=True)
+    from tortoise_cpp_amd import synth_weights as sw
+    out = {}
+    for name, blocks in (("small", 2), ("full", 6)):
+        p = os.path.join(d, "ggml-conditioning-model-%s.bin" % name)
+        if not os.path.exists(p + ".done"):
+            sw.write_voice_encoder(p, blocks=blocks, seed=50 + blocks)
+            open(p + ".done", "w").write("ok")
+        out[name] = p
+    return out
+
+
+def _mels(seed, lens):
+    rs = np.random.RandomState(seed)
+    return [(rs.randn(80, n) * 1.5 - 2.0).astype(np.float32) for n in lens]  # log-mel-like range
+
+
+def test_voice_encoder_oracle_vs_torch(oracle, venc_models):
+    mels = _mels(0, (50, 33))
+    o = oracle.VoiceEncoder(oracle.Model(venc_models["small"])).latent(mels)
+    t64 = TR.TorchVoiceEncoder(venc_models["small"], torch.float64).latent(mels)
+    t32 = TR.TorchVoiceEncoder(venc_models["small"]).latent(mels)
+    scale = np.abs(t64).max()
+    assert np.abs(o - t64).max() < 2e-5 * scale and np.abs(t32 - t64).max() < 2e-5 * scale
+    assert scale > 0.1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,lens", [("small", (50, 33, 7)), ("full", (517, 301))])
+def test_voice_encoder_engine_vs_oracle(pkg, oracle, venc_models, which, lens):
+    """fp16-operand GEMMs (f32 accumulate) against the f32 oracle: 3e-3 of the latent's range; deterministic; a clip's contribution does not
+    depend on the other clips (mean of single-clip latents == the multi-clip latent)."""
+    mels = _mels(4, lens)
+    e = pkg.Engine(0)
+    e.load_voice_encoder(venc_models[which])
+    got = e.voice_latent(mels)
+    want = oracle.VoiceEncoder(oracle.Model(venc_models[which])).latent(mels)
+    err = float(np.abs(got - want).max() / np.abs(want).max())
+    print("voice encoder %s: max err %.1e of range %.2f" % (which, err, np.abs(want).max()))
+    assert np.isfinite(got).all() and err < 3e-3
+    assert (got == e.voice_latent(mels)).all()
+    singles = np.mean([e.voice_latent([m]).astype(np.float64) for m in mels], axis=0)
+    assert np.abs(singles - got).max() < 1e-5 * np.abs(want).max()
+    e.close()
+
+
+@pytest.mark.gpu
+def test_voice_encoder_errors(pkg, venc_models, small_models):
+    e = pkg.Engine(0)
+    with pytest.raises(pkg.TtsError, match="tts_load_voice_encoder not called"):
+        e.voice_latent(_mels(0, (5,)))
+    with pytest.raises(pkg.TtsError, match="not a conditioning-encoder file"):
+        e.load_voice_encoder(small_models + "/ggml-model.bin")
+    e.load_voice_encoder(venc_models["small"])
+    assert e.voice_latent(_mels(0, (1,))).shape == (1024,)  # a one-frame clip is legal
+    e.close()

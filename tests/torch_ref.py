@@ -336,3 +336,39 @@ class TorchCLVP:
         t = self.w["temperature"].reshape(()).exp()
         return np.array([float((zt * self.latent("speech_transformer", "speech_emb.weight", "to_speech_latent.weight", sp)).sum() * t)
                          for sp in speech_list])
+
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Voice-conditioning encoder: upstream tortoise-tts UnifiedVoice.get_conditioning (ConditioningEncoder + arch_util
+# AttentionBlock / QKVAttentionLegacy) with torch ops; pins oracle.VoiceEncoder. No reference code exists (the reference reads the
+# finished latent from --voice).
+# ------------------------------------------------------------------------------------------------------------------------------
+class TorchVoiceEncoder:
+    def __init__(self, path, dtype=torch.float32):
+        from tortoise_cpp_amd import synth_weights as sw
+        self.w = {k: torch.from_numpy(v).to(dtype) for k, v in sw.read_ggml(path).items()}
+        self.dtype = dtype
+        self.blocks = 0
+        while "conditioning_encoder.attn.%d.norm.weight" % self.blocks in self.w:
+            self.blocks += 1
+
+    def clip(self, mel):  # mel [80, T]
+        w = self.w
+        x = torch.as_tensor(np.asarray(mel)).to(self.dtype)[None]
+        h = F.conv1d(x, w["conditioning_encoder.init.weight"], w["conditioning_encoder.init.bias"])
+        for i in range(self.blocks):
+            p = "conditioning_encoder.attn.%d." % i
+            y = F.group_norm(h, 32, w[p + "norm.weight"], w[p + "norm.bias"], 1e-5)
+            qkv = F.conv1d(y, w[p + "qkv.weight"], w[p + "qkv.bias"])
+            bs, width, length = qkv.shape
+            ch = width // (3 * 16)
+            q, k, v = qkv.reshape(bs * 16, ch * 3, length).split(ch, dim=1)
+            scale = 1 / (ch ** 0.25)
+            wt = torch.softmax(torch.einsum("bct,bcs->bts", q * scale, k * scale), dim=-1)
+            a = torch.einsum("bts,bcs->bct", wt, v).reshape(bs, -1, length)
+            h = h + F.conv1d(a, w[p + "proj_out.weight"], w[p + "proj_out.bias"])
+        return h[0, :, 0]
+
+    def latent(self, mels):
+        return torch.stack([self.clip(m) for m in mels]).mean(dim=0).to(torch.float64).numpy()

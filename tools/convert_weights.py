@@ -166,6 +166,23 @@ def convert_vocoder(sd, path):
     return i
 
 
+def convert_conditioning_encoder(sd, path):
+    """ggml-conditioning-model.bin for tts_load_voice_encoder: the `conditioning_encoder.*` tensors of upstream tortoise-tts' autoregressive.pth
+    (the tensors convert_ar leaves out: the reference reads the finished voice latent from a file), under their state-dict names."""
+    w = GgmlWriter(path)
+    n = 0
+    for k in sorted(sd):
+        if k.startswith("conditioning_encoder."):
+            if ".relative_pos_embeddings." in k:
+                raise SystemExit("convert_conditioning_encoder: '%s' — an encoder with relative position embeddings is not the UnifiedVoice one" % k)
+            w.add(k, _np(sd[k]))
+            n += k.endswith(".norm.weight")
+    w.close()
+    if n == 0:
+        raise SystemExit("convert_conditioning_encoder: no conditioning_encoder.* tensors in the checkpoint")
+    return n
+
+
 def convert_clvp(sd, path):
     """ggml-clvp-model.bin for tts_load_clvp: upstream tortoise-tts CLVP (clvp2.pth, use_xformers=True), tensors under their state-dict names.
     Kept: embeddings, latent projections, temperature (0-dim -> [1]), every `*.attn_layers.layers.N.{0.g, 1.*}` parameter and the final norms;
@@ -195,6 +212,8 @@ def main():
     ap.add_argument("--diffusion")
     ap.add_argument("--diffusion-conditioning-latent", help=".pth / .npy / raw f32 file holding the voice's [1, 2048] diffusion conditioning latent")
     ap.add_argument("--vocoder")
+    ap.add_argument("--conditioning-encoder", action="store_true", help="with --ar: also write ggml-conditioning-model.bin (the checkpoint's "
+                                                                         "conditioning_encoder.* tensors: mel -> voice latent, tts_load_voice_encoder; not in the reference)")
     ap.add_argument("--clvp", help="clvp2.pth of upstream tortoise-tts -> ggml-clvp-model.bin (candidate re-ranking, tts_load_clvp; not in the reference)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
@@ -202,6 +221,10 @@ def main():
     load = lambda p: torch.load(p, map_location="cpu", weights_only=True)
     if a.ar:
         print("ggml-model.bin: %d transformer layers" % convert_ar(load(a.ar), os.path.join(a.out, "ggml-model.bin")))
+    if a.conditioning_encoder:
+        if not a.ar:
+            sys.exit("--conditioning-encoder needs --ar (the encoder's tensors live in autoregressive.pth)")
+        print("ggml-conditioning-model.bin: %d attention blocks" % convert_conditioning_encoder(load(a.ar), os.path.join(a.out, "ggml-conditioning-model.bin")))
     if a.diffusion:
         if not a.diffusion_conditioning_latent:
             sys.exit("--diffusion needs --diffusion-conditioning-latent (the reference bakes the voice's diffusion latent into the weight file)")

@@ -49,6 +49,7 @@ def lib():
         "tts_set_option": (ci, [vp, C.c_char_p, C.c_double]),
         "tts_load_ar": (ci, [vp, C.c_char_p]), "tts_load_diffusion": (ci, [vp, C.c_char_p]),
         "tts_load_vocoder": (ci, [vp, C.c_char_p]), "tts_load_clvp": (ci, [vp, C.c_char_p]),
+        "tts_load_voice_encoder": (ci, [vp, C.c_char_p]), "tts_voice_latent": (ci, [vp, _f32p, _i32p, ci, _f32p]),
         "tts_clvp_score": (ci, [vp, _i32p, ci, _i32p, _i32p, ci, ci, _f32p]), "tts_ar_layers": (ci, [vp]), "tts_diffusion_layers": (ci, [vp]),
         "tts_seed": (None, [vp, C.c_uint32]), "tts_rng_load_state": (ci, [vp, C.c_char_p]), "tts_rng_save_state": (ci, [vp, C.c_char_p]),
         "tts_rng_uniform": (cf, [vp]), "tts_rng_normal": (None, [vp, _f32p, C.c_int64]),
@@ -207,6 +208,18 @@ class Engine:
         """Per candidate of the last autoregressive() call: 1 = ended in a sampled stop token, 0 = cut at max_steps."""
         out = np.zeros(B, np.int32)
         self._ck(self.L.tts_ar_stop_status(self.h, out, B))
+        return out
+
+    # ---- voice-conditioning encoder (not in the reference) ----
+    def load_voice_encoder(self, path):
+        self._ck(self.L.tts_load_voice_encoder(self.h, path.encode()))
+
+    def voice_latent(self, mels):
+        """mels: list of [80, T_c] log-mel spectrograms of the reference clips. Returns the 1024-float voice latent (a --voice file)."""
+        frames = np.array([m.shape[1] for m in mels], np.int32)
+        mel = np.ascontiguousarray(np.concatenate([np.asarray(m, np.float32).reshape(-1) for m in mels]))
+        out = np.empty(1024, np.float32)
+        self._ck(self.L.tts_voice_latent(self.h, mel, frames, len(mels), out))
         return out
 
     # ---- candidate re-ranking (not in the reference) ----

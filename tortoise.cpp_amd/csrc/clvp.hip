@@ -14,6 +14,10 @@
 // to a multiple of 128); every projection is one launch of the fp16-MFMA GEMM of gemm_f16.h (fp16 operands, f32 accumulate, bias and
 // residual fused into the epilogue) over all rows; attention runs per (sequence, head) with K/V staged through LDS in chunks of 128 keys.
 // The scorer runs once per utterance on <= 16 x ~200 rows: it is 1-2 ms of work, the kernels are written for clarity.
+//
+// Second part of this file: the voice-conditioning encoder — upstream tortoise-tts' UnifiedVoice.get_conditioning, i.e.
+// what produces the 1024-float latent the reference reads from --voice (main.cpp:5179-5184; README.md:54-72 gives only an offline PyTorch
+// recipe). Same device layout and the same attention kernel (without the rotary embedding); see tts_load_voice_encoder / tts_voice_latent.
 #include "common.h"
 #include "gemm_f16.h"
 #include <cmath>
@@ -49,6 +53,7 @@ __global__ __launch_bounds__(256) void clvp_rmsnorm_kernel(const float *__restri
 
 // One workgroup = 256 queries of one (sequence, head); a thread owns one query (q and the output row in registers, f32), the keys stream
 // through LDS in chunks of 128 (K rotated on the way in). qkv: fp16 [row][3 inner] = q | k | v, head h at columns h*64.
+template <bool ROT> // ROT: CLVP's rotary embedding on the first 32 head dims; false: plain softmax(q k^T / 8) v (voice encoder)
 __global__ __launch_bounds__(256) void clvp_attn_kernel(const __half *__restrict__ qkv, const int *__restrict__ seq_start, const int *__restrict__ seq_len,
                                                         int inner, __half *__restrict__ out) {
   __shared__ __half sk[CLVP_KCHUNK][CLVP_DH], sv[CLVP_KCHUNK][CLVP_DH];
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(256) void clvp_attn_kernel(const __half *__restrict
     const __half *qp = qkv + (size_t)(r0 + (live ? qi : 0)) * ld + h * CLVP_DH;
 #pragma unroll
     for (int d = 0; d < CLVP_DH; d++) { q[d] = __half2float(qp[d]); acc[d] = 0.f; }
-    rot(q, live ? qi : 0);
+    if (ROT) rot(q, live ? qi : 0);
   }
   float m = -INFINITY, l = 0.f;
   for (int k0 = 0; k0 < n; k0 += CLVP_KCHUNK) {
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(256) void clvp_attn_kernel(const __half *__restrict
         float t[32];
 #pragma unroll
         for (int d = 0; d < 32; d++) t[d] = __half2float(kp[d]);
-        if (half == 0) rot(t, key);
+        if (ROT && half == 0) rot(t, key);
 #pragma unroll
         for (int d = 0; d < 32; d++) { sk[kj][half * 32 + d] = __float2half_rn(t[d]); sv[kj][half * 32 + d] = vp[d]; }
       }
@@ -137,6 +142,31 @@ __global__ __launch_bounds__(256) void clvp_pool_kernel(const float *__restrict_
     for (int i = 0, c = threadIdx.x; c < dim; c += 256, i++) acc[i] += (xr[c] - mean) * rstd * w[c] + b[c];
   }
   for (int i = 0, c = threadIdx.x; c < dim; c += 256, i++) pooled[(size_t)s * dim + c] = acc[i] / n;
+}
+// ---- voice-conditioning encoder kernels ----
+// mel [80][T] of every clip (concatenated) -> fp16 rows [row][128] (channels 80..127 zero): the A operand of the k = 1 init convolution
+__global__ __launch_bounds__(128) void venc_mel_rows_kernel(const float *__restrict__ mel, const int *__restrict__ seq_start, const int *__restrict__ seq_len,
+                                                            const long long *__restrict__ mel_off, __half *__restrict__ a16) {
+  const int s = blockIdx.y, t = blockIdx.x, T = seq_len[s];
+  if (t >= T) return;
+  const int c = threadIdx.x;
+  a16[(size_t)(seq_start[s] + t) * 128 + c] = __float2half_rn(c < 80 ? mel[mel_off[s] + (size_t)c * T + t] : 0.f);
+}
+
+// GroupNorm(32 groups of 32 channels, eps 1e-5, statistics over the whole clip) -> fp16; one workgroup per (clip, group)
+__global__ __launch_bounds__(256) void venc_groupnorm_kernel(const float *__restrict__ x, const int *__restrict__ seq_start, const int *__restrict__ seq_len,
+                                                             const float *__restrict__ g, const float *__restrict__ b, __half *__restrict__ y) {
+  __shared__ float red[4];
+  const int s = blockIdx.y, grp = blockIdx.x, T = seq_len[s], r0 = seq_start[s];
+  const int c = grp * 32 + (threadIdx.x & 31), t0 = threadIdx.x >> 5; // 8 rows per sweep
+  float sum = 0.f;
+  for (int t = t0; t < T; t += 8) sum += x[(size_t)(r0 + t) * 1024 + c];
+  const float mean = block_sum(sum, red) / (32.f * T);
+  float sq = 0.f;
+  for (int t = t0; t < T; t += 8) { const float d = x[(size_t)(r0 + t) * 1024 + c] - mean; sq += d * d; }
+  const float rstd = rsqrtf(block_sum(sq, red) / (32.f * T) + 1e-5f);
+  const float gg = g[c], bb = b[c];
+  for (int t = t0; t < T; t += 8) y[(size_t)(r0 + t) * 1024 + c] = __float2half_rn((x[(size_t)(r0 + t) * 1024 + c] - mean) * rstd * gg + bb);
 }
 } // namespace
 
@@ -285,7 +315,7 @@ static int clvp_encode(tts_ctx *ctx, ClvpState *st, int e, const std::vector<int
     ProfScope ps(ctx, "clvp_layer", 2.0 * rows * ((double)d * 3 * in + (double)in * d + (double)d * 2 * ff + (double)ff * d));
     clvp_rmsnorm_kernel<<<rows, 256, 0, ctx->stream>>>(x, l.g_attn, d, y);
     { GemmArgs g = gemm(y, d, l.w_qkv, 3 * in, nullptr); g.mode = GEMM_OUT_F16; g.outH = qkv; g.ldh = 3 * in; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
-    clvp_attn_kernel<<<dim3(nseq, in / CLVP_DH, (maxlen + 255) / 256), 256, 0, ctx->stream>>>(qkv, d_start, d_len, in, att);
+    clvp_attn_kernel<true><<<dim3(nseq, in / CLVP_DH, (maxlen + 255) / 256), 256, 0, ctx->stream>>>(qkv, d_start, d_len, in, att);
     { GemmArgs g = gemm(att, in, l.w_out, d, l.b_out); g.mode = GEMM_OUT_F32; g.outF = x; g.ldo = d; g.resid = x; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
     clvp_rmsnorm_kernel<<<rows, 256, 0, ctx->stream>>>(x, l.g_ff, d, y);
     { GemmArgs g = gemm(y, d, l.w_ff1, 2 * ff, l.b_ff1); g.mode = GEMM_OUT_F32; g.outF = u; g.ldo = 2 * ff; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
@@ -340,6 +370,148 @@ int clvp_score(tts_ctx *ctx, const int32_t *text_ids, int n_text, const int32_t 
     double a = 0;
     for (int o = 0; o < st->latent; o++) a += (double)zt[o] * zs[(size_t)c * st->latent + o];
     scores_out[c] = (float)(a * temp);
+  }
+  return TTS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// voice-conditioning encoder
+// ------------------------------------------------------------------------------------------------------------------------------
+struct VencBlock {
+  float *g = nullptr, *b = nullptr, *b_qkv = nullptr, *b_proj = nullptr;
+  __half *w_qkv = nullptr, *w_proj = nullptr;
+};
+struct VoiceEncState {
+  float *b_init = nullptr;
+  __half *w_init = nullptr; // [1024][128]: K padded 80 -> 128
+  std::vector<VencBlock> blk;
+  std::vector<void *> owned;
+  DevBuf x, y16, qkv16, att16, a16, meta, mel;
+  ~VoiceEncState() { for (void *p : owned) (void)hipFree(p); }
+};
+void voice_enc_free(VoiceEncState *s) { delete s; }
+
+template <class T> static int venc_up(tts_ctx *ctx, VoiceEncState *st, const std::vector<T> &src, T **dst) {
+  void *p = nullptr;
+  TTS_HIP(ctx, hipMalloc(&p, src.size() * sizeof(T)));
+  st->owned.push_back(p);
+  TTS_HIP(ctx, hipMemcpy(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dst = (T *)p;
+  return TTS_OK;
+}
+
+int voice_enc_load(tts_ctx *ctx, const char *path) {
+  WeightFile wf;
+  std::string err;
+  int rc = read_weight_file(path, wf, err);
+  if (rc != TTS_OK) return fail(ctx, rc, "voice_encoder_load: %s", err.c_str());
+  constexpr int D = 1024, H = 16;
+  auto get = [&](const std::string &name, int64_t nelem) -> const HostTensor * {
+    auto it = wf.t.find(name);
+    if (it == wf.t.end()) { fail(ctx, TTS_ERR_FORMAT, "tensor '%s' missing from the conditioning-encoder file", name.c_str()); return nullptr; }
+    if (it->second.nelem() != nelem) { fail(ctx, TTS_ERR_FORMAT, "tensor '%s' has %d elements, %d expected", name.c_str(), (int)it->second.nelem(), (int)nelem); return nullptr; }
+    return &it->second;
+  };
+  if (!wf.has("conditioning_encoder.init.weight")) return fail(ctx, TTS_ERR_FORMAT, "'%s' is not a conditioning-encoder file", path);
+  std::unique_ptr<VoiceEncState> st(new VoiceEncState());
+  const HostTensor *t, *tb;
+  if (!(t = get("conditioning_encoder.init.weight", D * 80)) || !(tb = get("conditioning_encoder.init.bias", D))) return TTS_ERR_FORMAT;
+  {
+    std::vector<__half> w((size_t)D * 128, __float2half_rn(0.f));
+    for (int n = 0; n < D; n++)
+      for (int k = 0; k < 80; k++) w[(size_t)n * 128 + k] = __float2half_rn(t->data[(size_t)n * 80 + k]);
+    if ((rc = venc_up(ctx, st.get(), w, &st->w_init)) || (rc = venc_up(ctx, st.get(), tb->data, &st->b_init))) return rc;
+  }
+  size_t known = 2;
+  for (int i = 0; wf.has("conditioning_encoder.attn." + std::to_string(i) + ".norm.weight"); i++) {
+    const std::string p = "conditioning_encoder.attn." + std::to_string(i) + ".";
+    VencBlock b;
+    const HostTensor *g, *gb, *qw, *qb, *pw, *pb;
+    if (!(g = get(p + "norm.weight", D)) || !(gb = get(p + "norm.bias", D)) || !(qw = get(p + "qkv.weight", 3 * D * D)) || !(qb = get(p + "qkv.bias", 3 * D)) ||
+        !(pw = get(p + "proj_out.weight", D * D)) || !(pb = get(p + "proj_out.bias", D)))
+      return TTS_ERR_FORMAT;
+    // QKVAttentionLegacy: output channel = head * 192 + {q, k, v} * 64 + d. The rows are re-ordered to q | k | v blocks with head h at
+    // columns h * 64 (the layout clvp_attn_kernel reads): new row t * 1024 + h * 64 + d  <-  old row h * 192 + t * 64 + d
+    std::vector<__half> w((size_t)3 * D * D);
+    std::vector<float> bq(3 * D);
+    for (int h = 0; h < H; h++)
+      for (int tq = 0; tq < 3; tq++)
+        for (int d = 0; d < 64; d++) {
+          const int o = h * 192 + tq * 64 + d, n = tq * D + h * 64 + d;
+          bq[n] = qb->data[o];
+          for (int k = 0; k < D; k++) w[(size_t)n * D + k] = __float2half_rn(qw->data[(size_t)o * D + k]);
+        }
+    std::vector<__half> wp((size_t)D * D);
+    for (size_t k = 0; k < wp.size(); k++) wp[k] = __float2half_rn(pw->data[k]);
+    if ((rc = venc_up(ctx, st.get(), g->data, &b.g)) || (rc = venc_up(ctx, st.get(), gb->data, &b.b)) || (rc = venc_up(ctx, st.get(), w, &b.w_qkv)) ||
+        (rc = venc_up(ctx, st.get(), bq, &b.b_qkv)) || (rc = venc_up(ctx, st.get(), wp, &b.w_proj)) || (rc = venc_up(ctx, st.get(), pb->data, &b.b_proj)))
+      return rc;
+    st->blk.push_back(b);
+    known += 6;
+  }
+  if (st->blk.empty()) return fail(ctx, TTS_ERR_FORMAT, "no attention blocks in '%s'", path);
+  if (wf.t.size() != known) return fail(ctx, TTS_ERR_FORMAT, "unknown tensors in conditioning-encoder file '%s' (%d tensors, %d expected)", path, (int)wf.t.size(), (int)known);
+  if (ctx->venc) voice_enc_free(ctx->venc);
+  ctx->venc = st.release();
+  return TTS_OK;
+}
+
+int voice_enc_latent(tts_ctx *ctx, const float *mel, const int32_t *frames, int n_clips, float *out1024) {
+  VoiceEncState *st = ctx->venc;
+  if (!st) return fail(ctx, TTS_ERR_STATE, "tts_load_voice_encoder not called");
+  if (!mel || !frames || n_clips < 1 || !out1024) return fail(ctx, TTS_ERR_ARG, "tts_voice_latent: bad arguments");
+  constexpr int D = 1024;
+  int rows = 0, maxlen = 0;
+  std::vector<int> meta(2 * n_clips);
+  std::vector<long long> moff(n_clips);
+  long long off = 0;
+  for (int s = 0; s < n_clips; s++) {
+    if (frames[s] < 1 || frames[s] > 16384) return fail(ctx, TTS_ERR_ARG, "clip %d: %d mel frames (1 .. 16384 expected)", s, frames[s]);
+    meta[s] = rows; meta[n_clips + s] = frames[s]; moff[s] = off;
+    rows += frames[s]; off += (long long)80 * frames[s]; maxlen = std::max(maxlen, frames[s]);
+  }
+  const int M = (rows + 127) / 128 * 128;
+  TTS_HIP(ctx, st->x.reserve((size_t)M * D * 4));
+  TTS_HIP(ctx, st->y16.reserve((size_t)M * D * 2));
+  TTS_HIP(ctx, st->qkv16.reserve((size_t)M * 3 * D * 2));
+  TTS_HIP(ctx, st->att16.reserve((size_t)M * D * 2));
+  TTS_HIP(ctx, st->a16.reserve((size_t)M * 128 * 2));
+  TTS_HIP(ctx, st->meta.reserve((size_t)2 * n_clips * 4 + (size_t)n_clips * 8 + 16));
+  TTS_HIP(ctx, st->mel.reserve((size_t)off * 4));
+  int *d_start = st->meta.as<int>(), *d_len = d_start + n_clips;
+  long long *d_moff = (long long *)(st->meta.as<char>() + (((size_t)2 * n_clips * 4 + 7) & ~(size_t)7));
+  TTS_HIP(ctx, hipMemcpyAsync(d_start, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  TTS_HIP(ctx, hipMemcpyAsync(d_moff, moff.data(), moff.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  TTS_HIP(ctx, hipMemcpyAsync(st->mel.p, mel, (size_t)off * 4, hipMemcpyHostToDevice, ctx->stream));
+  TTS_HIP(ctx, hipMemsetAsync(st->a16.p, 0, (size_t)M * 128 * 2, ctx->stream)); // rows past the last frame: finite, never read back
+  TTS_HIP(ctx, hipMemsetAsync(st->y16.p, 0, (size_t)M * D * 2, ctx->stream));
+  TTS_HIP(ctx, hipMemsetAsync(st->att16.p, 0, (size_t)M * D * 2, ctx->stream));
+  float *x = st->x.as<float>();
+  __half *y = st->y16.as<__half>(), *qkv = st->qkv16.as<__half>(), *att = st->att16.as<__half>(), *a16 = st->a16.as<__half>();
+  venc_mel_rows_kernel<<<dim3(maxlen, n_clips), 128, 0, ctx->stream>>>(st->mel.as<float>(), d_start, d_len, d_moff, a16);
+  auto gemm = [&](const __half *A, int K, const __half *W, int N, const float *bias) {
+    GemmArgs g{};
+    for (int i = 0; i < 3; i++) { g.A[i] = A; g.row_off[i] = 0; }
+    g.nseg = 1; g.kseg = K; g.lda = K; g.W = W; g.M = M; g.N = N; g.bias = bias;
+    return g;
+  };
+  { GemmArgs g = gemm(a16, 128, st->w_init, D, st->b_init); g.mode = GEMM_OUT_F32; g.outF = x; g.ldo = D; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
+  for (const VencBlock &b : st->blk) {
+    venc_groupnorm_kernel<<<dim3(32, n_clips), 256, 0, ctx->stream>>>(x, d_start, d_len, b.g, b.b, y);
+    { GemmArgs g = gemm(y, D, b.w_qkv, 3 * D, b.b_qkv); g.mode = GEMM_OUT_F16; g.outH = qkv; g.ldh = 3 * D; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
+    clvp_attn_kernel<false><<<dim3(n_clips, D / CLVP_DH, (maxlen + 255) / 256), 256, 0, ctx->stream>>>(qkv, d_start, d_len, D, att);
+    { GemmArgs g = gemm(att, D, b.w_proj, D, b.b_proj); g.mode = GEMM_OUT_F32; g.outF = x; g.ldo = D; g.resid = x; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
+  }
+  TTS_HIP(ctx, hipGetLastError());
+  // position 0 of every clip, mean over the clips
+  std::vector<float> first((size_t)n_clips * D);
+  for (int s = 0; s < n_clips; s++)
+    TTS_HIP(ctx, hipMemcpyAsync(&first[(size_t)s * D], x + (size_t)meta[s] * D, D * 4, hipMemcpyDeviceToHost, ctx->stream));
+  TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int c = 0; c < D; c++) {
+    double a = 0;
+    for (int s = 0; s < n_clips; s++) a += first[(size_t)s * D + c];
+    out1024[c] = (float)(a / n_clips);
   }
   return TTS_OK;
 }

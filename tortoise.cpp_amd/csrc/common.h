@@ -53,6 +53,7 @@ struct ArState;
 struct DiffState;
 struct VocState;
 struct ClvpState;
+struct VoiceEncState;
 struct Tokenizer;
 struct SamplerPool;
 void sampler_pool_free(SamplerPool *p);
@@ -77,6 +78,7 @@ struct tts_ctx {
   tts::DiffState *diff = nullptr;
   tts::VocState *voc = nullptr;
   tts::ClvpState *clvp = nullptr; // candidate re-ranker (clvp.hip; not in the reference)
+  tts::VoiceEncState *venc = nullptr; // voice-conditioning encoder (clvp.hip; not in the reference)
   tts::Tokenizer *tok = nullptr;
   tts::SamplerPool *sampler_pool = nullptr; // worker threads for the per-candidate sampler scans (host_logic.cpp)
   int sampler_threads = -1;                 // -1: min(7, hardware threads - 1); option "sampler_threads"
@@ -180,6 +182,9 @@ int voc_load(tts_ctx *ctx, const char *path);
 #define TTS_VOC_CHUNK_HALO 24
 int voc_halo_frames();
 void voc_free(VocState *);
+int voice_enc_load(tts_ctx *ctx, const char *path);
+void voice_enc_free(VoiceEncState *);
+int voice_enc_latent(tts_ctx *ctx, const float *mel, const int32_t *frames, int n_clips, float *out1024);
 int clvp_load(tts_ctx *ctx, const char *path);
 void clvp_free(ClvpState *);
 int clvp_score(tts_ctx *ctx, const int32_t *text_ids, int n_text, const int32_t *codes, const int32_t *code_len, int n_candidates, int code_stride,

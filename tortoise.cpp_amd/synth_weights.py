@@ -196,6 +196,23 @@ def write_clvp(path, depth=20, dim=768, heads=12, ff_mult=2, seed=1237):
     w.close()
 
 
+def write_voice_encoder(path, blocks=6, seed=1238):
+    """ggml-conditioning-model.bin: the conditioning encoder of upstream tortoise-tts' UnifiedVoice (tortoise/models/autoregressive.py:
+    ConditioningEncoder(80, 1024, attn_blocks=6, num_attn_heads=16) = Conv1d(80, 1024, 1) + 6 AttentionBlocks (GroupNorm32, qkv Conv1d k=1,
+    QKVAttentionLegacy, proj_out) -> position 0), which turns an 80-band mel of a reference clip into the 1024-float voice latent the reference
+    reads from --voice (main.cpp:5179-5184; README.md:54-72 is the offline recipe). Tensor names = the upstream state dict's. SURVEY 8 f3."""
+    g = _Gen(seed)
+    w = GgmlWriter(path)
+    D = 1024
+    w.add("conditioning_encoder.init.weight", g.lecun((D, 80, 1), 80)); w.add("conditioning_encoder.init.bias", g.normal((D,), 0.02))
+    for i in range(blocks):
+        p = "conditioning_encoder.attn.%d." % i
+        w.add(p + "norm.weight", g.gamma(D)); w.add(p + "norm.bias", g.beta(D))
+        w.add(p + "qkv.weight", g.lecun((3 * D, D, 1), D, 1.5)); w.add(p + "qkv.bias", g.normal((3 * D,), 0.02))
+        w.add(p + "proj_out.weight", g.lecun((D, D, 1), D, 0.5)); w.add(p + "proj_out.bias", g.normal((D,), 0.02))
+    w.close()
+
+
 def write_all(out_dir, ar_layers=30, diff_main=10, diff_tail=3, diff_integ=3, diff_lc=4, seed=1234):
     import os
     os.makedirs(out_dir, exist_ok=True)
