@@ -92,6 +92,13 @@ int tts_load_clvp(tts_ctx *ctx, const char *path);
  * --conditioning-encoder). tts_voice_latent: mel = the clips' 80-band log-mel spectrograms [80][frames[c]] one after the other (the audio
  * front-end — STFT, mel filterbank, normalisation — stays with the caller); out1024 = what a --voice file holds. */
 int tts_load_voice_encoder(tts_ctx *ctx, const char *path);
+/* The other voice latent: upstream DiffusionTts.get_conditioning (contextual_embedder: two k = 3 / stride 2 convolutions, five 2048-channel
+ * attention blocks with relative position bias, mean over the frames of all clips) turns the clips' 100-band mel [100][frames[c]] into the
+ * 2048 floats the reference reads as the WEIGHT `diffusion_conditioning_latent` of ggml-diffusion-model.bin (main.cpp:1557-1560: one voice
+ * per weight file). tts_set_diffusion_conditioning_latent replaces that weight in the loaded diffusion model (after tts_load_diffusion). */
+int tts_load_diffusion_conditioning_encoder(tts_ctx *ctx, const char *path);
+int tts_diffusion_conditioning_latent(tts_ctx *ctx, const float *mel, const int32_t *frames, int n_clips, float *out2048);
+int tts_set_diffusion_conditioning_latent(tts_ctx *ctx, const float *latent2048);
 int tts_voice_latent(tts_ctx *ctx, const float *mel, const int32_t *frames, int n_clips, float *out1024);
 int tts_ar_layers(const tts_ctx *ctx);
 int tts_diffusion_layers(const tts_ctx *ctx);

@@ -452,6 +452,62 @@ class VoiceEncoder:
         return np.mean([self.clip(m).astype(np.float64) for m in mels], axis=0)
 
 
+class DiffusionConditioning:
+    """Diffusion conditioning latent, numpy restatement of UPSTREAM tortoise-tts (tortoise/models/diffusion_decoder.py:
+    DiffusionTts.get_conditioning -> contextual_embedder = Conv1d(100, 1024, 3, stride 2, padding 1), Conv1d(1024, 2048, 3, stride 2,
+    padding 1), 5 x arch_util.AttentionBlock(2048, 16 heads, relative_pos_embeddings=True): GroupNorm(32, eps 1e-5), qkv (k = 1),
+    QKVAttentionLegacy with head dim 128 (q, k scaled by 128^-1/4) + T5 bucket bias (32 buckets, max distance 64, buckets() of this module)
+    x sqrt(128), proj_out, + x; mean over the frames of all clips). The reference reads the result as a WEIGHT of ggml-diffusion-model.bin
+    (main.cpp:1557-1560): nothing to cite or pin against — PARITY UNPINNED, pinned against the torch restatement (tests/torch_ref.py)."""
+
+    def __init__(self, model, dtype=np.float32):
+        self.m, self.dt, self.blocks = model, dtype, 0
+        while True:
+            try:
+                model.tensor("contextual_embedder.%d.norm.weight" % (2 + self.blocks))
+            except KeyError:
+                break
+            self.blocks += 1
+
+    def _t(self, name, *shape):
+        return self.m.tensor(name).reshape(shape).astype(self.dt)
+
+    def _conv3s2(self, x, wname, bname, cout, cin):  # x [T, cin] -> [T', cout]
+        w, b = self._t(wname, cout, cin, 3), self._t(bname, cout)
+        T = x.shape[0]
+        To = (T - 1) // 2 + 1
+        xp = np.concatenate([np.zeros((1, cin), self.dt), x, np.zeros((2, cin), self.dt)])
+        out = np.zeros((To, cout), self.dt)
+        for tap in range(3):
+            out += xp[tap:tap + 2 * To:2] @ w[:, :, tap].T
+        return out + b
+
+    def clip(self, mel):  # [100, T] -> [T2, 2048]
+        D, H, dh = 2048, 16, 128
+        h = self._conv3s2(np.asarray(mel, self.dt).T, "contextual_embedder.0.weight", "contextual_embedder.0.bias", 1024, 100)
+        h = self._conv3s2(h, "contextual_embedder.1.weight", "contextual_embedder.1.bias", D, 1024)
+        n = h.shape[0]
+        bk = buckets(n).reshape(n, n)  # [query, key], the reference's get_relative_position_buckets (main.cpp:4722-4749) = the upstream T5 rule
+        for i in range(self.blocks):
+            p = "contextual_embedder.%d." % (2 + i)
+            g = h.reshape(n, 32, 64)
+            mu = g.mean(axis=(0, 2), keepdims=True)
+            var = ((g - mu) ** 2).mean(axis=(0, 2), keepdims=True)
+            y = ((g - mu) / np.sqrt(var + self.dt(1e-5))).reshape(n, D) * self._t(p + "norm.weight", D) + self._t(p + "norm.bias", D)
+            qkv = (y @ self._t(p + "qkv.weight", 3 * D, D).T + self._t(p + "qkv.bias", 3 * D)).reshape(n, H, 3, dh)
+            q, k, v = (qkv[:, :, j].transpose(1, 0, 2) for j in range(3))
+            sc = (q * self.dt(dh ** -0.25)) @ (k * self.dt(dh ** -0.25)).transpose(0, 2, 1)
+            emb = self._t(p + "relative_pos_embeddings.relative_attention_bias.weight", 32, H)
+            sc = sc + emb[bk].transpose(2, 0, 1) * self.dt(dh ** 0.5)
+            sc = np.exp(sc - sc.max(-1, keepdims=True))
+            a = ((sc / sc.sum(-1, keepdims=True)) @ v).transpose(1, 0, 2).reshape(n, D)
+            h = h + a @ self._t(p + "proj_out.weight", D, D).T + self._t(p + "proj_out.bias", D)
+        return h
+
+    def latent(self, mels):
+        return np.concatenate([self.clip(m).astype(np.float64) for m in mels]).mean(axis=0)
+
+
 def ref():
     global _ref
     if _ref is None:

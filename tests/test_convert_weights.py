@@ -143,3 +143,22 @@ def test_conditioning_encoder_from_the_ar_checkpoint(small_models, tmp_path, ora
     a = oracle.VoiceEncoder(oracle.Model(src)).latent(mels)
     b = oracle.VoiceEncoder(oracle.Model(out + "/ggml-conditioning-model.bin")).latent(mels)
     assert (a == b).all()
+
+
+def test_diffusion_conditioning_encoder_from_the_diffusion_checkpoint(tmp_path, oracle):
+    import tortoise_cpp_amd_loader
+    tortoise_cpp_amd_loader.load()
+    from tortoise_cpp_amd import synth_weights as sw
+    src = str(tmp_path / "dcond.bin")
+    sw.write_diffusion_conditioning_encoder(src, blocks=1, seed=4)
+    sd = {k: torch.from_numpy(v) for k, v in sw.read_ggml(src).items()}
+    sd["layers.0.resblk.in_layers.2.weight"] = torch.zeros(4, 4, 1)  # the rest of the checkpoint is ignored
+    torch.save(sd, str(tmp_path / "diffusion_decoder.pth"))
+    out = str(tmp_path / "out")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "convert_weights.py"), "--diffusion-conditioning-encoder",
+                        str(tmp_path / "diffusion_decoder.pth"), "--out", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "1 attention blocks" in r.stdout, r.stdout + r.stderr
+    mels = [np.random.RandomState(1).randn(100, 37).astype(np.float32)]
+    a = oracle.DiffusionConditioning(oracle.Model(src)).latent(mels)
+    b = oracle.DiffusionConditioning(oracle.Model(out + "/ggml-diffusion-conditioning-model.bin")).latent(mels)
+    assert (a == b).all()

@@ -71,3 +71,76 @@ def test_voice_encoder_errors(pkg, venc_models, small_models):
     e.load_voice_encoder(venc_models["small"])
     assert e.voice_latent(_mels(0, (1,))).shape == (1024,)  # a one-frame clip is legal
     e.close()
+
+
+# ---- the other voice latent: diffusion conditioning (100-band mel -> the 2048 floats the reference keeps as a weight) -----------------
+@pytest.fixture(scope="session")
+def dcond_models(pkg):
+    d = os.path.join(os.environ.get("TTS_SYNTH_DIR", "/tmp/tts_synth"), "dcond")
+    os.makedirs(d, exist_ok=True)
+    from tortoise_cpp_amd import synth_weights as sw
+    out = {}
+    for name, blocks in (("small", 2), ("full", 5)):
+        p = os.path.join(d, "ggml-diffusion-conditioning-model-%s.bin" % name)
+        if not os.path.exists(p + ".done"):
+            sw.write_diffusion_conditioning_encoder(p, blocks=blocks, seed=70 + blocks)
+            open(p + ".done", "w").write("ok")
+        out[name] = p
+    return out
+
+
+def _mels100(seed, lens):
+    rs = np.random.RandomState(seed)
+    return [(rs.randn(100, n) * 1.5 - 2.0).astype(np.float32) for n in lens]
+
+
+def test_diffusion_conditioning_oracle_vs_torch(oracle, dcond_models):
+    mels = _mels100(0, (301, 120, 7))  # odd / even lengths through both stride-2 convolutions, a clip shorter than the receptive field
+    o = oracle.DiffusionConditioning(oracle.Model(dcond_models["small"])).latent(mels)
+    t64 = TR.TorchDiffusionConditioning(dcond_models["small"], torch.float64).latent(mels)
+    t32 = TR.TorchDiffusionConditioning(dcond_models["small"]).latent(mels)
+    scale = np.abs(t64).max()
+    assert np.abs(o - t64).max() < 2e-5 * scale and np.abs(t32 - t64).max() < 2e-5 * scale and scale > 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,lens", [("small", (301, 120, 7, 1)), ("full", (938, 517))])
+def test_diffusion_conditioning_engine_vs_oracle(pkg, oracle, dcond_models, which, lens):
+    mels = _mels100(5, lens)
+    e = pkg.Engine(0)
+    e.load_diffusion_conditioning_encoder(dcond_models[which])
+    got = e.diffusion_conditioning_latent(mels)
+    want = oracle.DiffusionConditioning(oracle.Model(dcond_models[which])).latent(mels)
+    err = float(np.abs(got - want).max() / np.abs(want).max())
+    print("diffusion conditioning %s: max err %.1e of range %.2f" % (which, err, np.abs(want).max()))
+    assert np.isfinite(got).all() and err < 3e-3
+    assert (got == e.diffusion_conditioning_latent(mels)).all()
+    e.close()
+
+
+@pytest.mark.gpu
+def test_set_diffusion_conditioning_latent(pkg, small_models, tmp_path):
+    """tts_set_diffusion_conditioning_latent == a weight file with that latent baked in (the reference's only way, main.cpp:1557-1560)."""
+    from tortoise_cpp_amd import synth_weights as sw
+    t = sw.read_ggml(small_models + "/ggml-diffusion-model.bin")
+    rs = np.random.RandomState(8)
+    lat2 = (t["diffusion_conditioning_latent"].reshape(-1) + rs.randn(2048).astype(np.float32) * 0.1).astype(np.float32)
+    path = str(tmp_path / "ggml-diffusion-model-other-voice.bin")
+    w = sw.GgmlWriter(path)
+    for k, v in t.items():
+        w.add(k, lat2.reshape(v.shape) if k == "diffusion_conditioning_latent" else v)
+    w.close()
+    latents = rs.randn(9, 1024).astype(np.float32)
+    x_t = rs.randn(100, pkg.Engine.frames(9)).astype(np.float32)
+    e = pkg.Engine(0)
+    with pytest.raises(pkg.TtsError, match="tts_load_diffusion not called"):
+        e.set_diffusion_conditioning_latent(lat2)
+    e.load(diffusion=small_models + "/ggml-diffusion-model.bin")
+    base = e.diffusion_forward(latents, x_t, 500, False)
+    e.set_diffusion_conditioning_latent(lat2)
+    swapped = e.diffusion_forward(latents, x_t, 500, False)
+    e2 = pkg.Engine(0)
+    e2.load(diffusion=path)
+    baked = e2.diffusion_forward(latents, x_t, 500, False)
+    assert (swapped == baked).all() and not (swapped == base).all()
+    e.close(); e2.close()

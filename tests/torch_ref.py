@@ -372,3 +372,57 @@ class TorchVoiceEncoder:
 
     def latent(self, mels):
         return torch.stack([self.clip(m) for m in mels]).mean(dim=0).to(torch.float64).numpy()
+
+
+
+def _t5_bucket(rel, num_buckets=32, max_distance=64):
+    """x-transformers / T5 bidirectional bucket of rel = k_pos - q_pos (tortoise arch_util.RelativePositionBias._relative_position_bucket)."""
+    import math
+    n = -rel
+    nb = num_buckets // 2
+    ret = (n < 0).long() * nb
+    n = n.abs()
+    max_exact = nb // 2
+    is_small = n < max_exact
+    large = max_exact + (torch.log(n.float().clamp(min=1) / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)).long()
+    large = torch.min(large, torch.full_like(large, nb - 1))
+    return ret + torch.where(is_small, n, large)
+
+
+class TorchDiffusionConditioning:
+    """Upstream DiffusionTts.get_conditioning (contextual_embedder) with torch ops: 100-band mel of the reference clips -> the 2048-float
+    diffusion conditioning latent. Pins oracle.DiffusionConditioning; no reference code exists (the reference reads the latent as a weight)."""
+
+    def __init__(self, path, dtype=torch.float32):
+        from tortoise_cpp_amd import synth_weights as sw
+        self.w = {k: torch.from_numpy(v).to(dtype) for k, v in sw.read_ggml(path).items()}
+        self.dtype = dtype
+        self.blocks = 0
+        while "contextual_embedder.%d.norm.weight" % (2 + self.blocks) in self.w:
+            self.blocks += 1
+
+    def clip(self, mel):  # [100, T] -> [2048, T2]
+        w = self.w
+        h = torch.as_tensor(np.asarray(mel)).to(self.dtype)[None]
+        h = F.conv1d(h, w["contextual_embedder.0.weight"], w["contextual_embedder.0.bias"], stride=2, padding=1)
+        h = F.conv1d(h, w["contextual_embedder.1.weight"], w["contextual_embedder.1.bias"], stride=2, padding=1)
+        n = h.shape[-1]
+        pos = torch.arange(n)
+        bucket = _t5_bucket(pos[None, :] - pos[:, None])  # [q, k]
+        for i in range(self.blocks):
+            p = "contextual_embedder.%d." % (2 + i)
+            y = F.group_norm(h, 32, w[p + "norm.weight"], w[p + "norm.bias"], 1e-5)
+            qkv = F.conv1d(y, w[p + "qkv.weight"], w[p + "qkv.bias"])
+            bs, width, length = qkv.shape
+            ch = width // (3 * 16)
+            q, k, v = qkv.reshape(bs * 16, ch * 3, length).split(ch, dim=1)
+            scale = 1 / (ch ** 0.25)
+            wt = torch.einsum("bct,bcs->bts", q * scale, k * scale)
+            bias = w[p + "relative_pos_embeddings.relative_attention_bias.weight"][bucket].permute(2, 0, 1)  # [h, q, k]
+            wt = torch.softmax(wt + bias * (ch ** 0.5), dim=-1)
+            a = torch.einsum("bts,bcs->bct", wt, v).reshape(bs, -1, length)
+            h = h + F.conv1d(a, w[p + "proj_out.weight"], w[p + "proj_out.bias"])
+        return h[0]
+
+    def latent(self, mels):
+        return torch.cat([self.clip(m) for m in mels], dim=-1).mean(dim=-1).to(torch.float64).numpy()

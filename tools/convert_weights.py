@@ -183,6 +183,21 @@ def convert_conditioning_encoder(sd, path):
     return n
 
 
+def convert_diffusion_conditioning_encoder(sd, path):
+    """ggml-diffusion-conditioning-model.bin for tts_load_diffusion_conditioning_encoder: the `contextual_embedder.*` tensors of upstream
+    tortoise-tts' diffusion_decoder.pth (left out of ggml-diffusion-model.bin, which carries one voice's finished latent instead)."""
+    w = GgmlWriter(path)
+    n = 0
+    for k in sorted(sd):
+        if k.startswith("contextual_embedder."):
+            w.add(k, _np(sd[k]))
+            n += k.endswith(".norm.weight")
+    w.close()
+    if n == 0:
+        raise SystemExit("convert_diffusion_conditioning_encoder: no contextual_embedder.* tensors in the checkpoint")
+    return n
+
+
 def convert_clvp(sd, path):
     """ggml-clvp-model.bin for tts_load_clvp: upstream tortoise-tts CLVP (clvp2.pth, use_xformers=True), tensors under their state-dict names.
     Kept: embeddings, latent projections, temperature (0-dim -> [1]), every `*.attn_layers.layers.N.{0.g, 1.*}` parameter and the final norms;
@@ -214,6 +229,8 @@ def main():
     ap.add_argument("--vocoder")
     ap.add_argument("--conditioning-encoder", action="store_true", help="with --ar: also write ggml-conditioning-model.bin (the checkpoint's "
                                                                          "conditioning_encoder.* tensors: mel -> voice latent, tts_load_voice_encoder; not in the reference)")
+    ap.add_argument("--diffusion-conditioning-encoder", help="diffusion_decoder.pth -> ggml-diffusion-conditioning-model.bin (its contextual_embedder.* tensors: "
+                                                              "100-band mel -> the diffusion conditioning latent, tts_load_diffusion_conditioning_encoder; not in the reference)")
     ap.add_argument("--clvp", help="clvp2.pth of upstream tortoise-tts -> ggml-clvp-model.bin (candidate re-ranking, tts_load_clvp; not in the reference)")
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
@@ -232,6 +249,9 @@ def main():
         lat = np.load(p) if p.endswith(".npy") else load(p) if p.endswith((".pth", ".pt")) else np.fromfile(p, np.float32)
         print("ggml-diffusion-model.bin: blocks (latent conditioner, integrator, main, tail) = %s"
               % (convert_diffusion(load(a.diffusion), lat, os.path.join(a.out, "ggml-diffusion-model.bin")),))
+    if a.diffusion_conditioning_encoder:
+        print("ggml-diffusion-conditioning-model.bin: %d attention blocks"
+              % convert_diffusion_conditioning_encoder(load(a.diffusion_conditioning_encoder), os.path.join(a.out, "ggml-diffusion-conditioning-model.bin")))
     if a.clvp:
         print("ggml-clvp-model.bin: %d encoder layers" % convert_clvp(load(a.clvp), os.path.join(a.out, "ggml-clvp-model.bin")))
     if a.vocoder:

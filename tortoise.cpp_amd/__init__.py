@@ -49,6 +49,8 @@ def lib():
         "tts_set_option": (ci, [vp, C.c_char_p, C.c_double]),
         "tts_load_ar": (ci, [vp, C.c_char_p]), "tts_load_diffusion": (ci, [vp, C.c_char_p]),
         "tts_load_vocoder": (ci, [vp, C.c_char_p]), "tts_load_clvp": (ci, [vp, C.c_char_p]),
+        "tts_load_diffusion_conditioning_encoder": (ci, [vp, C.c_char_p]), "tts_diffusion_conditioning_latent": (ci, [vp, _f32p, _i32p, ci, _f32p]),
+        "tts_set_diffusion_conditioning_latent": (ci, [vp, _f32p]),
         "tts_load_voice_encoder": (ci, [vp, C.c_char_p]), "tts_voice_latent": (ci, [vp, _f32p, _i32p, ci, _f32p]),
         "tts_clvp_score": (ci, [vp, _i32p, ci, _i32p, _i32p, ci, ci, _f32p]), "tts_ar_layers": (ci, [vp]), "tts_diffusion_layers": (ci, [vp]),
         "tts_seed": (None, [vp, C.c_uint32]), "tts_rng_load_state": (ci, [vp, C.c_char_p]), "tts_rng_save_state": (ci, [vp, C.c_char_p]),
@@ -221,6 +223,20 @@ class Engine:
         out = np.empty(1024, np.float32)
         self._ck(self.L.tts_voice_latent(self.h, mel, frames, len(mels), out))
         return out
+
+    def load_diffusion_conditioning_encoder(self, path):
+        self._ck(self.L.tts_load_diffusion_conditioning_encoder(self.h, path.encode()))
+
+    def diffusion_conditioning_latent(self, mels):
+        """mels: list of [100, T_c] mel spectrograms of the reference clips. Returns the 2048-float diffusion conditioning latent."""
+        frames = np.array([m.shape[1] for m in mels], np.int32)
+        mel = np.ascontiguousarray(np.concatenate([np.asarray(m, np.float32).reshape(-1) for m in mels]))
+        out = np.empty(2048, np.float32)
+        self._ck(self.L.tts_diffusion_conditioning_latent(self.h, mel, frames, len(mels), out))
+        return out
+
+    def set_diffusion_conditioning_latent(self, latent):
+        self._ck(self.L.tts_set_diffusion_conditioning_latent(self.h, np.ascontiguousarray(latent, np.float32).reshape(2048)))
 
     # ---- candidate re-ranking (not in the reference) ----
     def load_clvp(self, path):

@@ -80,6 +80,7 @@ void tts_destroy(tts_ctx *c) {
   if (c->voc) voc_free(c->voc);
   if (c->clvp) clvp_free(c->clvp);
   if (c->venc) voice_enc_free(c->venc);
+  if (c->dcond) diff_cond_enc_free(c->dcond);
   delete c->tok;
   for (auto &kv : c->prof)
     for (auto &pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -122,7 +123,7 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
     // hipExtStreamCreateWithCUMask on gfx950: bit i = XCD i % 8, CU slot i / 8 (tools/cu_mask_probe.hip); an XCD with no bit set is
     // unrestricted, so every XCD keeps at least one CU. Only before any model is loaded / graph captured on the old stream.
     if (c->device < 0) return fail(c, TTS_ERR_HIP, "host-only context: no stream");
-    if (c->ar || c->diff || c->voc || c->clvp || c->venc) return fail(c, TTS_ERR_STATE, "stream_cus must be set before the models are loaded");
+    if (c->ar || c->diff || c->voc || c->clvp || c->venc || c->dcond) return fail(c, TTS_ERR_STATE, "stream_cus must be set before the models are loaded");
     (void)hipSetDevice(c->device);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) return fail(c, TTS_ERR_HIP, "hipGetDeviceProperties failed");
@@ -160,6 +161,12 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
 int tts_load_ar(tts_ctx *c, const char *path) { NEED_CTX(c); return guarded(c, [&] { return ar_load(c, path); }); }
 int tts_load_diffusion(tts_ctx *c, const char *path) { NEED_CTX(c); return guarded(c, [&] { return diff_load(c, path); }); }
 int tts_load_vocoder(tts_ctx *c, const char *path) { NEED_CTX(c); return guarded(c, [&] { return voc_load(c, path); }); }
+int tts_load_diffusion_conditioning_encoder(tts_ctx *c, const char *path) { NEED_CTX(c); return guarded(c, [&] { return diff_cond_enc_load(c, path); }); }
+int tts_diffusion_conditioning_latent(tts_ctx *c, const float *mel, const int32_t *frames, int n_clips, float *out2048) {
+  NEED_CTX(c);
+  return guarded(c, [&] { return diff_cond_enc_latent(c, mel, frames, n_clips, out2048); });
+}
+int tts_set_diffusion_conditioning_latent(tts_ctx *c, const float *latent2048) { NEED_CTX(c); return guarded(c, [&] { return diff_set_cond_latent(c, latent2048); }); }
 int tts_load_voice_encoder(tts_ctx *c, const char *path) { NEED_CTX(c); return guarded(c, [&] { return voice_enc_load(c, path); }); }
 int tts_voice_latent(tts_ctx *c, const float *mel, const int32_t *frames, int n_clips, float *out1024) {
   NEED_CTX(c);

@@ -25,7 +25,7 @@
 namespace tts {
 
 namespace {
-constexpr int CLVP_DH = 64, CLVP_KCHUNK = 128; // head dim (the first 32 carry the rotary embedding), keys per LDS stage
+constexpr int CLVP_DH = 64; // head dim of CLVP and of the voice encoder (the first 32 carry CLVP's rotary embedding)
 
 __global__ __launch_bounds__(256) void clvp_embed_kernel(const float *__restrict__ emb, const int *__restrict__ tok, int dim, float *__restrict__ x) {
   const float *src = emb + (size_t)tok[blockIdx.x] * dim;
@@ -53,10 +53,15 @@ __global__ __launch_bounds__(256) void clvp_rmsnorm_kernel(const float *__restri
 
 // One workgroup = 256 queries of one (sequence, head); a thread owns one query (q and the output row in registers, f32), the keys stream
 // through LDS in chunks of 128 (K rotated on the way in). qkv: fp16 [row][3 inner] = q | k | v, head h at columns h*64.
-template <bool ROT> // ROT: CLVP's rotary embedding on the first 32 head dims; false: plain softmax(q k^T / 8) v (voice encoder)
+// ROT: CLVP's rotary embedding on the first 32 head dims. DH: head dim (64, or 128 for the diffusion conditioning encoder). BIAS: relative
+// position bias by signed key - query distance (T5 buckets expanded per distance at load, saturated at +-63, already multiplied by sqrt(DH)):
+// bias_tab[head][(query < key) * 64 + min(|key - query|, 63)].
+template <bool ROT, int DH, bool BIAS>
 __global__ __launch_bounds__(256) void clvp_attn_kernel(const __half *__restrict__ qkv, const int *__restrict__ seq_start, const int *__restrict__ seq_len,
-                                                        int inner, __half *__restrict__ out) {
-  __shared__ __half sk[CLVP_KCHUNK][CLVP_DH], sv[CLVP_KCHUNK][CLVP_DH];
+                                                        int inner, __half *__restrict__ out, const float *__restrict__ bias_tab) {
+  constexpr int KC = 8192 / DH, PARTS = DH / 32; // keys per LDS stage (32 KB for K and V together), 32-dim parts per key
+  __shared__ __half sk[KC][DH], sv[KC][DH];
+  __shared__ float stab[128];
   const int s = blockIdx.x, h = blockIdx.y, n = seq_len[s], r0 = seq_start[s];
   const int qi = blockIdx.z * 256 + threadIdx.x;
   if (blockIdx.z * 256 >= n) return;
@@ -70,49 +75,55 @@ __global__ __launch_bounds__(256) void clvp_attn_kernel(const __half *__restrict
       t[d + 16] = b * c + a * sn;
     }
   };
-  float q[CLVP_DH], acc[CLVP_DH];
+  if (BIAS && threadIdx.x < 128) stab[threadIdx.x] = bias_tab[h * 128 + threadIdx.x];
+  float q[DH], acc[DH];
   const bool live = qi < n;
   {
-    const __half *qp = qkv + (size_t)(r0 + (live ? qi : 0)) * ld + h * CLVP_DH;
+    const __half *qp = qkv + (size_t)(r0 + (live ? qi : 0)) * ld + h * DH;
 #pragma unroll
-    for (int d = 0; d < CLVP_DH; d++) { q[d] = __half2float(qp[d]); acc[d] = 0.f; }
+    for (int d = 0; d < DH; d++) { q[d] = __half2float(qp[d]); acc[d] = 0.f; }
     if (ROT) rot(q, live ? qi : 0);
   }
+  const float scale = DH == 64 ? 0.125f : 0.08838834764831845f; // 1 / sqrt(DH)
   float m = -INFINITY, l = 0.f;
-  for (int k0 = 0; k0 < n; k0 += CLVP_KCHUNK) {
+  for (int k0 = 0; k0 < n; k0 += KC) {
     __syncthreads();
-    { // 256 threads stage 128 keys: thread t -> key t >> 1, dims (t & 1) * 32 .. + 31 (the rotated half is dims 0..31: one thread owns it)
-      const int kj = threadIdx.x >> 1, half = threadIdx.x & 1, key = k0 + kj;
+    { // 256 threads stage KC keys: thread t -> key t / PARTS, dims (t % PARTS) * 32 .. + 31 (the rotated dims 0..31 belong to ONE thread)
+      const int kj = threadIdx.x / PARTS, part = threadIdx.x % PARTS, key = k0 + kj;
       if (key < n) {
-        const __half *kp = qkv + (size_t)(r0 + key) * ld + inner + h * CLVP_DH + half * 32;
-        const __half *vp = qkv + (size_t)(r0 + key) * ld + 2 * inner + h * CLVP_DH + half * 32;
+        const __half *kp = qkv + (size_t)(r0 + key) * ld + inner + h * DH + part * 32;
+        const __half *vp = qkv + (size_t)(r0 + key) * ld + 2 * inner + h * DH + part * 32;
         float t[32];
 #pragma unroll
         for (int d = 0; d < 32; d++) t[d] = __half2float(kp[d]);
-        if (ROT && half == 0) rot(t, key);
+        if (ROT && part == 0) rot(t, key);
 #pragma unroll
-        for (int d = 0; d < 32; d++) { sk[kj][half * 32 + d] = __float2half_rn(t[d]); sv[kj][half * 32 + d] = vp[d]; }
+        for (int d = 0; d < 32; d++) { sk[kj][part * 32 + d] = __float2half_rn(t[d]); sv[kj][part * 32 + d] = vp[d]; }
       }
     }
     __syncthreads();
-    const int kn = min(CLVP_KCHUNK, n - k0);
+    const int kn = min(KC, n - k0);
     for (int j = 0; j < kn; j++) {
       float sc = 0.f;
 #pragma unroll
-      for (int d = 0; d < CLVP_DH; d++) sc += q[d] * __half2float(sk[j][d]);
-      sc *= 0.125f;
+      for (int d = 0; d < DH; d++) sc += q[d] * __half2float(sk[j][d]);
+      sc *= scale;
+      if (BIAS) {
+        const int dist = k0 + j - qi, ad = dist < 0 ? -dist : dist;
+        sc += stab[(dist > 0 ? 64 : 0) + (ad < 63 ? ad : 63)];
+      }
       const float mn = fmaxf(m, sc), a = expf(m - mn), p = expf(sc - mn);
       l = l * a + p;
 #pragma unroll
-      for (int d = 0; d < CLVP_DH; d++) acc[d] = acc[d] * a + p * __half2float(sv[j][d]);
+      for (int d = 0; d < DH; d++) acc[d] = acc[d] * a + p * __half2float(sv[j][d]);
       m = mn;
     }
   }
   if (live) {
     const float inv = 1.0f / l;
-    __half *op = out + (size_t)(r0 + qi) * inner + h * CLVP_DH;
+    __half *op = out + (size_t)(r0 + qi) * inner + h * DH;
 #pragma unroll
-    for (int d = 0; d < CLVP_DH; d++) op[d] = __float2half_rn(acc[d] * inv);
+    for (int d = 0; d < DH; d++) op[d] = __float2half_rn(acc[d] * inv);
   }
 }
 
@@ -153,20 +164,41 @@ __global__ __launch_bounds__(128) void venc_mel_rows_kernel(const float *__restr
   a16[(size_t)(seq_start[s] + t) * 128 + c] = __float2half_rn(c < 80 ? mel[mel_off[s] + (size_t)c * T + t] : 0.f);
 }
 
-// GroupNorm(32 groups of 32 channels, eps 1e-5, statistics over the whole clip) -> fp16; one workgroup per (clip, group)
+// GroupNorm(32 groups of D / 32 channels, eps 1e-5, statistics over the whole clip) -> fp16; one workgroup per (clip, group)
+template <int D>
 __global__ __launch_bounds__(256) void venc_groupnorm_kernel(const float *__restrict__ x, const int *__restrict__ seq_start, const int *__restrict__ seq_len,
                                                              const float *__restrict__ g, const float *__restrict__ b, __half *__restrict__ y) {
+  constexpr int G = D / 32, SW = 256 / G; // channels per group, rows per sweep
   __shared__ float red[4];
   const int s = blockIdx.y, grp = blockIdx.x, T = seq_len[s], r0 = seq_start[s];
-  const int c = grp * 32 + (threadIdx.x & 31), t0 = threadIdx.x >> 5; // 8 rows per sweep
+  const int c = grp * G + (threadIdx.x % G), t0 = threadIdx.x / G;
   float sum = 0.f;
-  for (int t = t0; t < T; t += 8) sum += x[(size_t)(r0 + t) * 1024 + c];
-  const float mean = block_sum(sum, red) / (32.f * T);
+  for (int t = t0; t < T; t += SW) sum += x[(size_t)(r0 + t) * D + c];
+  const float mean = block_sum(sum, red) / ((float)G * T);
   float sq = 0.f;
-  for (int t = t0; t < T; t += 8) { const float d = x[(size_t)(r0 + t) * 1024 + c] - mean; sq += d * d; }
-  const float rstd = rsqrtf(block_sum(sq, red) / (32.f * T) + 1e-5f);
+  for (int t = t0; t < T; t += SW) { const float d = x[(size_t)(r0 + t) * D + c] - mean; sq += d * d; }
+  const float rstd = rsqrtf(block_sum(sq, red) / ((float)G * T) + 1e-5f);
   const float gg = g[c], bb = b[c];
-  for (int t = t0; t < T; t += 8) y[(size_t)(r0 + t) * 1024 + c] = __float2half_rn((x[(size_t)(r0 + t) * 1024 + c] - mean) * rstd * gg + bb);
+  for (int t = t0; t < T; t += SW) y[(size_t)(r0 + t) * D + c] = __float2half_rn((x[(size_t)(r0 + t) * D + c] - mean) * rstd * gg + bb);
+}
+
+// im2col of a k = 3, stride 2, padding 1 convolution over the frames of every clip: output row (clip, t) = [x[2t-1] | x[2t] | x[2t+1]] (zeros outside
+// the clip), fp16, row length kpad >= 3 cin (zero padded). CM: the input is the caller's channel-major mel [cin][T] per clip (mel_off),
+// otherwise f32 rows [row][cin] laid out by (in_start, in_len).
+template <bool CM>
+__global__ __launch_bounds__(256) void dcond_im2col_kernel(const float *__restrict__ x, const long long *__restrict__ mel_off, const int *__restrict__ in_start,
+                                                           const int *__restrict__ in_len, const int *__restrict__ out_start, const int *__restrict__ out_len,
+                                                           int cin, int kpad, __half *__restrict__ a16) {
+  const int s = blockIdx.y, t = blockIdx.x;
+  if (t >= out_len[s]) return;
+  const int Tin = in_len[s];
+  __half *dst = a16 + (size_t)(out_start[s] + t) * kpad;
+  for (int k = threadIdx.x; k < kpad; k += 256) {
+    const int tap = k / cin, c = k - tap * cin, ti = 2 * t + tap - 1;
+    float v = 0.f;
+    if (tap < 3 && ti >= 0 && ti < Tin) v = CM ? x[mel_off[s] + (size_t)c * Tin + ti] : x[(size_t)(in_start[s] + ti) * cin + c];
+    dst[k] = __float2half_rn(v);
+  }
 }
 } // namespace
 
@@ -315,7 +347,7 @@ static int clvp_encode(tts_ctx *ctx, ClvpState *st, int e, const std::vector<int
     ProfScope ps(ctx, "clvp_layer", 2.0 * rows * ((double)d * 3 * in + (double)in * d + (double)d * 2 * ff + (double)ff * d));
     clvp_rmsnorm_kernel<<<rows, 256, 0, ctx->stream>>>(x, l.g_attn, d, y);
     { GemmArgs g = gemm(y, d, l.w_qkv, 3 * in, nullptr); g.mode = GEMM_OUT_F16; g.outH = qkv; g.ldh = 3 * in; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
-    clvp_attn_kernel<true><<<dim3(nseq, in / CLVP_DH, (maxlen + 255) / 256), 256, 0, ctx->stream>>>(qkv, d_start, d_len, in, att);
+    clvp_attn_kernel<true, 64, false><<<dim3(nseq, in / CLVP_DH, (maxlen + 255) / 256), 256, 0, ctx->stream>>>(qkv, d_start, d_len, in, att, nullptr);
     { GemmArgs g = gemm(att, in, l.w_out, d, l.b_out); g.mode = GEMM_OUT_F32; g.outF = x; g.ldo = d; g.resid = x; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
     clvp_rmsnorm_kernel<<<rows, 256, 0, ctx->stream>>>(x, l.g_ff, d, y);
     { GemmArgs g = gemm(y, d, l.w_ff1, 2 * ff, l.b_ff1); g.mode = GEMM_OUT_F32; g.outF = u; g.ldo = 2 * ff; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
@@ -497,9 +529,9 @@ int voice_enc_latent(tts_ctx *ctx, const float *mel, const int32_t *frames, int 
   };
   { GemmArgs g = gemm(a16, 128, st->w_init, D, st->b_init); g.mode = GEMM_OUT_F32; g.outF = x; g.ldo = D; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
   for (const VencBlock &b : st->blk) {
-    venc_groupnorm_kernel<<<dim3(32, n_clips), 256, 0, ctx->stream>>>(x, d_start, d_len, b.g, b.b, y);
+    venc_groupnorm_kernel<1024><<<dim3(32, n_clips), 256, 0, ctx->stream>>>(x, d_start, d_len, b.g, b.b, y);
     { GemmArgs g = gemm(y, D, b.w_qkv, 3 * D, b.b_qkv); g.mode = GEMM_OUT_F16; g.outH = qkv; g.ldh = 3 * D; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
-    clvp_attn_kernel<false><<<dim3(n_clips, D / CLVP_DH, (maxlen + 255) / 256), 256, 0, ctx->stream>>>(qkv, d_start, d_len, D, att);
+    clvp_attn_kernel<false, 64, false><<<dim3(n_clips, D / CLVP_DH, (maxlen + 255) / 256), 256, 0, ctx->stream>>>(qkv, d_start, d_len, D, att, nullptr);
     { GemmArgs g = gemm(att, D, b.w_proj, D, b.b_proj); g.mode = GEMM_OUT_F32; g.outF = x; g.ldo = D; g.resid = x; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
   }
   TTS_HIP(ctx, hipGetLastError());
@@ -512,6 +544,175 @@ int voice_enc_latent(tts_ctx *ctx, const float *mel, const int32_t *frames, int 
     double a = 0;
     for (int s = 0; s < n_clips; s++) a += first[(size_t)s * D + c];
     out1024[c] = (float)(a / n_clips);
+  }
+  return TTS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// diffusion conditioning encoder (the other half of SURVEY 8 f3): upstream DiffusionTts.get_conditioning. 100-band mel of the reference clips
+// -> the 2048 floats the reference reads as the weight `diffusion_conditioning_latent` of ggml-diffusion-model.bin (main.cpp:1557-1560).
+// Two k = 3 / stride 2 convolutions (im2col + GEMM), five attention blocks with 2048 channels (16 heads of 128, relative position bias),
+// mean over the frames of all clips.
+// ------------------------------------------------------------------------------------------------------------------------------
+struct DcondBlock {
+  float *g = nullptr, *b = nullptr, *b_qkv = nullptr, *b_proj = nullptr, *bias_tab = nullptr;
+  __half *w_qkv = nullptr, *w_proj = nullptr;
+};
+struct DiffCondEncState {
+  __half *w0 = nullptr, *w1 = nullptr; // [1024][320] (K = 3 x 100 padded), [2048][3072]
+  float *b0 = nullptr, *b1 = nullptr;
+  std::vector<DcondBlock> blk;
+  std::vector<void *> owned;
+  DevBuf h1, x, y16, qkv16, att16, a16, meta, mel;
+  ~DiffCondEncState() { for (void *p : owned) (void)hipFree(p); }
+};
+void diff_cond_enc_free(DiffCondEncState *s) { delete s; }
+
+template <class T> static int dcond_up(tts_ctx *ctx, DiffCondEncState *st, const std::vector<T> &src, T **dst) {
+  void *p = nullptr;
+  TTS_HIP(ctx, hipMalloc(&p, src.size() * sizeof(T)));
+  st->owned.push_back(p);
+  TTS_HIP(ctx, hipMemcpy(p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dst = (T *)p;
+  return TTS_OK;
+}
+// Conv1d weight [cout][cin][3] -> GEMM weight [cout][kpad], k = tap * cin + c (the im2col order), fp16
+static std::vector<__half> dcond_conv_weight(const std::vector<float> &w, int cout, int cin, int kpad) {
+  std::vector<__half> o((size_t)cout * kpad, __float2half_rn(0.f));
+  for (int n = 0; n < cout; n++)
+    for (int c = 0; c < cin; c++)
+      for (int tap = 0; tap < 3; tap++) o[(size_t)n * kpad + tap * cin + c] = __float2half_rn(w[((size_t)n * cin + c) * 3 + tap]);
+  return o;
+}
+
+int diff_cond_enc_load(tts_ctx *ctx, const char *path) {
+  WeightFile wf;
+  std::string err;
+  int rc = read_weight_file(path, wf, err);
+  if (rc != TTS_OK) return fail(ctx, rc, "diffusion_conditioning_encoder_load: %s", err.c_str());
+  constexpr int D = 2048, H = 16, DH = 128;
+  auto get = [&](const std::string &name, int64_t nelem) -> const HostTensor * {
+    auto it = wf.t.find(name);
+    if (it == wf.t.end()) { fail(ctx, TTS_ERR_FORMAT, "tensor '%s' missing from the diffusion-conditioning-encoder file", name.c_str()); return nullptr; }
+    if (it->second.nelem() != nelem) { fail(ctx, TTS_ERR_FORMAT, "tensor '%s' has %d elements, %d expected", name.c_str(), (int)it->second.nelem(), (int)nelem); return nullptr; }
+    return &it->second;
+  };
+  if (!wf.has("contextual_embedder.0.weight")) return fail(ctx, TTS_ERR_FORMAT, "'%s' is not a diffusion-conditioning-encoder file", path);
+  std::unique_ptr<DiffCondEncState> st(new DiffCondEncState());
+  const HostTensor *w0, *b0, *w1, *b1;
+  if (!(w0 = get("contextual_embedder.0.weight", 1024 * 100 * 3)) || !(b0 = get("contextual_embedder.0.bias", 1024)) ||
+      !(w1 = get("contextual_embedder.1.weight", (int64_t)D * 1024 * 3)) || !(b1 = get("contextual_embedder.1.bias", D)))
+    return TTS_ERR_FORMAT;
+  if ((rc = dcond_up(ctx, st.get(), dcond_conv_weight(w0->data, 1024, 100, 320), &st->w0)) || (rc = dcond_up(ctx, st.get(), b0->data, &st->b0)) ||
+      (rc = dcond_up(ctx, st.get(), dcond_conv_weight(w1->data, D, 1024, 3072), &st->w1)) || (rc = dcond_up(ctx, st.get(), b1->data, &st->b1)))
+    return rc;
+  size_t known = 4;
+  for (int i = 0; wf.has("contextual_embedder." + std::to_string(2 + i) + ".norm.weight"); i++) {
+    const std::string p = "contextual_embedder." + std::to_string(2 + i) + ".";
+    DcondBlock b;
+    const HostTensor *g, *gb, *qw, *qb, *pw, *pb, *rp;
+    if (!(g = get(p + "norm.weight", D)) || !(gb = get(p + "norm.bias", D)) || !(qw = get(p + "qkv.weight", (int64_t)3 * D * D)) || !(qb = get(p + "qkv.bias", 3 * D)) ||
+        !(pw = get(p + "proj_out.weight", (int64_t)D * D)) || !(pb = get(p + "proj_out.bias", D)) ||
+        !(rp = get(p + "relative_pos_embeddings.relative_attention_bias.weight", 32 * H)))
+      return TTS_ERR_FORMAT;
+    // QKVAttentionLegacy rows (head * 3 DH + {q, k, v} * DH + d) -> q | k | v blocks with head h at columns h * DH
+    std::vector<__half> w((size_t)3 * D * D);
+    std::vector<float> bq(3 * D);
+    for (int h = 0; h < H; h++)
+      for (int tq = 0; tq < 3; tq++)
+        for (int d = 0; d < DH; d++) {
+          const int o = h * 3 * DH + tq * DH + d, n = tq * D + h * DH + d;
+          bq[n] = qb->data[o];
+          for (int k = 0; k < D; k++) w[(size_t)n * D + k] = __float2half_rn(qw->data[(size_t)o * D + k]);
+        }
+    std::vector<__half> wp((size_t)D * D);
+    for (size_t k = 0; k < wp.size(); k++) wp[k] = __float2half_rn(pw->data[k]);
+    // bias by signed distance (rel_bucket(i = query, c = key): main.cpp:4722-4749 is the same T5 rule), x sqrt(head dim) as upstream's RelativePositionBias scale
+    std::vector<float> tab((size_t)H * 128);
+    for (int h = 0; h < H; h++)
+      for (int sgn = 0; sgn < 2; sgn++)
+        for (int ad = 0; ad < 64; ad++)
+          tab[(size_t)h * 128 + sgn * 64 + ad] = rp->data[(size_t)rel_bucket(sgn ? 0 : ad, sgn ? ad : 0) * H + h] * 11.313708498984761f;
+    if ((rc = dcond_up(ctx, st.get(), g->data, &b.g)) || (rc = dcond_up(ctx, st.get(), gb->data, &b.b)) || (rc = dcond_up(ctx, st.get(), w, &b.w_qkv)) ||
+        (rc = dcond_up(ctx, st.get(), bq, &b.b_qkv)) || (rc = dcond_up(ctx, st.get(), wp, &b.w_proj)) || (rc = dcond_up(ctx, st.get(), pb->data, &b.b_proj)) ||
+        (rc = dcond_up(ctx, st.get(), tab, &b.bias_tab)))
+      return rc;
+    st->blk.push_back(b);
+    known += 7;
+  }
+  if (st->blk.empty()) return fail(ctx, TTS_ERR_FORMAT, "no attention blocks in '%s'", path);
+  if (wf.t.size() != known) return fail(ctx, TTS_ERR_FORMAT, "unknown tensors in diffusion-conditioning-encoder file '%s' (%d tensors, %d expected)", path, (int)wf.t.size(), (int)known);
+  if (ctx->dcond) diff_cond_enc_free(ctx->dcond);
+  ctx->dcond = st.release();
+  return TTS_OK;
+}
+
+int diff_cond_enc_latent(tts_ctx *ctx, const float *mel, const int32_t *frames, int n_clips, float *out2048) {
+  DiffCondEncState *st = ctx->dcond;
+  if (!st) return fail(ctx, TTS_ERR_STATE, "tts_load_diffusion_conditioning_encoder not called");
+  if (!mel || !frames || n_clips < 1 || !out2048) return fail(ctx, TTS_ERR_ARG, "tts_diffusion_conditioning_latent: bad arguments");
+  constexpr int D = 2048;
+  // three row layouts: the mel frames (T), after the first convolution (T1 = (T - 1) / 2 + 1), after the second (T2)
+  std::vector<int> meta(6 * n_clips);
+  std::vector<long long> moff(n_clips);
+  int r1 = 0, r2 = 0, max0 = 0;
+  long long off = 0;
+  for (int s = 0; s < n_clips; s++) {
+    if (frames[s] < 1 || frames[s] > 16384) return fail(ctx, TTS_ERR_ARG, "clip %d: %d mel frames (1 .. 16384 expected)", s, frames[s]);
+    const int T1 = (frames[s] - 1) / 2 + 1, T2 = (T1 - 1) / 2 + 1;
+    meta[s] = 0; meta[n_clips + s] = frames[s];             // input of conv 0 (channel-major mel: start unused)
+    meta[2 * n_clips + s] = r1; meta[3 * n_clips + s] = T1; // rows of h1
+    meta[4 * n_clips + s] = r2; meta[5 * n_clips + s] = T2; // rows of x
+    moff[s] = off;
+    off += (long long)100 * frames[s]; r1 += T1; r2 += T2; max0 = std::max(max0, frames[s]);
+  }
+  const int max1 = (max0 - 1) / 2 + 1, max2 = (max1 - 1) / 2 + 1;
+  const int M1 = (r1 + 127) / 128 * 128, M2 = (r2 + 127) / 128 * 128;
+  TTS_HIP(ctx, st->h1.reserve((size_t)M1 * 1024 * 4));
+  TTS_HIP(ctx, st->x.reserve((size_t)M2 * D * 4));
+  TTS_HIP(ctx, st->a16.reserve((size_t)std::max((size_t)M1 * 320, (size_t)M2 * 3072) * 2));
+  TTS_HIP(ctx, st->y16.reserve((size_t)M2 * D * 2));
+  TTS_HIP(ctx, st->qkv16.reserve((size_t)M2 * 3 * D * 2));
+  TTS_HIP(ctx, st->att16.reserve((size_t)M2 * D * 2));
+  TTS_HIP(ctx, st->meta.reserve((size_t)6 * n_clips * 4 + (size_t)n_clips * 8 + 16));
+  TTS_HIP(ctx, st->mel.reserve((size_t)off * 4));
+  int *dm = st->meta.as<int>();
+  long long *d_moff = (long long *)(st->meta.as<char>() + (((size_t)6 * n_clips * 4 + 7) & ~(size_t)7));
+  TTS_HIP(ctx, hipMemcpyAsync(dm, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  TTS_HIP(ctx, hipMemcpyAsync(d_moff, moff.data(), moff.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  TTS_HIP(ctx, hipMemcpyAsync(st->mel.p, mel, (size_t)off * 4, hipMemcpyHostToDevice, ctx->stream));
+  float *h1 = st->h1.as<float>(), *x = st->x.as<float>();
+  __half *a16 = st->a16.as<__half>(), *y = st->y16.as<__half>(), *qkv = st->qkv16.as<__half>(), *att = st->att16.as<__half>();
+  auto gemm = [&](const __half *A, int K, const __half *W, int M, int N, const float *bias) {
+    GemmArgs g{};
+    for (int i = 0; i < 3; i++) { g.A[i] = A; g.row_off[i] = 0; }
+    g.nseg = 1; g.kseg = K; g.lda = K; g.W = W; g.M = M; g.N = N; g.bias = bias;
+    return g;
+  };
+  // rows past the last frame of a layout are multiplied like the others and never read back: keep them finite
+  TTS_HIP(ctx, hipMemsetAsync(a16, 0, (size_t)M1 * 320 * 2, ctx->stream));
+  dcond_im2col_kernel<true><<<dim3(max1, n_clips), 256, 0, ctx->stream>>>(st->mel.as<float>(), d_moff, dm, dm + n_clips, dm + 2 * n_clips, dm + 3 * n_clips, 100, 320, a16);
+  { GemmArgs g = gemm(a16, 320, st->w0, M1, 1024, st->b0); g.mode = GEMM_OUT_F32; g.outF = h1; g.ldo = 1024; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
+  TTS_HIP(ctx, hipMemsetAsync(a16, 0, (size_t)M2 * 3072 * 2, ctx->stream));
+  dcond_im2col_kernel<false><<<dim3(max2, n_clips), 256, 0, ctx->stream>>>(h1, d_moff, dm + 2 * n_clips, dm + 3 * n_clips, dm + 4 * n_clips, dm + 5 * n_clips, 1024, 3072, a16);
+  { GemmArgs g = gemm(a16, 3072, st->w1, M2, D, st->b1); g.mode = GEMM_OUT_F32; g.outF = x; g.ldo = D; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
+  TTS_HIP(ctx, hipMemsetAsync(y, 0, (size_t)M2 * D * 2, ctx->stream));
+  TTS_HIP(ctx, hipMemsetAsync(att, 0, (size_t)M2 * D * 2, ctx->stream));
+  const int *d_start = dm + 4 * n_clips, *d_len = dm + 5 * n_clips;
+  for (const DcondBlock &b : st->blk) {
+    venc_groupnorm_kernel<2048><<<dim3(32, n_clips), 256, 0, ctx->stream>>>(x, d_start, d_len, b.g, b.b, y);
+    { GemmArgs g = gemm(y, D, b.w_qkv, M2, 3 * D, b.b_qkv); g.mode = GEMM_OUT_F16; g.outH = qkv; g.ldh = 3 * D; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
+    clvp_attn_kernel<false, 128, true><<<dim3(n_clips, 16, (max2 + 255) / 256), 256, 0, ctx->stream>>>(qkv, d_start, d_len, D, att, b.bias_tab);
+    { GemmArgs g = gemm(att, D, b.w_proj, M2, D, b.b_proj); g.mode = GEMM_OUT_F32; g.outF = x; g.ldo = D; g.resid = x; TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream)); }
+  }
+  TTS_HIP(ctx, hipGetLastError());
+  std::vector<float> hx((size_t)r2 * D); // the layouts have no gaps: rows 0 .. r2 - 1 are the frames of all clips
+  TTS_HIP(ctx, hipMemcpyAsync(hx.data(), x, hx.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+  TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int c = 0; c < D; c++) {
+    double a = 0;
+    for (int r = 0; r < r2; r++) a += hx[(size_t)r * D + c];
+    out2048[c] = (float)(a / r2);
   }
   return TTS_OK;
 }

@@ -54,6 +54,7 @@ struct DiffState;
 struct VocState;
 struct ClvpState;
 struct VoiceEncState;
+struct DiffCondEncState;
 struct Tokenizer;
 struct SamplerPool;
 void sampler_pool_free(SamplerPool *p);
@@ -79,6 +80,7 @@ struct tts_ctx {
   tts::VocState *voc = nullptr;
   tts::ClvpState *clvp = nullptr; // candidate re-ranker (clvp.hip; not in the reference)
   tts::VoiceEncState *venc = nullptr; // voice-conditioning encoder (clvp.hip; not in the reference)
+  tts::DiffCondEncState *dcond = nullptr; // diffusion conditioning encoder (clvp.hip; not in the reference)
   tts::Tokenizer *tok = nullptr;
   tts::SamplerPool *sampler_pool = nullptr; // worker threads for the per-candidate sampler scans (host_logic.cpp)
   int sampler_threads = -1;                 // -1: min(7, hardware threads - 1); option "sampler_threads"
@@ -182,6 +184,10 @@ int voc_load(tts_ctx *ctx, const char *path);
 #define TTS_VOC_CHUNK_HALO 24
 int voc_halo_frames();
 void voc_free(VocState *);
+int diff_cond_enc_load(tts_ctx *ctx, const char *path);
+void diff_cond_enc_free(DiffCondEncState *);
+int diff_cond_enc_latent(tts_ctx *ctx, const float *mel, const int32_t *frames, int n_clips, float *out2048);
+int diff_set_cond_latent(tts_ctx *ctx, const float *latent2048); // diffusion.hip: overrides the weight file's diffusion_conditioning_latent
 int voice_enc_load(tts_ctx *ctx, const char *path);
 void voice_enc_free(VoiceEncState *);
 int voice_enc_latent(tts_ctx *ctx, const float *mel, const int32_t *frames, int n_clips, float *out1024);

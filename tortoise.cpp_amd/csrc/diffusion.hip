@@ -661,6 +661,15 @@ struct DiffState {
 
 void diff_free(DiffState *s) { delete s; }
 int diff_layers(const tts_ctx *ctx) { return ctx->diff ? ctx->diff->n_main : 0; }
+// The voice's diffusion conditioning latent is a WEIGHT of the reference's file (main.cpp:1557-1560: one voice per ggml-diffusion-model.bin);
+// this replaces it in the loaded model, e.g. with the output of tts_diffusion_conditioning_latent.
+int diff_set_cond_latent(tts_ctx *ctx, const float *latent2048) {
+  if (!ctx->diff) return fail(ctx, TTS_ERR_STATE, "tts_load_diffusion not called");
+  if (!latent2048) return fail(ctx, TTS_ERR_ARG, "null latent");
+  TTS_HIP(ctx, hipMemcpyAsync(ctx->diff->cond_latent, latent2048, (size_t)2 * C * 4, hipMemcpyHostToDevice, ctx->stream));
+  TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return TTS_OK;
+}
 
 namespace {
 struct Loader {

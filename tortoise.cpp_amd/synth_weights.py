@@ -213,6 +213,25 @@ def write_voice_encoder(path, blocks=6, seed=1238):
     w.close()
 
 
+def write_diffusion_conditioning_encoder(path, blocks=5, seed=1239):
+    """ggml-diffusion-conditioning-model.bin: `contextual_embedder` of upstream tortoise-tts' DiffusionTts (tortoise/models/diffusion_decoder.py:
+    Conv1d(100, 1024, 3, padding=1, stride=2), Conv1d(1024, 2048, 3, padding=1, stride=2), 5 x AttentionBlock(2048, 16 heads, relative position
+    embeddings)); get_conditioning = mean over the frames of all clips -> the 2048-float `diffusion_conditioning_latent` the reference bakes
+    into ggml-diffusion-model.bin (main.cpp:1557-1560 reads it as a weight). Tensor names = the upstream state dict's. SURVEY 8 f3."""
+    g = _Gen(seed)
+    w = GgmlWriter(path)
+    w.add("contextual_embedder.0.weight", g.lecun((1024, 100, 3), 300)); w.add("contextual_embedder.0.bias", g.normal((1024,), 0.02))
+    w.add("contextual_embedder.1.weight", g.lecun((2048, 1024, 3), 3072)); w.add("contextual_embedder.1.bias", g.normal((2048,), 0.02))
+    D = 2048
+    for i in range(blocks):
+        p = "contextual_embedder.%d." % (2 + i)
+        w.add(p + "norm.weight", g.gamma(D)); w.add(p + "norm.bias", g.beta(D))
+        w.add(p + "qkv.weight", g.lecun((3 * D, D, 1), D, 1.5)); w.add(p + "qkv.bias", g.normal((3 * D,), 0.02))
+        w.add(p + "proj_out.weight", g.lecun((D, D, 1), D, 0.5)); w.add(p + "proj_out.bias", g.normal((D,), 0.02))
+        w.add(p + "relative_pos_embeddings.relative_attention_bias.weight", g.normal((32, 16), 0.1))
+    w.close()
+
+
 def write_all(out_dir, ar_layers=30, diff_main=10, diff_tail=3, diff_integ=3, diff_lc=4, seed=1234):
     import os
     os.makedirs(out_dir, exist_ok=True)
