@@ -78,9 +78,9 @@ struct tts_ctx {
   tts::ArState *ar = nullptr;
   tts::DiffState *diff = nullptr;
   tts::VocState *voc = nullptr;
-  tts::ClvpState *clvp = nullptr; // candidate re-ranker (clvp.hip; not in the reference)
-  tts::VoiceEncState *venc = nullptr; // voice-conditioning encoder (clvp.hip; not in the reference)
-  tts::DiffCondEncState *dcond = nullptr; // diffusion conditioning encoder (clvp.hip; not in the reference)
+  tts::ClvpState *clvp = nullptr; // candidate re-ranker (extras.hip; not in the reference)
+  tts::VoiceEncState *venc = nullptr; // voice-conditioning encoder (extras.hip; not in the reference)
+  tts::DiffCondEncState *dcond = nullptr; // diffusion conditioning encoder (extras.hip; not in the reference)
   tts::Tokenizer *tok = nullptr;
   tts::SamplerPool *sampler_pool = nullptr; // worker threads for the per-candidate sampler scans (host_logic.cpp)
   int sampler_threads = -1;                 // -1: min(7, hardware threads - 1); option "sampler_threads"

@@ -1,23 +1,24 @@
-// CLVP candidate re-ranking on MI355X (gfx950) — SURVEY section 8 f2.
+// Upstream tortoise-tts pieces the reference leaves out, on MI355X (gfx950):
+//   1. CLVP candidate re-ranking                      tts_load_clvp / tts_clvp_score
+//   2. the voice-conditioning encoder (AR side)        tts_load_voice_encoder / tts_voice_latent
+//   3. the diffusion conditioning encoder              tts_load_diffusion_conditioning_encoder / tts_diffusion_conditioning_latent
 //
-// The reference has no CLVP: main.cpp:6575 writes candidate 0. Upstream tortoise-tts scores every autoregressive candidate with CLVP
-// (tortoise/models/clvp.py, use_xformers=True) and keeps the best; this file is that scorer behind tts_load_clvp / tts_clvp_score, for a
-// weight file in the reference's container format whose tensor names are the upstream state dict's (tortoise.cpp_amd/synth_weights.py:
-// write_clvp lists them). Checked against oracle.Clvp (numpy, pinned against a torch restatement): no upstream weights or fixtures exist
-// offline, so its parity is "unpinned" in the sense of the task statement.
+// 1. The reference has no CLVP: main.cpp:6575 writes candidate 0. Upstream tortoise-tts scores every autoregressive candidate with CLVP
+// (tortoise/models/clvp.py, use_xformers=True) and keeps the best; this file is that scorer, for a weight file in the reference's container
+// format whose tensor names are the upstream state dict's (tortoise.cpp_amd/synth_weights.py: write_clvp lists them). Checked against
+// oracle.Clvp (numpy, pinned against a torch restatement): no upstream weights or fixtures exist offline, so its parity is "unpinned" in the
+// sense of the task statement. Model: two encoders (text, speech codes) of `depth` x [RMSNorm -> attention (bias-free q/k/v, rotary on the
+// first 32 of 64 head dims, softmax(q k^T / 8) v, to_out + bias) -> residual; RMSNorm -> GEGLU feed-forward (ff = 2 dim) -> residual], final
+// LayerNorm, mean over the sequence, bias-free latent projection, L2 normalise; score = <text latent, speech latent> exp(temperature).
 //
-// Model: two encoders (text, speech codes) of `depth` x [RMSNorm -> attention (bias-free q/k/v, rotary on the first 32 of 64 head dims,
-// softmax(q k^T / 8) v, to_out + bias) -> residual; RMSNorm -> GEGLU feed-forward (ff = 2 dim) -> residual], final LayerNorm, mean over the
-// sequence, bias-free latent projection, L2 normalise; score = <text latent, speech latent> exp(temperature).
+// 2 / 3. The reference READS both voice latents (--voice: main.cpp:5179-5184; `diffusion_conditioning_latent`, a weight of
+// ggml-diffusion-model.bin: main.cpp:1557-1560); README.md:54-72 gives an offline PyTorch recipe. Here: upstream's
+// UnifiedVoice.get_conditioning and DiffusionTts.get_conditioning (see the sections below), from the mel spectrograms of the reference clips.
 //
-// Device layout: all sequences of a call are packed into ONE row-major activation matrix x[rows][dim] (f32 residual stream, rows padded
-// to a multiple of 128); every projection is one launch of the fp16-MFMA GEMM of gemm_f16.h (fp16 operands, f32 accumulate, bias and
-// residual fused into the epilogue) over all rows; attention runs per (sequence, head) with K/V staged through LDS in chunks of 128 keys.
-// The scorer runs once per utterance on <= 16 x ~200 rows: it is 1-2 ms of work, the kernels are written for clarity.
-//
-// Second part of this file: the voice-conditioning encoder — upstream tortoise-tts' UnifiedVoice.get_conditioning, i.e.
-// what produces the 1024-float latent the reference reads from --voice (main.cpp:5179-5184; README.md:54-72 gives only an offline PyTorch
-// recipe). Same device layout and the same attention kernel (without the rotary embedding); see tts_load_voice_encoder / tts_voice_latent.
+// Device layout (all three): the sequences of a call are packed into ONE row-major activation matrix x[rows][dim] (f32 residual stream,
+// rows padded to a multiple of 128); every projection / convolution is one launch of the fp16-MFMA GEMM of gemm_f16.h (fp16 operands, f32
+// accumulate, bias and residual fused into the epilogue) over all rows; attention runs per (sequence, head) with K/V staged through LDS.
+// These run once per utterance (CLVP: 13 ms for 16 candidates) or once per voice: the kernels are written for clarity, not for the roofline.
 #include "common.h"
 #include "gemm_f16.h"
 #include <cmath>
