@@ -24,10 +24,12 @@
 //   (text ids + voice latent), the result sizes / CLVP scores are all-gathered, the audio is sent to rank 0, which writes every WAV file.
 #include "tortoise_mi355x.h"
 #include "cli_rccl.h"
+#include <algorithm>
 #include <csignal>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <iomanip>
 #include <iostream>
 #include <string>
 #include <vector>
@@ -111,12 +113,15 @@ int main(int argc, char **argv) {
       pids.push_back(pid);
     }
     int rc = 0;
-    for (size_t left = pids.size(); left > 0; left--) {
+    std::vector<pid_t> alive = pids;
+    while (!alive.empty()) {
       int st = 0;
       const pid_t pid = wait(&st);
-      if (pid < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) {
-        if (rc == 0 && exchange == "rccl")  // the other workers would wait in a collective for ever
-          for (pid_t p : pids) if (p != pid) kill(p, SIGTERM);
+      if (pid < 0) { rc = 1; break; }
+      alive.erase(std::remove(alive.begin(), alive.end(), pid), alive.end());
+      if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+        if (rc == 0 && exchange == "rccl")  // the workers still running would wait in a collective for ever
+          for (pid_t p : alive) kill(p, SIGTERM);
         rc = 1;
       }
     }
@@ -295,7 +300,7 @@ int main(int argc, char **argv) {
     }
     if (kept_gc >= 0 && shard >= 0) {
       std::ofstream f(outputPath + ".shard" + std::to_string(shard) + ".score");
-      f << kept_gc << " " << kept_score << "\n";
+      f << kept_gc << " " << std::setprecision(17) << kept_score << "\n";
     }
   }
   tts_destroy(ctx);
