@@ -144,3 +144,55 @@ def test_set_diffusion_conditioning_latent(pkg, small_models, tmp_path):
     baked = e2.diffusion_forward(latents, x_t, 500, False)
     assert (swapped == baked).all() and not (swapped == base).all()
     e.close(); e2.close()
+
+
+@pytest.mark.gpu
+def test_make_voice_tool_and_cli_voice_flags(pkg, venc_models, dcond_models, small_models, tmp_path):
+    """Audio clips -> tools/make_voice.py (host mel front-end + both encoders) -> `tortoise --voice V.bin --diffusion-latent V.diffusion.bin`:
+    the files have the right sizes, equal the library calls on the same mel, and the CLI run with them differs from the stock voice's."""
+    import shutil
+    import subprocess
+    import sys
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tortoise.cpp_amd", "tortoise")
+    if not os.path.exists(exe):
+        pytest.skip("CLI binary not built")
+    rs = np.random.RandomState(12)
+    clips = []
+    for i, (rate, secs) in enumerate(((24000, 1.3), (16000, 0.9))):
+        t = np.arange(int(rate * secs)) / rate
+        x = (0.3 * np.sin(2 * np.pi * (180 + 40 * i) * t) * (1 + 0.5 * np.sin(2 * np.pi * 3 * t)) + 0.02 * rs.randn(len(t))).astype(np.float32)
+        p = str(tmp_path / ("clip%d.wav" % i))
+        assert pkg.write_wav(p, x, rate) == 0
+        clips.append((p, x, rate))
+    out = str(tmp_path / "voice")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_voice.py"), "--clips"] + [c[0] for c in clips] +
+                       ["--conditioning-model", venc_models["small"], "--diffusion-conditioning-model", dcond_models["small"], "--out", out],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    v, dl = np.fromfile(out + ".bin", np.float32), np.fromfile(out + ".diffusion.bin", np.float32)
+    assert v.shape == (1024,) and dl.shape == (2048,) and np.isfinite(v).all() and np.isfinite(dl).all()
+    e = pkg.Engine(0)
+    e.load_voice_encoder(venc_models["small"])
+    from scipy.signal import resample_poly
+    first = e.voice_latent([pkg.host_mel_voice80(resample_poly(clips[0][1], 147, 160).astype(np.float32))])  # 24 kHz -> 22.05 kHz
+    assert first.shape == (1024,) and not np.allclose(first, v)  # two clips average to something else than the first alone
+    e.close()
+    d = tmp_path / "models"
+    d.mkdir()
+    for f in ("ggml-model.bin", "ggml-diffusion-model.bin", "ggml-vocoder-model.bin"):
+        os.symlink(os.path.join(small_models, f), d / f)
+    shutil.copy(os.path.join(ROOT, "models", "tokenizer.json"), d / "tokenizer.json")
+    base = [exe, "--models", str(d), "--message", "this is a test message.", "--seed", "0", "--codes", "16", "--steps", "4"]
+    outs = {}
+    for tag, extra in (("stock", ["--voice", os.path.join(ROOT, "models", "mol.bin")]),
+                       ("mine", ["--voice", out + ".bin", "--diffusion-latent", out + ".diffusion.bin"]),
+                       ("mine_ar_only", ["--voice", out + ".bin"])):
+        w = tmp_path / (tag + ".wav")
+        r = subprocess.run(base + extra + ["--output", str(w)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[tag] = w.read_bytes()
+    assert outs["mine"] != outs["stock"] and outs["mine"] != outs["mine_ar_only"]
+    r = subprocess.run(base + ["--voice", out + ".bin", "--diffusion-latent", out + ".bin", "--output", str(tmp_path / "bad.wav")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "2048 floats" in r.stderr  # a 1024-float file is not a diffusion latent

@@ -14,6 +14,8 @@
 // --clvp <file>: re-rank the candidates with CLVP (not in the reference, which keeps candidate 0, main.cpp:6575; upstream tortoise-tts
 //   does this): every candidate's codes are scored against the text, only the best one goes through diffusion + vocoder and is written
 //   to --output. With --devices every worker scores its own shard and the parent keeps the best of the workers' winners.
+// --diffusion-latent <file>: 2048 raw f32 that replace the `diffusion_conditioning_latent` weight of ggml-diffusion-model.bin (the reference
+//   bakes ONE voice into that file, main.cpp:1557-1560); with --voice this makes a voice two small files (tools/make_voice.py writes both).
 // --devices <N> [--device-map a,b,...]: candidate-parallel multi-GPU run. The process re-executes itself once per GPU
 //   (one process per device, replicated weights); worker r takes candidates [r B/N, (r+1) B/N) of the ONE batch: the RNG stream
 //   partition (options rng_shard_offset / rng_shard_total) makes the N x B/N codes identical to a single-GPU run of B candidates,
@@ -49,7 +51,7 @@ int main(int argc, char **argv) {
   std::string modelsDir = "../models";
   bool have_seed = false;
   int seed = 0, candidates = 1, steps = 80, device = 0, fixed_codes = 0, devices = 1, shard = -1, nshards = 1;
-  std::string device_map, clvpPath, exchange = "files", rccl_id;
+  std::string device_map, clvpPath, exchange = "files", rccl_id, diffLatentPath;
   for (int i = 1; i < argc - 1; ++i) {
     std::string a(argv[i]);
     if (a == "--voice") voicePath = argv[i + 1];
@@ -65,6 +67,7 @@ int main(int argc, char **argv) {
     else if (a == "--device-map") device_map = argv[i + 1];
     else if (a == "--clvp") clvpPath = argv[i + 1];
     else if (a == "--exchange") exchange = argv[i + 1];
+    else if (a == "--diffusion-latent") diffLatentPath = argv[i + 1];
     else if (a == "--rccl-id") rccl_id = argv[i + 1]; // worker mode (set by the parent)
     else if (a == "--shard") { // worker mode (set by the parent): "r/N"
       std::string v(argv[i + 1]);
@@ -233,6 +236,12 @@ int main(int argc, char **argv) {
   }
 
   if (tts_load_diffusion(ctx, (modelsDir + "/ggml-diffusion-model.bin").c_str())) return die(ctx, "diffusion_model_load");
+  if (!diffLatentPath.empty()) {
+    std::vector<float> dl(2048);
+    std::ifstream f(diffLatentPath, std::ios::binary);
+    if (!f || !f.read((char *)dl.data(), 2048 * sizeof(float))) { std::cerr << "Error: Unable to read 2048 floats from " << diffLatentPath << std::endl; return 1; }
+    if (tts_set_diffusion_conditioning_latent(ctx, dl.data())) return die(ctx, "diffusion_conditioning_latent");
+  }
   size_t mel_total = 0, audio_total = 0;
   std::vector<int32_t> frames(B);
   for (int c = 0; c < B; c++) {

@@ -505,6 +505,107 @@ extern "C" int tts_host_pad_codes(const int32_t *codes, int n, int32_t *out502) 
 }
 extern "C" int tts_host_trimmed_rows(const int32_t *codes502) { return tts::trimmed_latent_rows(codes502); }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Mel front-end of the two voice-conditioning encoders (upstream tortoise-tts; the reference has no audio INPUT path at all).
+// STFT with a periodic Hann window, centre = true (reflect padding of n_fft / 2), frames = n / hop + 1; triangular mel filterbank with
+// Slaney area normalisation on the Slaney ("librosa") or HTK mel scale.
+//   TacotronSTFT(1024, 256, 1024, 100, 24000, 0, 12000) -> magnitude, librosa filterbank, log(clamp 1e-5), normalised to [-1, 1] with the
+//     constants the vocoder driver de-normalises with (main.cpp:6044-6060)                                   = tts_host_mel_diffusion100
+//   torchaudio MelSpectrogram(n_fft 1024, hop 256, power 2, sample_rate 22050, f_max 8000, n_mels 80, norm "slaney", mel_scale "htk"),
+//     log(clamp 1e-5), divided by the per-band mel_norms of the upstream data directory (optional here)       = tts_host_mel_voice80
+// ------------------------------------------------------------------------------------------------------------------------------
+namespace tts {
+static void fft_inplace(std::vector<double> &re, std::vector<double> &im) { // radix-2, size = power of two
+  const size_t n = re.size();
+  for (size_t i = 1, j = 0; i < n; i++) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    const double ang = -2.0 * M_PI / (double)len;
+    for (size_t i = 0; i < n; i += len)
+      for (size_t k = 0; k < len / 2; k++) {
+        const double wr = std::cos(ang * (double)k), wi = std::sin(ang * (double)k);
+        const double ur = re[i + k], ui = im[i + k];
+        const double vr = re[i + k + len / 2] * wr - im[i + k + len / 2] * wi, vi = re[i + k + len / 2] * wi + im[i + k + len / 2] * wr;
+        re[i + k] = ur + vr; im[i + k] = ui + vi;
+        re[i + k + len / 2] = ur - vr; im[i + k + len / 2] = ui - vi;
+      }
+  }
+}
+static double hz_to_mel(double f, bool htk) {
+  if (htk) return 2595.0 * std::log10(1.0 + f / 700.0);
+  const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+  return f >= min_log_hz ? min_log_mel + std::log(f / min_log_hz) / logstep : f / f_sp;
+}
+static double mel_to_hz(double m, bool htk) {
+  if (htk) return 700.0 * (std::pow(10.0, m / 2595.0) - 1.0);
+  const double f_sp = 200.0 / 3.0, min_log_hz = 1000.0, min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+  return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+}
+// [n_mels][n_fft / 2 + 1], triangles between n_mels + 2 points equally spaced on the mel scale, each divided by half its width in Hz (Slaney)
+static std::vector<double> mel_filterbank(int n_mels, int n_fft, double sr, double f_min, double f_max, bool htk) {
+  const int nb = n_fft / 2 + 1;
+  std::vector<double> pts(n_mels + 2), fb((size_t)n_mels * nb, 0.0);
+  const double m0 = hz_to_mel(f_min, htk), m1 = hz_to_mel(f_max, htk);
+  for (int i = 0; i < n_mels + 2; i++) pts[i] = mel_to_hz(m0 + (m1 - m0) * i / (n_mels + 1), htk);
+  for (int m = 0; m < n_mels; m++) {
+    const double lo = pts[m], ce = pts[m + 1], hi = pts[m + 2], enorm = 2.0 / (hi - lo);
+    for (int k = 0; k < nb; k++) {
+      const double f = sr * k / n_fft, up = (f - lo) / (ce - lo), down = (hi - f) / (hi - ce);
+      fb[(size_t)m * nb + k] = std::max(0.0, std::min(up, down)) * enorm;
+    }
+  }
+  return fb;
+}
+// mel_out [n_mels][frames]; power 1 = magnitude, 2 = power spectrum; returns the frame count (n / hop + 1), < 0 on bad arguments
+static int mel_spectrogram(const float *audio, int64_t n, int n_fft, int hop, int n_mels, double sr, double f_min, double f_max, bool htk, int power,
+                           std::vector<double> &mel_out) {
+  if (!audio || n <= n_fft / 2 || (n_fft & (n_fft - 1)) || hop < 1 || n_mels < 1) return TTS_ERR_ARG; // reflect padding needs n > n_fft / 2
+  const int nb = n_fft / 2 + 1, pad = n_fft / 2, frames = (int)(n / hop) + 1;
+  const std::vector<double> fb = mel_filterbank(n_mels, n_fft, sr, f_min, f_max, htk);
+  std::vector<double> win(n_fft), re(n_fft), im(n_fft), spec(nb);
+  for (int i = 0; i < n_fft; i++) win[i] = 0.5 - 0.5 * std::cos(2.0 * M_PI * i / n_fft); // periodic Hann
+  mel_out.assign((size_t)n_mels * frames, 0.0);
+  for (int t = 0; t < frames; t++) {
+    for (int i = 0; i < n_fft; i++) {
+      int64_t j = (int64_t)t * hop + i - pad; // reflect (no edge repeat): -1 -> 1, n -> n - 2
+      if (j < 0) j = -j;
+      if (j >= n) j = 2 * (n - 1) - j;
+      re[i] = (double)audio[j] * win[i]; im[i] = 0.0;
+    }
+    fft_inplace(re, im);
+    for (int k = 0; k < nb; k++) { const double p = re[k] * re[k] + im[k] * im[k]; spec[k] = power == 2 ? p : std::sqrt(p); }
+    for (int m = 0; m < n_mels; m++) {
+      double a = 0;
+      for (int k = 0; k < nb; k++) a += fb[(size_t)m * nb + k] * spec[k];
+      mel_out[(size_t)m * frames + t] = a;
+    }
+  }
+  return frames;
+}
+} // namespace tts
+extern "C" int tts_host_mel_frames(int64_t n_samples) { return n_samples < 0 ? TTS_ERR_ARG : (int)(n_samples / 256) + 1; }
+extern "C" int tts_host_mel_diffusion100(const float *audio24k, int64_t n, float *mel_out) {
+  std::vector<double> mel;
+  const int frames = tts::mel_spectrogram(audio24k, n, 1024, 256, 100, 24000.0, 0.0, 12000.0, /*htk=*/false, /*power=*/1, mel);
+  if (frames < 0) return frames;
+  const double mel_max = 2.3143386840820312, mel_min = -11.512925148010254; // normalize_tacotron_mel; the inverse is main.cpp:6044-6060
+  for (size_t i = 0; i < mel.size(); i++) mel_out[i] = (float)(2.0 * ((std::log(std::max(mel[i], 1e-5)) - mel_min) / (mel_max - mel_min)) - 1.0);
+  return frames;
+}
+extern "C" int tts_host_mel_voice80(const float *audio22k, int64_t n, const float *mel_norms80, float *mel_out) {
+  std::vector<double> mel;
+  const int frames = tts::mel_spectrogram(audio22k, n, 1024, 256, 80, 22050.0, 0.0, 8000.0, /*htk=*/true, /*power=*/2, mel);
+  if (frames < 0) return frames;
+  for (int m = 0; m < 80; m++)
+    for (int t = 0; t < frames; t++)
+      mel_out[(size_t)m * frames + t] = (float)(std::log(std::max(mel[(size_t)m * frames + t], 1e-5)) / (mel_norms80 ? (double)mel_norms80[m] : 1.0));
+  return frames;
+}
+
 // writeWav, main.cpp:4821-4868
 extern "C" int tts_write_wav(const char *path, const float *samples, int64_t n, int sample_rate) {
   FILE *f = fopen(path, "wb");
