@@ -68,3 +68,34 @@ def test_mel_filterbank_rows_are_slaney_normalised():
         fb = _fb(nm, sr, 0.0, fmax, htk)
         area = fb.sum(axis=1) * (sr / 1024)
         assert np.abs(area[5:] - 1.0).max() < 0.12  # the discrete sum of a narrow triangle is only roughly its area
+
+
+def test_make_voice_wav_reader_and_resampler(tmp_path, pkg):
+    """tools/make_voice.py's host side: float32 and PCM16 WAV files (the reference writes float32, main.cpp:4821-4868), stereo down-mix,
+    rational resampling to the two encoder rates."""
+    import importlib.util
+    import os
+    import struct
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("make_voice", os.path.join(ROOT, "tools", "make_voice.py"))
+    mv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mv)
+    t = np.arange(8000) / 16000.0
+    x = (0.5 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    p32 = str(tmp_path / "f32.wav")
+    assert pkg.write_wav(p32, x, 16000) == 0
+    y, rate = mv.read_wav(p32)
+    assert rate == 16000 and (y == x).all()
+    # PCM16 stereo, written by hand
+    pcm = (np.stack([x, x], axis=1) * 32767).astype(np.int16)
+    data = pcm.tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 2, 16000, 16000 * 4, 4, 16) + b"data" + struct.pack("<I", len(data))
+    p16 = str(tmp_path / "pcm16.wav")
+    open(p16, "wb").write(hdr + data)
+    y16, rate = mv.read_wav(p16)
+    assert rate == 16000 and y16.shape == x.shape and np.abs(y16 - x).max() < 1e-4
+    for target in (22050, 24000):
+        z = mv.resample(x, 16000, target)
+        assert abs(len(z) - len(x) * target / 16000) <= 1
+        k = np.argmax(np.abs(np.fft.rfft(z * np.hanning(len(z)))))
+        assert abs(k * target / len(z) - 440) < 3  # the tone is still at 440 Hz
