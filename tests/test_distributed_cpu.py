@@ -152,3 +152,18 @@ def test_bench_self_launches_its_ranks(pkg):
     for e in (want0, e0, e1):
         e.close()
     assert out["dry_engine"]["gathered_samples"] > 0
+
+
+def test_bench_force_dist_one_rank_gloo():
+    """`bench.py --force-dist` (the switch the GPU suite uses to run RCCL with one rank) on the CPU: a one-rank gloo group of its own
+    rendezvous, every collective of the N > 1 path executed, the line carries the backend, the rank count and the gathered sample count."""
+    import json
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--backend", "gloo", "--dry-engine", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["collective_backend"] == "gloo" and out["collective_ranks"] == 1
+    assert out["gathered_samples"] == out["dry_engine"]["gathered_samples"] > 0
