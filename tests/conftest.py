@@ -77,14 +77,24 @@ def engine(pkg):
     eng.close()
 
 
-def loop_gate(kind):
+def loop_gate(kind, attn_f32=False):
     """Gate (max abs on the +-1 mel range) of an 80-/200-step sampling-loop comparison between the engine and the oracle on the
-    `kind` = small | mid | full weights: max(1e-3, 2 x the distance a faithful f32 emulation of the engine's arithmetic keeps from the
-    oracle), measured on the CPU with torch (tests/test_parity_floor.py; record in tests/golden/parity_floor.json). north_star asks for
-    1e-3; two CORRECT f32 evaluations of the reference's own graph are 0.7-1.1e-3 apart over 80 steps, so no tighter gate can be kept
-    by any f32 implementation; the reference's own gate is 0.01 (main.cpp:6223)."""
+    `kind` = small | mid | full weights (record: tests/golden/parity_floor.json, measured on the CPU with torch by
+    tools/regen_parity_floor.py / tests/test_parity_floor.py).
+
+    attn_f32 = True  — the engine's reference-precision mode (option attn_f32 = 1: F32 AttentionBlock as main.cpp:3848-3875): the gate is
+                       the largest distance measured between the oracle and a torch-f32 evaluation of the reference's graph on this
+                       class of problem (`oracle_vs_t32`): two correct f32 evaluations, nothing multiplied in. north_star asks for 1e-3;
+                       the trajectory is chaotic at that level (fp16 rounding of every convolution operand), so the distance between two
+                       correct f32 evaluations IS the tolerance an f32 engine can be held to.
+    attn_f32 = False — throughput mode (fp16 MFMA operands in the AttentionBlock, a north-star design decision): max(1e-3, 2 x the
+                       distance an f32 emulation of that arithmetic keeps from the oracle). The reference's own gate is 0.01 (main.cpp:6223)."""
     import json
-    return float(json.load(open(os.path.join(GOLDEN, "parity_floor.json")))[kind]["gate"])
+    rec = json.load(open(os.path.join(GOLDEN, "parity_floor.json")))[kind]
+    return float(rec["gate_f32"] if attn_f32 else rec["gate"])
+
+
+ATTN_MODES = ((0, "throughput mode: fp16 attention operands"), (1, "reference precision: attn_f32"))
 
 
 DEFAULT_TOKENS = np.array([255, 147, 2, 54, 2, 14, 2, 136, 63, 2, 80, 32, 150, 112, 9, 0], np.int32)

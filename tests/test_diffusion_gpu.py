@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import loop_gate
+from conftest import ATTN_MODES, loop_gate
 
 pytestmark = pytest.mark.gpu
 
@@ -30,14 +30,20 @@ def test_forward_matches_oracle(engine, oracle, small_models, mid_models, models
     T = engine.frames(L)
     assert T == od.T_of(L)
     x_t = np.random.RandomState(7).randn(100, T).astype(np.float32)
-    got = engine.diffusion_forward(lat, x_t, timestep, cond_free)
     ce = None if cond_free else od.code_embedding(lat, T)
     want = od.forward(ce, x_t, timestep)
-    assert got.shape == want.shape == (200, T)
-    # tolerance from the north star: 1e-3 relative (fp16 MFMA inputs for attention/proj_out, f32 accumulate)
-    e = rel_err(got, want)
-    print("forward rel err %s L=%d t=%d cond_free=%s: %.2e" % (models, L, timestep, cond_free, e))
-    assert e < 1e-3, e
+    try:
+        for mode, what in ATTN_MODES:
+            engine.set_option("attn_f32", mode)
+            got = engine.diffusion_forward(lat, x_t, timestep, cond_free)
+            assert got.shape == want.shape == (200, T)
+            # north star: 1e-3 relative with fp16 MFMA inputs for attention / proj_out (f32 accumulate); the reference-precision mode sits on the
+            # single-forward chaos floor of the fp16-rounded convolutions (two f32 evaluations: 2-5e-4, tests/test_oracle_vs_torch.py)
+            e = rel_err(got, want)
+            print("forward rel err %s L=%d t=%d cond_free=%s [%s]: %.2e" % (models, L, timestep, cond_free, what, e))
+            assert e < (5e-4 if mode else 1e-3), (mode, e)
+    finally:
+        engine.set_option("attn_f32", 0)
 
 
 @pytest.mark.parametrize("gn_eps,lut", [(1e-5, 0), (1e-6, 1)])
@@ -78,13 +84,18 @@ def test_sampling_loop_matches_oracle(engine, oracle, small_models):
     lats = [_latents(20, 1), _latents(9, 2)]
     rs = np.random.RandomState(3)
     noise = [rs.randn(n_steps + 1, 100 * engine.frames(len(l))).astype(np.float32) for l in lats]
-    mels = engine.diffusion(lats, n_steps=n_steps, noise=noise)
-    for c, l in enumerate(lats):
-        want = od.sample(l, n_steps=n_steps, noise=noise[c])
-        assert mels[c].shape == want.shape
-        err = np.abs(mels[c] - want)
-        print("80-step sampling loop cand %d: max %.2e mean %.2e" % (c, err.max(), err.mean()))
-        assert err.max() <= loop_gate("small"), (c, err.max(), err.mean())
+    wants = [od.sample(l, n_steps=n_steps, noise=noise[c]) for c, l in enumerate(lats)]
+    try:
+        for mode, what in ATTN_MODES:
+            engine.set_option("attn_f32", mode)
+            mels = engine.diffusion(lats, n_steps=n_steps, noise=noise)
+            for c, want in enumerate(wants):
+                assert mels[c].shape == want.shape
+                err = np.abs(mels[c] - want)
+                print("80-step sampling loop cand %d [%s]: max %.2e mean %.2e (gate %.2e)" % (c, what, err.max(), err.mean(), loop_gate("small", mode)))
+                assert err.max() <= loop_gate("small", mode), (mode, c, err.max(), err.mean())
+    finally:
+        engine.set_option("attn_f32", 0)
 
 
 def test_sampling_loop_200_steps_config5(engine, oracle, small_models):
@@ -95,12 +106,17 @@ def test_sampling_loop_200_steps_config5(engine, oracle, small_models):
     lat = _latents(9, 3)
     T = engine.frames(9)
     noise = np.random.RandomState(8).randn(201, 100 * T).astype(np.float32)
-    mel = engine.diffusion([lat], n_steps=200, noise=[noise])[0]
     want = od.sample(lat, n_steps=200, noise=noise)
-    err = np.abs(mel - want)
-    print("200-step sampling loop (T=%d): max abs %.2e mean %.2e" % (T, err.max(), err.mean()))
-    assert mel.shape == want.shape == (100, T) and np.isfinite(mel).all() and np.abs(mel).max() <= 1.0 + 1e-6
-    assert err.max() <= loop_gate("small"), (err.max(), err.mean())
+    try:
+        for mode, what in ATTN_MODES:
+            engine.set_option("attn_f32", mode)
+            mel = engine.diffusion([lat], n_steps=200, noise=[noise])[0]
+            err = np.abs(mel - want)
+            print("200-step sampling loop (T=%d) [%s]: max abs %.2e mean %.2e (gate %.2e)" % (T, what, err.max(), err.mean(), loop_gate("small", mode)))
+            assert mel.shape == want.shape == (100, T) and np.isfinite(mel).all() and np.abs(mel).max() <= 1.0 + 1e-6
+            assert err.max() <= loop_gate("small", mode), (mode, err.max(), err.mean())
+    finally:
+        engine.set_option("attn_f32", 0)
 
 
 def test_reference_noise_stream(engine, oracle, small_models):

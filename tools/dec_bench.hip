@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DTTS_DEC_TRACE -I include -I tortoise.cpp_amd/csrc tools/dec_bench.hip \
 //         tortoise.cpp_amd/csrc/host_logic.cpp -o tools/dec_bench_bin
 #include "../tortoise.cpp_amd/csrc/ar.hip"
+#include <algorithm>
 #include <cstdio>
 #include <vector>
 using namespace tts;
@@ -10,10 +11,11 @@ hipEvent_t tts::prof_event(tts_ctx *) { return nullptr; } // profiling is off in
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
-static void dump_trace(const char *tag, int nblocks, int nph) {
-  std::vector<long long> t(8 * 4096);
-  hipError_t e = hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(tts::tts_dec_trace), t.size() * 8);
+static void dump_trace(const char *tag, int nblocks, int nph, int slot) {
+  std::vector<long long> all(6 * 1024 * 8);
+  hipError_t e = hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(tts::tts_dec_trace), all.size() * 8);
   if (e != hipSuccess) printf("memcpyFromSymbol: %s\n", hipGetErrorString(e));
+  std::vector<long long> t(all.begin() + (size_t)slot * 1024 * 8, all.begin() + (size_t)(slot + 1) * 1024 * 8);
   long long t0 = t[0];
   for (int b = 0; b < nblocks; b++) t0 = std::min(t0, t[b * 8]);
   printf("%s phases (us since first workgroup start; 100 MHz clock):\n", tag);
@@ -67,16 +69,16 @@ int main(int argc, char **argv) {
   timeit("dec_ln_gemv<GELU> fc", [&](int l) {
     DecLnArgs a{h, nullptr, nullptr, wfc[l], (const __half *)wfc[l], bvec, B, 4096, 0, 0, ff, nullptr, nullptr, ss, 0, 0};
     dec_ln_gemv_kernel<DEC_GELU, 1><<<dim3(256, 1), 256, 0, st>>>(a); }, 16.8e6);
-  dump_trace("fc", 256, 5);
+  dump_trace("fc", 256, 5, 3);
   timeit("dec_ln_gemv<QKV>", [&](int l) {
     DecLnArgs a{h, nullptr, nullptr, wqkv[l], (const __half *)wqkv[l], bvec, B, 3072, 1024, 0, q, kc, vc, ss, 256, 0};
     dec_ln_gemv_kernel<DEC_QKV, 1><<<dim3(192, 1), 256, 0, st>>>(a); }, 12.6e6);
-  dump_trace("qkv", 192, 5);
+  dump_trace("qkv", 192, 5, 0);
   timeit("dec_gemv_resid<4> fc2", [&](int l) { dec_gemv_resid_kernel<4><<<dim3(256, 1), 256, 0, st>>>(ff, B, wfc2[l], bvec, h); }, 16.8e6);
   timeit("dec_gemv_resid<4,512> fc2", [&](int l) { dec_gemv_resid_kernel<4, 512><<<dim3(256, 1), 512, 0, st>>>(ff, B, wfc2[l], bvec, h); }, 16.8e6);
-  dump_trace("fc2", 256, 4);
+  dump_trace("fc2", 256, 4, 4);
   timeit("dec_gemv_resid<1> proj", [&](int l) { dec_gemv_resid_kernel<1><<<dim3(256, 1), 256, 0, st>>>(att, B, wproj[l], bvec, h); }, 4.2e6);
-  dump_trace("proj", 256, 4);
+  dump_trace("proj", 256, 4, 2);
   for (int np : {20, 100, 164, 250}) {
     StepState hs2{np, 3}; CK(hipMemcpy(ss, &hs2, sizeof(hs2), hipMemcpyHostToDevice));
     char tag[64];
@@ -86,5 +88,62 @@ int main(int argc, char **argv) {
     timeit(tag, [&](int l) { attn_decode_fast_kernel<<<dim3(B, 16), 256, 0, st>>>(q, kc, vc, ss, 256, att); }, 0);
   }
   CK(hipMemcpy(ss, &hs, sizeof(hs), hipMemcpyHostToDevice));
+#ifdef TTS_DEC_TRACE
+
+  // ---- the decode step as it runs: 30 layers x {LN1+QKV, attention, projection, LN2+FC, MLP projection} + head, captured in a hipGraph ----
+  // Per kernel of the LAST layer (every layer overwrites its slot): first workgroup start, the median workgroup's phase stamps, last workgroup end,
+  // relative to the layer's first stamp; "gap" = first start of this kernel - last end of its predecessor (the dependent kernel boundary).
+  {
+    CK(hipMemcpy(ss, &hs, sizeof(hs), hipMemcpyHostToDevice)); // n_past = 20: keys of the attention
+    StepState hs3{164, 3}; CK(hipMemcpy(ss, &hs3, sizeof(hs3), hipMemcpyHostToDevice)); // mid-sequence context (P + 96)
+    hipGraph_t graph; hipGraphExec_t exec;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    for (int l = 0; l < L; l++) {
+      { DecLnArgs a{h, nullptr, nullptr, wqkv[l], (const __half *)wqkv[l], bvec, B, 3072, 1024, 0, q, kc, vc, ss, 256, 0};
+        dec_ln_gemv_kernel<DEC_QKV, 1, true><<<dim3(192, 1), 256, 0, st>>>(a); }
+      attn_decode_fast_kernel<<<dim3(B, 16), 256, 0, st>>>(q, kc, vc, ss, 256, att);
+      dec_gemv_resid_kernel<1, 256, 0, true><<<dim3(256, 1), 256, 0, st>>>(att, B, wproj[l], bvec, h);
+      { DecLnArgs a{h, nullptr, nullptr, wfc[l], (const __half *)wfc[l], bvec, B, 4096, 0, 0, ff, nullptr, nullptr, ss, 0, 0};
+        dec_ln_gemv_kernel<DEC_GELU, 1, true><<<dim3(256, 1), 256, 0, st>>>(a); }
+      dec_gemv_resid_kernel<4, 512, 0, true><<<dim3(256, 1), 512, 0, st>>>(ff, B, wfc2[l], bvec, h);
+    }
+    CK(hipStreamEndCapture(st, &graph));
+    CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    for (int i = 0; i < 5; i++) CK(hipGraphLaunch(exec, st));
+    CK(hipEventRecord(e0, st));
+    const int reps = 50;
+    for (int i = 0; i < reps; i++) CK(hipGraphLaunch(exec, st));
+    CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("\nlayer chain in a hipGraph (%d layers x 5 launches, B = %d, %d keys, TRACED build): %.1f us per replay = %.2f us per layer\n", L, B, hs3.n_past + 1,
+           1e3 * ms / reps, 1e3 * ms / reps / L);
+    std::vector<long long> all(6 * 1024 * 8);
+    CK(hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(tts::tts_dec_trace), all.size() * 8));
+    struct K { const char *name; int slot, nwg, nph; const char *phases; };
+    const K ks[5] = {{"LN1 + QKV (dec_ln_gemv)", 0, 192, 6, "start | loads issued | LayerNorm done (x arrived, 2 barriers) | weights arrived + MFMAs | cross-wave barrier | stored"},
+                     {"attention (attn_decode_fast)", 1, B * 16, 4, "start | K/V round trip + softmax + PV | barrier | stored"},
+                     {"attention projection (dec_gemv_resid<1>)", 2, 256, 5, "start | weights + activations arrived, FMAs | butterfly | barrier | stored"},
+                     {"LN2 + FC (dec_ln_gemv)", 3, 256, 6, "start | loads issued | LayerNorm done | weights arrived + MFMAs | cross-wave barrier | stored"},
+                     {"MLP projection (dec_gemv_resid<4,512>)", 4, 256, 5, "start | weights + activations arrived, FMAs | butterfly | barrier | stored"}};
+    long long t0 = all[(size_t)ks[0].slot * 1024 * 8];
+    for (int b = 0; b < ks[0].nwg; b++) t0 = std::min(t0, all[((size_t)ks[0].slot * 1024 + b) * 8]);
+    long long prev_end = 0;
+    for (int k = 0; k < 5; k++) {
+      std::vector<std::vector<long long>> ph(ks[k].nph);
+      long long first = 1ll << 62, last = 0;
+      for (int b = 0; b < ks[k].nwg; b++) {
+        const long long *p = &all[((size_t)ks[k].slot * 1024 + b) * 8];
+        first = std::min(first, p[0]); last = std::max(last, p[ks[k].nph - 1]);
+        for (int i = 0; i < ks[k].nph; i++) ph[i].push_back(p[i] - p[0]);
+      }
+      printf("  %-42s first start %6.2f us  (gap to predecessor's last end: %5.2f us)   last end %6.2f us   [kernel span %5.2f us]\n", ks[k].name, (first - t0) * 0.01,
+             k ? (first - prev_end) * 0.01 : 0.0, (last - t0) * 0.01, (last - first) * 0.01);
+      printf("      median workgroup, us since its own start: ");
+      for (int i = 0; i < ks[k].nph; i++) { std::sort(ph[i].begin(), ph[i].end()); printf(" %5.2f", ph[i][ph[i].size() / 2] * 0.01); }
+      printf("    (%s)\n", ks[k].phases);
+      prev_end = last;
+    }
+  }
+#endif
   return 0;
 }

@@ -1,0 +1,113 @@
+"""CPU: (re)measure the loop-level parity floors recorded in tests/golden/parity_floor.json (tests/test_parity_floor.py explains the columns).
+
+Round 4 adds, per sample, `oracle_vs_t32` = the 80-step distance between the ORACLE and a torch-f32 evaluation of the reference's graph — two
+correct f32 evaluations with different summation orders. It is what the engine's reference-precision mode (option attn_f32 = 1: F32 QK^T /
+softmax / PV / proj_out as main.cpp:3848-3875, on split-fp16 MFMA operands) is gated at: gate_f32 = max(1e-3 [north star], the largest such
+distance over the class's samples), nothing multiplied in.
+
+  python tools/regen_parity_floor.py small mid          # seconds to minutes per sample
+  python tools/regen_parity_floor.py full               # full depth: ~10 min per sample on 8 cores
+  python tools/regen_parity_floor.py --extra small:L=16,seed=21 ...   # add samples
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle as O  # noqa: E402
+import torch_ref as TR  # noqa: E402
+
+FLOOR_JSON = os.path.join(ROOT, "tests", "golden", "parity_floor.json")
+MODELS = {"small": os.environ.get("TTS_SYNTH_DIR", "/tmp/tts_synth") + "/small", "mid": os.environ.get("TTS_SYNTH_DIR", "/tmp/tts_synth") + "/mid",
+          "full": os.environ.get("TTS_BENCH_MODELS", "/tmp/tts_bench_models")}
+
+
+def ensure_models(kind):
+    import tortoise_cpp_amd_loader
+    tortoise_cpp_amd_loader.load()
+    from tortoise_cpp_amd import synth_weights as sw
+    d = MODELS[kind]
+    if not os.path.exists(os.path.join(d, ".done")):
+        kw = {"small": dict(ar_layers=2, diff_main=1, diff_tail=1, diff_integ=1, diff_lc=1, seed=4321),
+              "mid": dict(ar_layers=6, diff_main=3, diff_tail=1, diff_integ=1, diff_lc=2, seed=777), "full": dict(seed=1234)}[kind]
+        sw.write_all(d, **kw)
+        open(os.path.join(d, ".done"), "w").write("ok")
+    return d + "/ggml-diffusion-model.bin"
+
+
+def loops(path, L, seed, steps=80, which=("t32", "orc")):
+    od = O.Diffusion(O.Model(path))
+    T = od.T_of(L)
+    rs = np.random.RandomState(seed)
+    lat = rs.randn(L, 1024).astype(np.float32)
+    noise = rs.randn(steps + 1, 100 * T).astype(np.float32)
+    tm = O.default_timestep_map(steps)
+    ce = od.code_embedding(lat, T)
+    res = {}
+
+    def loop(net):
+        x = noise[0].copy()
+        for idx in range(steps):
+            t = steps - 1 - idx
+            te = O.timestep_embedding(int(tm[t]))
+            xc = x.reshape(100, T)
+            x = O.diffusion_update(tm, t, net.forward(ce, xc, te), net.forward(None, xc, te), x, noise[idx + 1], T)
+        return x.reshape(100, T)
+
+    mk = {"t32": lambda: TR.TorchDiffusion(path, O.buckets), "t64": lambda: TR.TorchDiffusion(path, O.buckets, dtype=torch.float64),
+          "e64": lambda: TR.TorchDiffusion(path, O.buckets, dtype=torch.float64, f16_attention=True),
+          "e32": lambda: TR.TorchDiffusion(path, O.buckets, f16_attention=True)}
+    for k in which:
+        res[k] = od.sample(lat, steps, noise=noise.reshape(-1)) if k == "orc" else loop(mk[k]())
+    return T, res
+
+
+def main():
+    torch.set_num_threads(int(os.environ.get("TTS_FLOOR_THREADS", "4")))
+    O.build()
+    rec = json.load(open(FLOOR_JSON))
+    args = sys.argv[1:]
+    extra = {}
+    if "--extra" in args:
+        i = args.index("--extra")
+        for spec in args[i + 1:]:
+            kind, kv = spec.split(":")
+            extra.setdefault(kind, []).append({k: int(v) for k, v in (p.split("=") for p in kv.split(","))})
+        args = args[:i]
+    kinds = args or ["small", "mid"]
+    for kind in kinds:
+        path = ensure_models(kind)
+        samples = rec[kind]["samples"]
+        for e in extra.get(kind, []):
+            if not any(s.get("L") == e["L"] and s.get("seed", 5) == e.get("seed", 5) for s in samples):
+                samples.append({"L": e["L"], "seed": e.get("seed", 5), "new": True})
+        for s in samples:
+            if "oracle_vs_t32" in s and not s.get("new"):
+                continue
+            new = s.pop("new", False)
+            which = ("t32", "orc", "t64", "e64", "e32") if new else ("t32", "orc")
+            T, r = loops(path, s["L"], s.get("seed", 5), which=which)
+            d = lambda a, b: float(np.abs(r[a] - r[b]).max())  # noqa: E731
+            s["T"] = int(T)
+            s["oracle_vs_t32"] = d("orc", "t32")
+            if new:
+                s.update(floor_f32=d("t32", "t64"), oracle=d("orc", "t64"), engine_math=d("e64", "t64"), pair=d("e32", "orc"))
+            print(kind, s, flush=True)
+            json.dump(rec, open(FLOOR_JSON, "w"), indent=1)
+        f = rec[kind]
+        for fld in ("floor_f32", "oracle", "engine_math", "pair", "oracle_vs_t32"):
+            f[fld] = max(x[fld] for x in samples)
+        f["gate"] = round(max(1e-3, 2.0 * f["pair"]), 5)
+        f["gate_f32"] = round(max(1e-3, f["oracle_vs_t32"]), 5)  # north star's 1e-3, or the measured f32-vs-f32 floor where that is higher
+        json.dump(rec, open(FLOOR_JSON, "w"), indent=1)
+        print(kind, {k: f[k] for k in ("floor_f32", "oracle", "engine_math", "pair", "oracle_vs_t32", "gate", "gate_f32")}, flush=True)
+
+
+if __name__ == "__main__":
+    main()

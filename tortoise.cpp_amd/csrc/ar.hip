@@ -22,12 +22,10 @@ namespace tts {
 
 static constexpr int D = 1024, NH = 16, HD = 64, FF = 4096, V = TTS_VOCAB_MEL, VPAD = 8256;
 
-// A/B switch for the LayerNorm-GEMV decode kernels: split-precision fp16 MFMA (default: three products per K step,
-// 2^-22 relative) vs exact-f32 MFMA products (TTS_DEC_F32MFMA=1, read at load time: it selects the weight packing)
-static const bool dec_f32_mfma = getenv("TTS_DEC_F32MFMA") != nullptr;
+// LayerNorm-GEMV decode kernels: split-precision fp16 MFMA (default: three products per K step, 2^-22 relative) or exact-f32 MFMA
+// products (option "dec_f32_mfma" = 1, read by tts_load_ar: it selects the weight packing; ArState::f32_mfma).
 // Weight slabs of the decode step are streamed once per step by exactly one workgroup: non-temporal loads keep them from displacing the
-// activations / KV rows in L2 (MI355X_MICROARCH.md, row "nt-weights"). TTS_DEC_NT=0 is the A/B switch back to default-policy loads.
-static const bool dec_nt = !(getenv("TTS_DEC_NT") && atoi(getenv("TTS_DEC_NT")) == 0);
+// activations / KV rows in L2 (MI355X_MICROARCH.md, row "nt-weights"; measured 1 008 vs 1 036 us per step, profiles/r3_bench_n1.json).
 typedef float ntfloat4 __attribute__((ext_vector_type(4)));
 template <bool NT> __device__ __forceinline__ float4 ldw4(const float4 *p) {
   if (!NT) return *p;
@@ -339,9 +337,9 @@ __global__ __launch_bounds__(256) void embed_step_kernel(const float *__restrict
 // register-resident operands: a row's 1024 values live in 4 lanes x 4 waves.
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 enum { DEC_QKV = 0, DEC_GELU = 1, DEC_LOGITS = 2 };
-#ifdef TTS_DEC_TRACE // developer build (tools/dec_bench.hip): phase timestamps of every workgroup
-__device__ long long tts_dec_trace[8 * 4096];
-#define DEC_T(i) do { if (threadIdx.x == 0) tts_dec_trace[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#ifdef TTS_DEC_TRACE // developer build (tools/dec_bench.hip): phase timestamps (100 MHz wall clock) of every workgroup, one slot per kernel of a layer
+__device__ long long tts_dec_trace[6 * 1024 * 8]; // slot: 0 LN1+QKV, 1 attention, 2 attention projection, 3 LN2+FC, 4 MLP projection, 5 head
+#define DEC_T(i) do { if (threadIdx.x == 0) tts_dec_trace[((TSLOT) * 1024 + blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define DEC_T(i)
 #endif
@@ -414,6 +412,7 @@ __device__ __forceinline__ void dec_layernorm(float4 (&x)[16], const float *__re
 template <int EPI, int SPLIT = 0, bool NTW = false>
 __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
   constexpr int SP = SPLIT ? 1 : 0;
+  constexpr int TSLOT = EPI == DEC_QKV ? 0 : EPI == DEC_GELU ? 3 : 5; (void)TSLOT;
   __shared__ float sred[4][4][16];
   __shared__ float4 accs[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, q = lane >> 4;
@@ -536,6 +535,7 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
     if (col + 2 < a.n_valid) o[2] = v.z;
     if (col + 3 < a.n_valid) o[3] = v.w;
   }
+  DEC_T(5);
 }
 
 // h[rows][1024] += X[rows][K] . W[K][1024] + bias, K = 1024 * KG. One workgroup owns 4 output columns over the
@@ -552,6 +552,7 @@ __global__ __launch_bounds__(NT) void dec_gemv_resid_kernel(const float *__restr
                                                             const float *__restrict__ bias, float *__restrict__ h,
                                                             const float *__restrict__ wscale = nullptr) {
   constexpr int K = 1024 * KG, NW = NT / 64, NG = K / (NT * 4); // NG K groups of NT*4 values per workgroup
+  constexpr int TSLOT = KG == 1 ? 2 : 4; (void)TSLOT;
   __shared__ float red[NW][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cb = blockIdx.x, row0 = blockIdx.y * 16;
@@ -672,6 +673,7 @@ __global__ __launch_bounds__(NT) void dec_gemv_resid_kernel(const float *__restr
       h[(size_t)r * D + col] = h_old + ((WH == 2 ? t * s_old : t) + b_old);
     }
   }
+  DEC_T(4);
 }
 
 // max over the four 16-lane rows of a wave (see rows4_sum)
@@ -752,10 +754,12 @@ __global__ __launch_bounds__(256) void attn_decode_fast_kernel(const float *__re
                                                                const __half *__restrict__ vc, const StepState *__restrict__ ss,
                                                                int max_pos, float *__restrict__ out) {
   constexpr float L2E = 1.4426950408889634f;
+  constexpr int TSLOT = 1; (void)TSLOT;
   __shared__ float red[4][HD];
   __shared__ float wm[4], wl[4];
   const int c = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l8 = tid & 7, kg = tid >> 3;
+  DEC_T(0);
   const int nk = ss->n_past + 1;
   const __half *kb = kc + (size_t)c * max_pos * D + h * HD;
   const __half *vb = vc + (size_t)c * max_pos * D + h * HD;
@@ -789,9 +793,11 @@ __global__ __launch_bounds__(256) void attn_decode_fast_kernel(const float *__re
     const float send = up ? acc[0] : acc[1], keep = up ? acc[1] : acc[0];
     acc[0] = keep + __shfl_xor(send, 8);
   }
+  DEC_T(1);
   red[wave][l8 * 8 + (lane >> 3)] = acc[0];
   if (lane == 0) { wm[wave] = m; wl[wave] = l; }
   __syncthreads();
+  DEC_T(2);
   if (tid < HD) {
     const float M = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])); // wave 0 always holds key 0: finite
     float tot = 0.f, o = 0.f;
@@ -803,6 +809,7 @@ __global__ __launch_bounds__(256) void attn_decode_fast_kernel(const float *__re
     }
     out[(size_t)c * D + h * HD + tid] = o / tot;
   }
+  DEC_T(3);
 }
 
 // Decode attention for one (candidate, head): q is this step's (fp16-rounded) query, K/V of the new position
@@ -923,6 +930,7 @@ struct ArState {
   uint8_t *o_lm = nullptr; // pack_mfma16o (option ar_weights = 2 at load)
   float *os_lm = nullptr;
   int loaded_wmode = 0;    // the reduced-precision decode slabs this state was loaded with (0 = none, 1 = fp16, 2 = fp8)
+  bool f32_mfma = false;   // option "dec_f32_mfma" at load: LayerNorm-GEMVs on v_mfma_f32_16x16x4_f32 (exact f32 products) instead of split fp16
   std::vector<void *> owned;
   // run state
   int B = 0, n_text = 0, P = 0, max_pos = 0;
@@ -1154,6 +1162,7 @@ int ar_load(tts_ctx *ctx, const char *path) {
   int rc = read_weight_file(path, wf, err);
   if (rc != TTS_OK) return fail(ctx, rc, "autoregressive_model_load: %s", err.c_str());
   std::unique_ptr<ArState> st(new ArState());
+  st->f32_mfma = ctx->dec_f32_mfma != 0;
   const std::string hp = "inference_model.transformer.h.";
   while (wf.has(hp + std::to_string(st->n_layers) + ".ln_1.weight")) st->n_layers++;
   if (st->n_layers == 0) return fail(ctx, TTS_ERR_FORMAT, "no transformer layers in '%s'", path);
@@ -1188,12 +1197,12 @@ int ar_load(tts_ctx *ctx, const char *path) {
     std::vector<float> wfold, cfold;
     fold_layernorm(wf.t.at(p + ".attn.c_attn.weight").data.data(), D, 3 * D, wf.t.at(p + ".ln_1.weight").data.data(),
                    wf.t.at(p + ".ln_1.bias").data.data(), wf.t.at(p + ".attn.c_attn.bias").data.data(), wfold, cfold);
-    if (dec_f32_mfma && (r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, 3 * D), &l.d_attn))) return r;
+    if (st->f32_mfma && (r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, 3 * D), &l.d_attn))) return r;
     if ((r = upload_h(ctx, st.get(), pack_mfma16h(wfold.data(), D, 3 * D), &l.dh_attn))) return r;
     if ((r = upload(ctx, st.get(), cfold, &l.db_attn))) return r;
     fold_layernorm(wf.t.at(p + ".mlp.c_fc.weight").data.data(), D, FF, wf.t.at(p + ".ln_2.weight").data.data(),
                    wf.t.at(p + ".ln_2.bias").data.data(), wf.t.at(p + ".mlp.c_fc.bias").data.data(), wfold, cfold);
-    if (dec_f32_mfma && (r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, FF), &l.d_fc))) return r;
+    if (st->f32_mfma && (r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, FF), &l.d_fc))) return r;
     if ((r = upload_h(ctx, st.get(), pack_mfma16h(wfold.data(), D, FF), &l.dh_fc))) return r;
     if ((r = upload(ctx, st.get(), cfold, &l.db_fc))) return r;
     if ((r = upload(ctx, st.get(), pack_cols4(wf.t.at(p + ".attn.c_proj.weight").data.data(), D, D), &l.d_proj))) return r;
@@ -1264,7 +1273,7 @@ int ar_load(tts_ctx *ctx, const char *path) {
       std::vector<float> wfold, cfold;
       fold_layernorm(wt.data(), D, VPAD, wf.t.at("inference_model.lm_head.0.weight").data.data(),
                      wf.t.at("inference_model.lm_head.0.bias").data.data(), bt.data(), wfold, cfold);
-      if (dec_f32_mfma) { r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, VPAD), &st->d_lm); if (r) return r; }
+      if (st->f32_mfma) { r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, VPAD), &st->d_lm); if (r) return r; }
       r = upload_h(ctx, st.get(), pack_mfma16h(wfold.data(), D, VPAD), &st->dh_lm); if (r) return r;
       if (ctx->ar_weights == 1) { r = upload_h(ctx, st.get(), pack_mfma16q(wfold.data(), D, VPAD), &st->q_lm); if (r) return r; }
       if (ctx->ar_weights == 2) {
@@ -1353,9 +1362,8 @@ static int launch_mfma_matmul(tts_ctx *ctx, ArState *st, const float *X, int row
 #define CHECK(x) do { int _r = (x); if (_r) return _r; } while (0)
 #define DEC_LN_LAUNCH(EPI_, GRID_)                                                         \
   do {                                                                                     \
-    if (dec_f32_mfma) dec_ln_gemv_kernel<EPI_, 0><<<GRID_, 256, 0, ctx->stream>>>(a);       \
-    else if (dec_nt) dec_ln_gemv_kernel<EPI_, 1, true><<<GRID_, 256, 0, ctx->stream>>>(a);  \
-    else dec_ln_gemv_kernel<EPI_, 1><<<GRID_, 256, 0, ctx->stream>>>(a);                    \
+    if (st->f32_mfma) dec_ln_gemv_kernel<EPI_, 0><<<GRID_, 256, 0, ctx->stream>>>(a);       \
+    else dec_ln_gemv_kernel<EPI_, 1, true><<<GRID_, 256, 0, ctx->stream>>>(a);              \
   } while (0)
 
 
@@ -1522,8 +1530,7 @@ static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
     { ProfScope ps(ctx, "ar_gemv", 1.0 * D * D * wb * tiles);
       if (wm == 2) dec_gemv_resid_kernel<1, 256, 2><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, (const float *)w.o_proj, w.b_proj, h, w.os_proj);
       else if (wm == 1) dec_gemv_resid_kernel<1, 256, 1><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, (const float *)w.q_proj, w.b_proj, h);
-      else if (dec_nt) dec_gemv_resid_kernel<1, 256, 0, true><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, w.d_proj, w.b_proj, h);
-      else dec_gemv_resid_kernel<1><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, w.d_proj, w.b_proj, h); }
+      else dec_gemv_resid_kernel<1, 256, 0, true><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, w.d_proj, w.b_proj, h); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * wb * tiles);
       DecLnArgs a{h, nullptr, nullptr, w.d_fc, wm == 2 ? (const __half *)w.o_fc : wm == 1 ? w.q_fc : w.dh_fc, w.db_fc, B, FF, 0, 0, ff, nullptr, nullptr, ss, 0,
                   ctx->ggml_lut, w.os_fc};
@@ -1533,8 +1540,7 @@ static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * wb * tiles);
       if (wm == 2) dec_gemv_resid_kernel<4, 512, 2><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, (const float *)w.o_fc2, w.b_fc2, h, w.os_fc2);
       else if (wm == 1) dec_gemv_resid_kernel<4, 512, 1><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, (const float *)w.q_fc2, w.b_fc2, h);
-      else if (dec_nt) dec_gemv_resid_kernel<4, 512, 0, true><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, w.d_fc2, w.b_fc2, h);
-      else dec_gemv_resid_kernel<4, 512><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, w.d_fc2, w.b_fc2, h); }
+      else dec_gemv_resid_kernel<4, 512, 0, true><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, w.d_fc2, w.b_fc2, h); }
   }
   { ProfScope ps(ctx, "ar_gemv", (double)D * VPAD * wb * tiles);
     DecLnArgs a{h, st->lnf_g, st->lnf_b, st->d_lm, wm == 2 ? (const __half *)st->o_lm : wm == 1 ? st->q_lm : st->dh_lm, st->d_lmb, B, V, V, 0, st->logits.as<float>(),

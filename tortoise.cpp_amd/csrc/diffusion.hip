@@ -444,6 +444,177 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
   }
 }
 
+// Reference-precision AttentionBlock core (option attn_f32; main.cpp:3848-3875 evaluates QK^T, softmax and PV as F32 ggml_mul_mat /
+// ggml_soft_max). Same decomposition as diff_attn_kernel (128 queries of one (sequence, head) per workgroup, everything transposed, K rows
+// permuted so that P^T is the B operand of the second product), but every matrix product runs on SPLIT-PRECISION fp16 operands: x = hi + lo
+// with hi = fp16(x), lo = fp16(x - hi), and a.b ~ a_lo.b_hi + a_hi.b_lo + a_hi.b_hi on three v_mfma_f32_16x16x32_f16 (every partial
+// product is exact in f32, the dropped lo.lo term is 2^-22 relative: f32-class arithmetic, the scheme of the AR multi-row passes).
+//  * s = q.k * 0.125 + bias in f32 exactly as the reference orders it, running max, p = 2^((s - m) log2 e + 8) on the hardware exp2 (the
+//    factor 2^8 keeps the low halves of P out of the fp16 subnormals; it cancels in o / l),
+//  * row sums are f32 VALU adds of the unrounded p (not the matrix pipe over rounded values), one cross-lane reduction at the end,
+//  * the output o / l is written as a split pair for the split-precision proj_out GEMM.
+// LDS: 2 ring slots x (K hi | K lo | V^T hi | V^T lo) 8 KB tiles + the bias table. ~3x the matrix work of diff_attn_kernel: the parity
+// mode, not the throughput mode.
+static constexpr int ATT32_SLOT = 32768, ATT32_LDS = 2 * ATT32_SLOT + 128 * 4;
+__global__ __launch_bounds__(256, 2) void diff_attn_f32_kernel(const __half *__restrict__ qk_hi, const __half *__restrict__ qk_lo,
+                                                               const __half *__restrict__ vt_hi, const __half *__restrict__ vt_lo, int ldvt,
+                                                               const int *__restrict__ seq_start, const int *__restrict__ seq_len,
+                                                               const float *__restrict__ bias_tab, __half *__restrict__ out_hi,
+                                                               __half *__restrict__ out_lo, int nq) {
+  extern __shared__ __attribute__((aligned(16))) char smem[]; // ONE LDS object (see diff_attn_kernel)
+  float *tab = (float *)(smem + 2 * ATT32_SLOT);              // bias by signed distance d = key - query, clamped to +-63: tab[d + 64]
+  const int xcd = blockIdx.x & 7, tt = blockIdx.x >> 3;
+  const int pair = (tt / nq) * 8 + xcd, h = pair & 15, s = pair >> 4;
+  const int T = seq_len[s], r0 = seq_start[s], q0 = (tt % nq) * 128;
+  if (q0 >= T) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fq = lane >> 4;
+  const float L2E = 1.44269504088896f;
+  if (tid < 128) {
+    const int d = tid - 64, ad = d < 0 ? -d : d;
+    tab[tid] = bias_tab[h * 128 + (d > 0 ? 64 : 0) + (ad < 63 ? ad : 63)];
+  }
+  const int qw = q0 + wave * 32;
+  half8 qh[2][2], ql[2][2]; // Q[query = qw + i*16 + fr][d = ks*32 + fq*8 ..+7]
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const size_t off = (size_t)(r0 + qw + i * 16 + fr) * 2048 + h * 128 + ks * 32 + fq * 8;
+      qh[i][ks] = *(const half8 *)(qk_hi + off);
+      ql[i][ks] = *(const half8 *)(qk_lo + off);
+    }
+  asm volatile("" ::"v"(qh[0][0]), "v"(qh[0][1]), "v"(qh[1][0]), "v"(qh[1][1]), "v"(ql[0][0]), "v"(ql[0][1]), "v"(ql[1][0]), "v"(ql[1][1])); // retire the Q loads before the DMA queue starts
+  floatx4 o[2][4]; // O^T[d = dt*16 + fq*4 + r][query = qw + i*16 + fr]
+  float lsum[2], mrow[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+    lsum[i] = 0.f;
+    mrow[i] = -INFINITY;
+  }
+  const int nkb = (T + 63) >> 6;
+  const int prow = lane >> 3, pslot = lane & 7;
+  const size_t kofs = (size_t)r0 * 2048 + h * 128 + 64, vofs = (size_t)(h * 64) * ldvt + r0;
+  int koff[2], voff[2]; // per-lane source offsets (halves) inside a tile: see diff_attn_kernel (key permutation SIG, swizzle on the source chunk)
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int row = wave * 16 + i * 8 + prow, c = pslot ^ (row & 7);
+    const int jt = row >> 4, x = row & 15;
+    const int key = (jt >> 1) * 32 + (x >> 2) * 8 + (jt & 1) * 4 + (x & 3);
+    koff[i] = key * 2048 + c * 8;
+    voff[i] = row * ldvt + c * 8;
+  }
+  auto stage = [&](int kb, int slot) {
+    kb = min(kb, nkb - 1);
+    const size_t ko = kofs + (size_t)kb * (64 * 2048), vo = vofs + kb * 64;
+    char *dst = smem + slot * ATT32_SLOT + wave * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      __builtin_amdgcn_global_load_lds((gptr_t)(qk_hi + ko + koff[i]), (lptr_t)(dst + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(qk_lo + ko + koff[i]), (lptr_t)(dst + 8192 + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(vt_hi + vo + voff[i]), (lptr_t)(dst + 16384 + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(vt_lo + vo + voff[i]), (lptr_t)(dst + 24576 + i * 1024), 16, 0, 0);
+    }
+  };
+  stage(0, 0);
+  for (int kb = 0; kb < nkb; kb++) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // tile kb has landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();                    // ... everybody's; and nobody still reads tile kb-1, whose slot is restaged now
+    stage(kb + 1, (kb + 1) & 1);
+    const char *Kh = smem + (kb & 1) * ATT32_SLOT, *Kl = Kh + 8192, *Vh = Kh + 16384, *Vl = Kh + 24576;
+    floatx4 sc[2][4]; // sc[i][jt][r] = q . k of query i*16+fr and key SIG(jt, fq*4 + r) = kmin + (jt>>1)*32 + fq*8 + (jt&1)*4 + r
+#pragma unroll
+    for (int jt = 0; jt < 4; jt++) {
+      const half8 kh0 = *(const half8 *)(Kh + attn_off(jt * 16 + fr, fq)), kh1 = *(const half8 *)(Kh + attn_off(jt * 16 + fr, 4 + fq));
+      const half8 kl0 = *(const half8 *)(Kl + attn_off(jt * 16 + fr, fq)), kl1 = *(const half8 *)(Kl + attn_off(jt * 16 + fr, 4 + fq));
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        floatx4 a = (floatx4){0.f, 0.f, 0.f, 0.f}; // small terms first
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl0, qh[i][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl1, qh[i][1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh0, ql[i][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh1, ql[i][1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh0, qh[i][0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh1, qh[i][1], a, 0, 0, 0);
+        sc[i][jt] = a;
+      }
+    }
+    const int kmin = kb * 64;
+    half8 ph[2][2], pl[2][2]; // P^T in B-operand layout: slot e of step ks2 = key 32 ks2 + 8 fq + e
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int qi = qw + i * 16 + fr;
+      const int dbase = kmin + fq * 8 - qi; // d of (jt, r) = dbase + off, off = (jt>>1)*32 + (jt&1)*4 + r
+      const int left = T - kmin - fq * 8;   // keys of this lane with off < left exist
+      float mx = -INFINITY;
+#pragma unroll
+      for (int jt = 0; jt < 4; jt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int off = (jt >> 1) * 32 + (jt & 1) * 4 + r;
+          const float b = tab[min(max(dbase + off, -63), 63) + 64];
+          float v = fmaf(sc[i][jt][r], 0.125f, b); // bias + dot * (1 / sqrt(64)) (main.cpp:3851-3870)
+          v = off < left ? v : -INFINITY;
+          sc[i][jt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = rows4_max(mx);
+      const float mnew = fmaxf(mrow[i], mx);
+      const float alpha = __builtin_amdgcn_exp2f((mrow[i] - mnew) * L2E);
+      mrow[i] = mnew;
+      if (!__all(alpha == 1.0f)) {
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) o[i][dt][r] *= alpha;
+        lsum[i] *= alpha;
+      }
+      float part = 0.f;
+#pragma unroll
+      for (int ks2 = 0; ks2 < 2; ks2++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(sc[i][2 * ks2 + (e >> 2)][e & 3] - mnew, L2E, 8.0f));
+          part += p;
+          const _Float16 hi = (_Float16)p;
+          ph[i][ks2][e] = hi;
+          pl[i][ks2][e] = (_Float16)(p - (float)hi);
+        }
+      lsum[i] += part;
+    }
+    // O^T += V^T P^T : A = V^T[d = dt*16 + fr][keys 32 ks2 + 8 fq ..+7], B = P^T
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ks2++)
+#pragma unroll
+      for (int dt = 0; dt < 4; dt++) {
+        const half8 vh = *(const half8 *)(Vh + attn_off(dt * 16 + fr, 4 * ks2 + fq)), vl = *(const half8 *)(Vl + attn_off(dt * 16 + fr, 4 * ks2 + fq));
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[i][ks2], o[i][dt], 0, 0, 0);
+          o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[i][ks2], o[i][dt], 0, 0, 0);
+          o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[i][ks2], o[i][dt], 0, 0, 0);
+        }
+      }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the trailing (clamped) DMA pieces must land before the LDS is released
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int qi = qw + i * 16 + fr;
+    const float l = rows4_sum(lsum[i]);
+    if (qi < T) {
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int dt = 0; dt < 4; dt++) {
+        const float v0 = o[i][dt][0] * inv, v1 = o[i][dt][1] * inv, v2 = o[i][dt][2] * inv, v3 = o[i][dt][3] * inv;
+        const size_t off = (size_t)(r0 + qi) * C + h * 64 + dt * 16 + fq * 4;
+        *(uint2 *)(out_hi + off) = pack_half4(v0, v1, v2, v3);
+        *(uint2 *)(out_lo + off) = pack_half4(split_lo(v0), split_lo(v1), split_lo(v2), split_lo(v3));
+      }
+    }
+  }
+}
+
 // nearest-neighbour upsample of the code embedding L -> T (ggml_upscale_ext: src = (int)(dst / ((float)T/L)))
 // for the conditioned sequences, unconditioned_embedding broadcast for the others. One block per row.
 __global__ __launch_bounds__(256) void build_code_emb_kernel(const float *__restrict__ lat_emb, const int *__restrict__ lat_start,
@@ -569,7 +740,11 @@ __global__ void rows_to_ct_kernel(const float *__restrict__ net, int row0, int T
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-struct AttnDev { float *norm_g, *norm_b, *qkv_b, *proj_b, *bias_tab; __half *qkv_w, *proj_w; };
+struct AttnDev {
+  float *norm_g, *norm_b, *qkv_b, *proj_b, *bias_tab;
+  __half *qkv_w, *proj_w;
+  __half *proj_w_split; // [C][hi(64 w) | lo(64 w)]: proj_out's F32 weight as a split-precision pair (option attn_f32; the factor 64 keeps the low halves normal)
+};
 struct ResDev { float *in_g, *in_b, *in_bias, *emb_w, *emb_b, *out_g, *out_b, *out_bias; __half *in_w, *out_w; };
 
 // Packed row layout: sequence s occupies rows [start[s], start[s]+len[s]); start % 8 == 0; at least one
@@ -604,6 +779,7 @@ struct Layout {
 struct Work {
   int rows = 0;
   DevBuf x, hbuf, a16, att16, qk16, vt16, stats;
+  DevBuf att16_lo, qk16_lo, vt16_lo; // low halves of the split-precision pairs (option attn_f32)
   float *X() { return x.as<float>(); }
   float *H() { return hbuf.as<float>(); }
   __half *A16() { return a16.as<__half>() + C; }
@@ -623,6 +799,11 @@ struct Work {
     TTS_HIP(ctx, rz(qk16, (size_t)(r + 128) * 2048 * 2));
     TTS_HIP(ctx, rz(vt16, (size_t)C * (r + 128) * 2));
     TTS_HIP(ctx, rz(stats, (size_t)ns * 32 * sizeof(float2)));
+    if (ctx->attn_f32) {
+      TTS_HIP(ctx, rz(att16_lo, (size_t)(r + 2) * C * 2));
+      TTS_HIP(ctx, rz(qk16_lo, (size_t)(r + 128) * 2048 * 2));
+      TTS_HIP(ctx, rz(vt16_lo, (size_t)C * (r + 128) * 2));
+    }
     return TTS_OK;
   }
 };
@@ -717,6 +898,18 @@ struct Loader {
     if ((r = conv16(p + ".qkv.weight", 3 * C, C, 1, 3 * C, C, &a.qkv_w))) return r;
     if ((r = f32(p + ".qkv.bias", 3 * C, &a.qkv_b))) return r;
     if ((r = conv16(p + ".proj_out.weight", C, C, 1, C, C, &a.proj_w))) return r;
+    {
+      const HostTensor *t = get(p + ".proj_out.weight", (int64_t)C * C);
+      std::vector<__half> sp((size_t)C * 2 * C);
+      for (int n = 0; n < C; n++)
+        for (int k = 0; k < C; k++) {
+          const float w = t->data[(size_t)n * C + k] * 64.0f;
+          const __half hi = __float2half_rn(w);
+          sp[(size_t)n * 2 * C + k] = hi;
+          sp[(size_t)n * 2 * C + C + k] = __float2half_rn(w - __half2float(hi));
+        }
+      if ((r = put(sp, &a.proj_w_split))) return r;
+    }
     if ((r = f32(p + ".proj_out.bias", C, &a.proj_b))) return r;
     const HostTensor *t = get(p + ".relative_pos_embeddings.relative_attention_bias.weight", 32 * 16);
     if (!t) return TTS_ERR_FORMAT;
@@ -800,6 +993,7 @@ int diff_load(tts_ctx *ctx, const char *path) {
 #undef R
   for (auto &kv : wf.t)
     if (!ld.used.count(kv.first)) return fail(ctx, TTS_ERR_FORMAT, "unknown tensor '%s' in model file", kv.first.c_str());
+  TTS_HIP(ctx, hipFuncSetAttribute((const void *)diff_attn_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT32_LDS)); // > 64 KB of dynamic LDS
   if (ctx->diff) diff_free(ctx->diff);
   ctx->diff = st.release();
   return TTS_OK;
@@ -848,7 +1042,7 @@ static int gn_stats(tts_ctx *ctx, const Layout &lay, Work &wk, const float *x) {
 // (T <= NJ * NT / 8 rows) is read from HBM exactly once into NJ float4 per thread, mean and centred variance are
 // reduced across the workgroup (two-pass on registers), and the normalised fp16 rows are written straight out.
 template <int NT, int NJ>
-__global__ __launch_bounds__(NT) void gn_reg_kernel(int getenv_gn_xcd, const float *__restrict__ x, const int *__restrict__ seq_start,
+__global__ __launch_bounds__(NT) void gn_reg_kernel(const float *__restrict__ x, const int *__restrict__ seq_start,
                                                     const int *__restrict__ seq_len, int rows_total, int ns, float eps,
                                                     const float *__restrict__ g, const float *__restrict__ b,
                                                     const float *__restrict__ ss, int do_silu, int lut, __half *__restrict__ y,
@@ -858,12 +1052,8 @@ __global__ __launch_bounds__(NT) void gn_reg_kernel(int getenv_gn_xcd, const flo
   __shared__ unsigned pf_sink[NW][64]; // landing zone of the weight touch below
   // workgroup b runs on XCD b % 8: give each XCD whole sequences (all 32 groups of a row = the full 4 KB row go
   // through one L2) instead of 128-byte slices of every row
-  int grp = blockIdx.x, s = blockIdx.y;
-  if (getenv_gn_xcd) {
-    const int b = blockIdx.y * 32 + blockIdx.x, nb = ns * 32, xcd = b & 7, j = b >> 3;
-    const int q = nb >> 3, item = xcd * q + j; // nb % 8 == 0 (32 groups)
-    s = item >> 5; grp = item & 31;
-  }
+  const int bid = blockIdx.y * 32 + blockIdx.x, nbk = ns * 32, item = (bid & 7) * (nbk >> 3) + (bid >> 3); // nbk % 8 == 0 (32 groups)
+  const int s = item >> 5, grp = item & 31;
   const int T = seq_len[s], r0 = seq_start[s];
   const int q = threadIdx.x & 7, c = grp * 32 + q * 4, t0 = threadIdx.x >> 3;
   const float *base = x + (size_t)r0 * C + c;
@@ -961,12 +1151,10 @@ static int gn_fused(tts_ctx *ctx, const Layout &lay, const float *x, const float
                     __half *y, const void *wa = nullptr, size_t wa_bytes = 0, const void *wb = nullptr, size_t wb_bytes = 0) {
   ProfScope ps(ctx, "diff_gn_fused");
   const int tmax = lay.max_len();
-  static const int gn_xcd = getenv("TTS_GN_NOXCD") ? 0 : 1; // A/B switch
-  // measured (tools/gn_touch_ab.sh): one utterance 165.2 -> 156.6 ms per diffusion stage with the touch; the 16-candidate batch 864.8 -> 874.0 ms
+  // measured (round 3): one utterance 165.2 -> 156.6 ms per diffusion stage with the touch; the 16-candidate batch 864.8 -> 874.0 ms
   // (its GEMMs re-use every weight line from thousands of tiles: the touch only adds requests) -> small problems only
-  static const bool touch = getenv("TTS_GN_NOTOUCH") == nullptr; // A/B switch
-  if (!touch || lay.rows > 4096) { wa_bytes = 0; wb_bytes = 0; }
-#define GN_ARGS gn_xcd, x, lay.d_start.as<int>(), lay.d_len.as<int>(), lay.rows, lay.ns, ctx->gn_eps, g, b, ss, do_silu, ctx->ggml_lut, y, \
+  if (lay.rows > 4096) { wa_bytes = 0; wb_bytes = 0; }
+#define GN_ARGS x, lay.d_start.as<int>(), lay.d_len.as<int>(), lay.rows, lay.ns, ctx->gn_eps, g, b, ss, do_silu, ctx->ggml_lut, y, \
                 (const char *)wa, (int)(wa_bytes >> 7), (const char *)wb, (int)(wb_bytes >> 7)
   if (tmax <= 14 * 64) gn_reg_kernel<512, 14><<<dim3(32, lay.ns), 512, 0, ctx->stream>>>(GN_ARGS);
   else if (tmax <= 18 * 128) gn_reg_kernel<1024, 18><<<dim3(32, lay.ns), 1024, 0, ctx->stream>>>(GN_ARGS);
@@ -985,25 +1173,42 @@ static int res_in_layers(tts_ctx *ctx, const Layout &lay, Work &wk, const float 
   return gemm(ctx, "diff_gemm", g, lay);
 }
 
-// AttentionBlock on X (in place).
+// AttentionBlock on X (in place). Two arithmetic modes (option attn_f32):
+//   0  throughput mode (north star: "MFMA ... for the dense fp16 GEMMs in attention"): q, k, v, P, the attention output and the
+//      proj_out weight are fp16 MFMA operands, f32 accumulation;
+//   1  reference precision (main.cpp:3848-3875: F32 QK^T, softmax, PV and proj_out): the same products on split-precision fp16 pairs
+//      (hi + lo, three MFMAs per product, 2^-22 relative) — the parity mode, as ar_weights = 0 is for the AR stage.
 static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, float *X, const AttnDev &w) {
+  const bool f32 = ctx->attn_f32 != 0;
   CHECK(gn_fused(ctx, lay, X, w.norm_g, w.norm_b, nullptr, 0, wk.A16(), w.qkv_w, (size_t)3 * C * C * 2, w.proj_w, (size_t)C * C * 2));
   GemmArgs g = gemm_base(lay, wk.A16(), C, 1, C, w.qkv_w, 3 * C, w.qkv_b);
-  g.mode = GEMM_OUT_QKV; g.outH = wk.qk16.as<__half>(); g.ldh = 2048; g.outVt = wk.vt16.as<__half>(); g.ldvt = wk.rows + 128;
+  g.mode = f32 ? GEMM_OUT_QKV_SPLIT : GEMM_OUT_QKV;
+  g.outH = wk.qk16.as<__half>(); g.ldh = 2048; g.outVt = wk.vt16.as<__half>(); g.ldvt = wk.rows + 128;
+  g.outH2 = wk.qk16_lo.as<__half>(); g.outVt2 = wk.vt16_lo.as<__half>();
   CHECK(gemm(ctx, "diff_gemm", g, lay));
   {
     double aw = 0;
     for (int l : lay.len) aw += 4.0 * l * (double)l * 64 * NHEAD; // QK^T + PV
     ProfScope ps(ctx, "diff_attn", aw);
     const int nq = (lay.max_len() + 127) / 128;
-    // measured (interleaved A/B, tools/diff_prof.py): 4 workgroups per CU with one tile in flight 162.5-163.0 us per
-    // launch, 3 workgroups with two tiles in flight 168.2-168.9 us
-    static const bool ring2 = getenv("TTS_ATT_RING3") == nullptr; // A/B switch
-    if (ring2) diff_attn_kernel<2><<<nq * NHEAD * lay.ns, 256, att_lds<2>(), ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128,
-                                                                   lay.d_start.as<int>(), lay.d_len.as<int>(), w.bias_tab, wk.ATT16(), nq);
-    else diff_attn_kernel<3><<<nq * NHEAD * lay.ns, 256, att_lds<3>(), ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128,
-                                                                   lay.d_start.as<int>(), lay.d_len.as<int>(), w.bias_tab, wk.ATT16(), nq);
+    if (f32) {
+      diff_attn_f32_kernel<<<nq * NHEAD * lay.ns, 256, ATT32_LDS, ctx->stream>>>(wk.qk16.as<__half>(), wk.qk16_lo.as<__half>(), wk.vt16.as<__half>(),
+                                                                                 wk.vt16_lo.as<__half>(), wk.rows + 128, lay.d_start.as<int>(),
+                                                                                 lay.d_len.as<int>(), w.bias_tab, wk.ATT16(), wk.att16_lo.as<__half>() + C, nq);
+    } else {
+      // one K/V tile in flight at 4 workgroups per CU (162.5-163.0 us per launch) beat two tiles in flight at 3 per CU (168.2-168.9 us; round 2)
+      diff_attn_kernel<2><<<nq * NHEAD * lay.ns, 256, att_lds<2>(), ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128,
+                                                                               lay.d_start.as<int>(), lay.d_len.as<int>(), w.bias_tab, wk.ATT16(), nq);
+    }
     TTS_HIP(ctx, hipGetLastError());
+  }
+  if (f32) { // att . W^T = att_hi . W_hi + att_lo . W_hi + att_hi . W_lo  (W scaled by 64 at load)
+    GemmArgs p = gemm_base(lay, wk.ATT16(), C, 3, C, w.proj_w_split, C, w.proj_b);
+    p.A[0] = wk.ATT16(); p.A[1] = wk.att16_lo.as<__half>() + C; p.A[2] = wk.ATT16();
+    p.row_off[0] = p.row_off[1] = p.row_off[2] = 0;
+    p.custom_w = 1; p.ldw_ = 2 * C; p.w_off_[0] = 0; p.w_off_[1] = 0; p.w_off_[2] = C;
+    p.mode = GEMM_OUT_F32_SCALED; p.alpha = 1.0f / 64.0f; p.outF = X; p.ldo = C; p.resid = X;
+    return gemm(ctx, "diff_gemm", p, lay, 0, C);
   }
   GemmArgs p = gemm_base(lay, wk.ATT16(), C, 1, C, w.proj_w, C, w.proj_b);
   p.mode = GEMM_OUT_F32; p.outF = X; p.ldo = C; p.resid = X;

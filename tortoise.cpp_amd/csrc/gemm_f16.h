@@ -42,7 +42,12 @@ namespace tts {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-enum { GEMM_OUT_F32 = 0, GEMM_OUT_F16 = 1, GEMM_OUT_QKV = 2 };
+// GEMM_OUT_QKV_SPLIT: the QKV projection of the reference-precision AttentionBlock (option attn_f32): every f32 result x is stored as the
+// fp16 pair hi = fp16(x), lo = fp16(x - hi) (hi + lo = x to 2^-22) in outH / outH2 and outVt / outVt2.
+// GEMM_OUT_F32_SCALED: out = alpha * acc + bias + resid (split-precision operands whose weights were scaled by 1 / alpha at load).
+enum { GEMM_OUT_F32 = 0, GEMM_OUT_F16 = 1, GEMM_OUT_QKV = 2, GEMM_OUT_QKV_SPLIT = 3, GEMM_OUT_F32_SCALED = 4 };
+constexpr bool gemm_mode_qkv(int mode) { return mode == GEMM_OUT_QKV || mode == GEMM_OUT_QKV_SPLIT; }
+constexpr bool gemm_mode_f32(int mode) { return mode == GEMM_OUT_F32 || mode == GEMM_OUT_F32_SCALED; }
 
 struct GemmArgs {
   const __half *A[3];  // per segment base (row 0 of the packed layout)
@@ -59,6 +64,8 @@ struct GemmArgs {
   // GEMM_OUT_F16 (n_valid columns written) / GEMM_OUT_QKV
   __half *outH; int ldh;
   __half *outVt; int ldvt; // QKV: V channels transposed [h*64+d][row]
+  __half *outH2, *outVt2;  // GEMM_OUT_QKV_SPLIT: the low halves (same leading dimensions)
+  float alpha;             // GEMM_OUT_F32_SCALED
   int mode;
   // tile walk, set by launch_gemm_f16: th = 16-row blocks per tile (0: chosen from the problem size), cn = column tiles per L2 chunk
   int th, cn;
@@ -99,6 +106,8 @@ typedef void __attribute__((address_space(3))) *lptr_t;
 // splits 4 / 3) and 64 columns: acc[i][j] = block wm + 2 i, columns wn * 64 + j * 16 ..
 __device__ __forceinline__ int vh_blk(int wm, int i) { return wm + 2 * i; }
 
+// low half of the split-precision pair of x: x - fp16(x), exact in f32, then rounded to fp16
+__device__ __forceinline__ float split_lo(float x) { return x - __half2float(__float2half_rn(x)); }
 __device__ __forceinline__ uint2 pack_half4(float a, float b, float c, float d) {
   const __half2 p0 = __floats2half2_rn(a, b), p1 = __floats2half2_rn(c, d);
   uint2 u;
@@ -119,7 +128,7 @@ template <int MODE, int MI, int RESID>
 __device__ __forceinline__ void gemm_epilogue_vh(const GemmArgs &g, floatx4 (&acc)[MI > 0 ? MI : 1][4], int m0, int n0, int wm, int wn, int fr, int fq) {
   constexpr int MA = MI > 0 ? MI : 1;
   if (MI == 0) return;
-  if (MODE == GEMM_OUT_QKV) {
+  if (gemm_mode_qkv(MODE)) {
     // col = h*192 + {q 0..63 | k 64..127 | v 128..191}; a wave's 64-column span is entirely q, k or v.
     const int c0 = n0 + wn * 64, h = c0 / 192, w0 = c0 - h * 192;
     if (w0 >= 128) { // V, natural operand order: lane = 4 consecutive rows of one column -> 8-byte transposed store
@@ -147,6 +156,8 @@ __device__ __forceinline__ void gemm_epilogue_vh(const GemmArgs &g, floatx4 (&ac
 #pragma unroll
           for (int r = 0; r < 4; r++) v[r] = gd[r] ? 0.f : acc[i][j][r] + bv[j];
           *(uint2 *)(g.outVt + (size_t)(h * 64 + j * 16 + fr) * g.ldvt + rbase) = pack_half4(v[0], v[1], v[2], v[3]);
+          if (MODE == GEMM_OUT_QKV_SPLIT)
+            *(uint2 *)(g.outVt2 + (size_t)(h * 64 + j * 16 + fr) * g.ldvt + rbase) = pack_half4(split_lo(v[0]), split_lo(v[1]), split_lo(v[2]), split_lo(v[3]));
         }
       }
       return;
@@ -179,11 +190,12 @@ __device__ __forceinline__ void gemm_epilogue_vh(const GemmArgs &g, floatx4 (&ac
 #pragma unroll
   for (int i = 0; i < MI; i++) sq[i] = hs ? sq[i] : 0;
   auto finish = [&](int i, int j) { // bias, guard
+    if (MODE == GEMM_OUT_F32_SCALED) acc[i][j] *= g.alpha;
     float4 v = make_float4(acc[i][j][0] + b4[j].x, acc[i][j][1] + b4[j].y, acc[i][j][2] + b4[j].z, acc[i][j][3] + b4[j].w);
     if (sq[i] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
     return v;
   };
-  if (MODE == GEMM_OUT_F32) {
+  if (gemm_mode_f32(MODE)) {
     if (RESID == EPI_RESID_LOAD) {
       // residual read here (k = 3 kernel): blocks in pairs, the next pair's 8 loads are in flight while this pair is stored
       constexpr int NP = (MI + 1) / 2;
@@ -197,6 +209,7 @@ __device__ __forceinline__ void gemm_epilogue_vh(const GemmArgs &g, floatx4 (&ac
 #pragma unroll
             for (int j = 0; j < 4; j++) {
               // same f32 adds in the same order as before: (acc + bias) + resid
+              if (MODE == GEMM_OUT_F32_SCALED) acc[i][j] *= g.alpha;
               float4 t = make_float4(acc[i][j][0] + b4[j].x, acc[i][j][1] + b4[j].y, acc[i][j][2] + b4[j].z, acc[i][j][3] + b4[j].w);
               t.x += rr[q][j].x; t.y += rr[q][j].y; t.z += rr[q][j].z; t.w += rr[q][j].w;
               if (sq[i] < 0) t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -242,6 +255,8 @@ __device__ __forceinline__ void gemm_epilogue_vh(const GemmArgs &g, floatx4 (&ac
       for (int j = 0; j < 4; j++) {
         const float4 v = finish(i, j);
         *(uint2 *)(op + j * 16) = pack_half4(v.x, v.y, v.z, v.w);
+        if (MODE == GEMM_OUT_QKV_SPLIT)
+          *(uint2 *)(g.outH2 + (op - g.outH) + j * 16) = pack_half4(split_lo(v.x), split_lo(v.y), split_lo(v.z), split_lo(v.w));
       }
     }
   }
@@ -296,7 +311,7 @@ __device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, 
   }
   char *sa = smem, *sb = smem + 16384;
   // operand order (see gemm_epilogue_vh): natural only for the V columns of a QKV projection (wave-uniform)
-  const bool natural = (MODE == GEMM_OUT_QKV) && (((n0 + wn * 64) % 192) >= 128);
+  const bool natural = gemm_mode_qkv(MODE) && (((n0 + wn * 64) % 192) >= 128);
   GEMM_TR(1);
   // the K loop is instantiated once per operand order so the choice costs nothing inside it
   auto kloop = [&](auto nat) {
@@ -346,10 +361,11 @@ __device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, 
       }
     }
   };
-  if (MODE == GEMM_OUT_QKV && natural) kloop(std::true_type{});
+  if (gemm_mode_qkv(MODE) && natural) kloop(std::true_type{});
   else kloop(std::false_type{});
   GEMM_TR(3);
   if (resid_first) gemm_epilogue_vh<MODE, MI, EPI_RESID_IN_ACC>(g, acc, m0, n0, wm, wn, fr, fq);
+  else if (MODE == GEMM_OUT_F32_SCALED && g.resid) gemm_epilogue_vh<MODE, MI, EPI_RESID_LOAD>(g, acc, m0, n0, wm, wn, fr, fq);
   else gemm_epilogue_vh<MODE, MI, EPI_NO_RESID>(g, acc, m0, n0, wm, wn, fr, fq);
   GEMM_TR(4);
 }
@@ -519,7 +535,7 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_vh_kernel(GemmAr
 // k = 3 convolution (three row-shifted segments of one activation buffer, tap-major weights): shared-slab kernel
 static inline bool gemm_is_conv3(const GemmArgs &g) {
   return g.nseg == 3 && !g.custom_w && g.A[0] == g.A[1] && g.A[1] == g.A[2] && g.row_off[0] == -1 && g.row_off[1] == 0 && g.row_off[2] == 1 &&
-         g.mode != GEMM_OUT_QKV;
+         !gemm_mode_qkv(g.mode) && g.mode != GEMM_OUT_F32_SCALED;
 }
 
 static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
@@ -563,7 +579,9 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
     else gemm_f16_conv3_vh_kernel<GEMM_OUT_F16><<<grid, 256, CONV3_VH_LDS, s>>>(gg);
   } else if (g.mode == GEMM_OUT_F32) gemm_f16_vh_kernel<GEMM_OUT_F32, 4><<<grid, 256, GEMM_VH_LDS, s>>>(gg);
   else if (g.mode == GEMM_OUT_F16) gemm_f16_vh_kernel<GEMM_OUT_F16, 4><<<grid, 256, GEMM_VH_LDS, s>>>(gg);
-  else gemm_f16_vh_kernel<GEMM_OUT_QKV, 4><<<grid, 256, GEMM_VH_LDS, s>>>(gg);
+  else if (g.mode == GEMM_OUT_QKV) gemm_f16_vh_kernel<GEMM_OUT_QKV, 4><<<grid, 256, GEMM_VH_LDS, s>>>(gg);
+  else if (g.mode == GEMM_OUT_QKV_SPLIT) gemm_f16_vh_kernel<GEMM_OUT_QKV_SPLIT, 4><<<grid, 256, GEMM_VH_LDS, s>>>(gg);
+  else gemm_f16_vh_kernel<GEMM_OUT_F32_SCALED, 4><<<grid, 256, GEMM_VH_LDS, s>>>(gg);
   return hipGetLastError();
 }
 
