@@ -226,12 +226,14 @@ int tts_host_trimmed_rows(const int32_t *codes502);
 /* Mel front-end of the two voice-conditioning encoders (host arithmetic, f64 inside; no counterpart in the reference, which has no audio input):
  * STFT n_fft = win = 1024, hop 256, periodic Hann, centre = true with reflect padding, frames = n / 256 + 1 (tts_host_mel_frames); n > 512.
  * tts_host_mel_diffusion100: 24 kHz audio -> [100][frames], upstream TacotronSTFT(1024, 256, 1024, 100, 24000, 0, 12000) magnitude mel (librosa
- *   Slaney filterbank), log(clamp 1e-5), normalised to [-1, 1] (normalize_tacotron_mel) = the input of tts_diffusion_conditioning_latent.
+ *   Slaney filterbank), log(clamp 1e-5). normalize = 0: as is = the input of tts_diffusion_conditioning_latent (upstream get_conditioning_latents:
+ *   wav_to_univnet_mel(..., do_normalization = False)); normalize = 1: mapped to [-1, 1] (normalize_tacotron_mel) = the scale of the diffusion
+ *   stage's output, which the vocoder driver de-normalises (main.cpp:6044-6060).
  * tts_host_mel_voice80: 22.05 kHz audio -> [80][frames], torchaudio MelSpectrogram(power 2, f_max 8000, norm "slaney", HTK mel scale),
  *   log(clamp 1e-5), divided per band by mel_norms80 (upstream's data/mel_norms.pth; NULL = no division) = the input of tts_voice_latent.
  * Return the frame count or a negative status. */
 int tts_host_mel_frames(int64_t n_samples);
-int tts_host_mel_diffusion100(const float *audio24k, int64_t n, float *mel_out);
+int tts_host_mel_diffusion100(const float *audio24k, int64_t n, int normalize, float *mel_out);
 int tts_host_mel_voice80(const float *audio22k, int64_t n, const float *mel_norms80, float *mel_out);
 /* The weight quantiser of option ar_weights = 2: OCP fp8 e4m3 (1-4-3, bias 7, largest finite 448, no infinities) code of v, round to
  * nearest even, saturating; NaN -> 0x7f. No counterpart in the reference. */

@@ -336,7 +336,7 @@ _ref = None
 class Clvp:
     """CLVP re-ranker (SURVEY section 8 f2), numpy restatement of the UPSTREAM tortoise-tts model (tortoise/models/clvp.py, use_xformers=True;
     its vendored x-transformers Encoder: RMSNorm pre-norm `x / max(|x| d^-1/2, 1e-8) * g`, bias-free q/k/v projections, rotary embedding on
-    the first 32 of the 64 head dims (half-split rotate, base 10000), softmax(q k^T / 8) v, to_out with bias, GEGLU feed-forward with
+    the first 32 of the 64 head dims of q, k and v (half-split rotate, base 10000), softmax(q k^T / 8) v, to_out with bias, GEGLU feed-forward with
     ff_mult = 2 (erf GELU), final LayerNorm; mean over the sequence, bias-free latent projection, L2 normalise, dot x exp(temperature)).
     The reference has NO CLVP (main.cpp:6575 takes candidate 0), so there is no reference file:line to cite and no fixture: PARITY UNPINNED —
     this class is pinned only against the torch restatement of the same equations (tests/torch_ref.py: TorchCLVP)."""
@@ -382,7 +382,7 @@ class Clvp:
             f = "%s.transformer.attn_layers.layers.%d." % (enc, 2 * i + 1)
             y = rms(x, self._t(a + "0.g", d))
             q, k, v = ((y @ self._t(a + "1.%s.weight" % nm, self.inner, d).T).reshape(n, H, 64).transpose(1, 0, 2) for nm in ("to_q", "to_k", "to_v"))
-            q, k = rope(q), rope(k)
+            q, k, v = rope(q), rope(k), rope(v)  # upstream's vendored x-transformers rotates the first 32 dims of q, k AND v
             sc = (q @ k.transpose(0, 2, 1)) * self.dt(0.125)
             sc = np.exp(sc - sc.max(-1, keepdims=True))
             att = sc / sc.sum(-1, keepdims=True)

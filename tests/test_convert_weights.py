@@ -162,3 +162,53 @@ def test_diffusion_conditioning_encoder_from_the_diffusion_checkpoint(tmp_path, 
     a = oracle.DiffusionConditioning(oracle.Model(src)).latent(mels)
     b = oracle.DiffusionConditioning(oracle.Model(out + "/ggml-diffusion-conditioning-model.bin")).latent(mels)
     assert (a == b).all()
+
+
+def test_expected_tensor_lists_match_the_synthetic_writers(tmp_path):
+    """tools/convert_weights.py --list-expected is the contract a real checkpoint is checked against; the synthetic writers
+    (tortoise_cpp_amd/synth_weights.py) are what every parity test runs on. They were written independently (loader contracts vs generator):
+    names and container shapes must agree tensor for tensor, for all six containers, so that neither drifts away from the loaders unnoticed."""
+    import importlib.util
+    import tortoise_cpp_amd_loader
+    tortoise_cpp_amd_loader.load()
+    from tortoise_cpp_amd import synth_weights as sw
+    spec = importlib.util.spec_from_file_location("convert_weights", os.path.join(ROOT, "tools", "convert_weights.py"))
+    cw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cw)
+    d = str(tmp_path)
+    sw.write_all(d, ar_layers=2, diff_main=2, diff_tail=1, diff_integ=1, diff_lc=2, seed=5)
+    sw.write_clvp(d + "/clvp.bin", depth=2, seed=6)
+    sw.write_voice_encoder(d + "/venc.bin", blocks=2, seed=7)
+    sw.write_diffusion_conditioning_encoder(d + "/dcond.bin", blocks=2, seed=8)
+    cases = (("ar", "ggml-model.bin", dict(layers=2)), ("diffusion", "ggml-diffusion-model.bin", dict(lc=2, integ=1, main=2, tail=1)),
+             ("vocoder", "ggml-vocoder-model.bin", {}), ("clvp", "clvp.bin", dict(depth=2)), ("conditioning-encoder", "venc.bin", dict(blocks=2)),
+             ("diffusion-conditioning-encoder", "dcond.bin", dict(blocks=2)))
+    for kind, fn, arch in cases:
+        have = {k: tuple(v.shape) for k, v in sw.read_ggml(os.path.join(d, fn)).items()}
+        exp = {k: cw.container_shape(kind, k, shp) for k, shp in cw.expected_tensors(kind, **arch).items()}
+        if kind == "diffusion":
+            exp["diffusion_conditioning_latent"] = (1, 2048)  # from --diffusion-conditioning-latent, not from the checkpoint
+        assert sorted(have) == sorted(exp), (kind, sorted(set(have) ^ set(exp))[:8])
+        for k in exp:
+            assert have[k] == exp[k], (kind, k, have[k], exp[k])
+        assert not cw.check_against(kind, {k: np.zeros(s, np.float32) for k, s in have.items()}), kind
+    # the upstream architecture: the counts a maintainer should see in --list-expected
+    assert len(cw.expected_tensors("ar")) == 4 + 30 * 12 + 6 and len(cw.expected_tensors("clvp")) == 5 + 2 * (20 * 11 + 2)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "convert_weights.py"), "--list-expected", "vocoder"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "res_stack.2.kernel_predictor.kernel_conv.weight" in r.stdout and "24576x64x3" in r.stdout
+
+
+def test_converter_reports_a_name_diff_instead_of_a_keyerror(small_models, tmp_path):
+    """a checkpoint whose tensor names differ from the expected ones (here: one renamed, one missing) is refused with the list of what is
+    missing, before anything is written"""
+    ar, df, vc = _to_state_dicts(small_models, str(tmp_path))
+    sd = torch.load(str(tmp_path / "diffusion_decoder.pth"), weights_only=True)
+    sd["code_norm_renamed.weight"] = sd.pop("code_norm.weight")
+    del sd["layers.0.attn.qkv.bias"]
+    torch.save(sd, str(tmp_path / "bad.pth"))
+    out = str(tmp_path / "out_bad")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "convert_weights.py"), "--diffusion", str(tmp_path / "bad.pth"),
+                        "--diffusion-conditioning-latent", str(tmp_path / "voice_diff.pth"), "--out", out], capture_output=True, text=True, timeout=300)
+    msg = r.stdout + r.stderr
+    assert r.returncode != 0 and "code_norm.weight" in msg and "layers.0.attn.qkv.bias" in msg and "KeyError" not in msg
+    assert not os.path.exists(os.path.join(out, "ggml-diffusion-model.bin"))

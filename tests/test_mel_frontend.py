@@ -46,8 +46,10 @@ def test_mel_frontends(pkg, n):
     assert mag.shape == (513, n // 256 + 1) and pkg.lib().tts_host_mel_frames(n) == n // 256 + 1
     # diffusion side: magnitude, librosa filterbank, log clamp, tacotron normalisation
     want = np.log(np.maximum(_fb(100, 24000.0, 0.0, 12000.0, False) @ mag, 1e-5))
+    got = pkg.host_mel_diffusion100(audio)  # un-normalised: what upstream feeds the diffusion conditioning encoder (do_normalization=False)
+    assert got.shape == want.shape and np.abs(got - want).max() < 2e-5 * 11.6 and got.min() >= np.float32(np.log(1e-5)) - 1e-5
     want = 2 * ((want + 11.512925148010254) / (2.3143386840820312 + 11.512925148010254)) - 1
-    got = pkg.host_mel_diffusion100(audio)
+    got = pkg.host_mel_diffusion100(audio, normalize=True)  # the [-1, 1] scale of the diffusion stage's output
     assert got.shape == want.shape and np.abs(got - want).max() < 2e-5
     # AR side: power, HTK scale with Slaney normalisation, log clamp, per-band norms
     norms = (1.0 + rs.rand(80)).astype(np.float32)

@@ -315,7 +315,7 @@ class TorchCLVP:
             def rope(t):
                 tl, tr = t[..., :32], t[..., 32:]
                 return torch.cat((tl * fr.cos() + self._rot_half(tl) * fr.sin(), tr), dim=-1)
-            q, k = rope(q), rope(k)
+            q, k, v = rope(q), rope(k), rope(v)  # tortoise-tts models/xtransformers.py Attention.forward: apply_rotary_pos_emb on (ql, kl, vl)
             att = torch.softmax((q @ k.transpose(-1, -2)) * 0.125, dim=-1)
             o = (att @ v).transpose(0, 1).reshape(n, H * 64)
             x = x + o @ w[a + "1.to_out.weight"].T + w[a + "1.to_out.bias"]

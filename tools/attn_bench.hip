@@ -3,11 +3,14 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -DTTS_ATT_TRACE=100 -I include -I tortoise.cpp_amd/csrc \
 //         tools/attn_bench.hip tortoise.cpp_amd/csrc/host_logic.cpp -o tools/attn_bench_bin   (TTS_ATT_TRACE = traced workgroup id)
 #include "../tortoise.cpp_amd/csrc/diffusion.hip"
+#include "attn_r3_kernel.h"
+#include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 using namespace tts;
 #ifndef ATT_NR
-#define ATT_NR 3
+#define ATT_NR 2
 #endif
 hipEvent_t tts::prof_event(tts_ctx *) { return nullptr; }
 extern "C" int32_t tts_diffusion_frames(int32_t rows) { return rows * 4 * 24000 / 22050; } // api.cpp is not linked here
@@ -34,13 +37,41 @@ int main() {
   CK(hipMemset(tab, 0, 16 * 128 * 4));
   const int nq = (T + 127) / 128;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; i++) diff_attn_kernel<ATT_NR><<<nq * 16 * ns, 256, att_lds<ATT_NR>(), 0>>>(qk, vt, ldvt, dst, dln, tab, out, nq);
-  CK(hipEventRecord(e0, 0));
-  for (int i = 0; i < 20; i++) diff_attn_kernel<ATT_NR><<<nq * 16 * ns, 256, att_lds<ATT_NR>(), 0>>>(qk, vt, ldvt, dst, dln, tab, out, nq);
-  CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
-  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  // random-ish bias table (the product's is 8 x the T5 bucket table): the near-diagonal path must be exercised with non-zero values
+  { std::vector<float> tb(16 * 128); for (size_t i = 0; i < tb.size(); i++) tb[i] = (float)((i * 40503u >> 3) & 255) / 64.f - 2.f; CK(hipMemcpy(tab, tb.data(), tb.size() * 4, hipMemcpyHostToDevice)); }
+  __half *out2; CK(hipMalloc(&out2, (size_t)(rows + 256) * 1024 * 2));
+  CK(hipMemset(out, 0, (size_t)(rows + 256) * 1024 * 2)); CK(hipMemset(out2, 0, (size_t)(rows + 256) * 1024 * 2));
+  diff_attn_kernel<ATT_NR><<<nq * 16 * ns, 256, att_lds<ATT_NR>(), 0>>>(qk, vt, ldvt, dst, dln, tab, out, nq);
+  diff_attn_r3_kernel<ATT_NR><<<nq * 16 * ns, 256, att_lds<ATT_NR>(), 0>>>(qk, vt, ldvt, dst, dln, tab, out2, nq);
+  CK(hipDeviceSynchronize());
+  {
+    std::vector<__half> a((size_t)(rows + 256) * 1024), b(a.size());
+    CK(hipMemcpy(a.data(), out, a.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), out2, b.size() * 2, hipMemcpyDeviceToHost));
+    size_t bad = 0, nz = 0;
+    for (size_t i = 0; i < a.size(); i++) { bad += memcmp(&a[i], &b[i], 2) != 0; nz += __half2float(a[i]) != 0.f; }
+    printf("product kernel vs round-3 kernel: %zu of %zu outputs differ (%zu non-zero)\n", bad, a.size(), nz);
+  }
+  double us[2][5];
+  for (int r = 0; r < 5; r++)
+    for (int v = 0; v < 2; v++) {
+      auto go = [&]() {
+        if (v == 0) diff_attn_kernel<ATT_NR><<<nq * 16 * ns, 256, att_lds<ATT_NR>(), 0>>>(qk, vt, ldvt, dst, dln, tab, out, nq);
+        else diff_attn_r3_kernel<ATT_NR><<<nq * 16 * ns, 256, att_lds<ATT_NR>(), 0>>>(qk, vt, ldvt, dst, dln, tab, out2, nq);
+      };
+      for (int i = 0; i < 3; i++) go();
+      CK(hipEventRecord(e0, 0));
+      for (int i = 0; i < 20; i++) go();
+      CK(hipEventRecord(e1, 0)); CK(hipDeviceSynchronize());
+      float ms1; CK(hipEventElapsedTime(&ms1, e0, e1));
+      us[v][r] = 1e3 * ms1 / 20;
+    }
   double fl = 4.0 * T * (double)T * 64 * 16 * ns;
-  printf("attention: %.1f us/launch, %.0f TF/s\n", 1e3 * ms / 20, fl / (ms / 20 * 1e-3) / 1e12);
+  for (int v = 0; v < 2; v++) {
+    std::sort(us[v], us[v] + 5);
+    printf("%-28s med %.1f us/launch (min %.1f), %.0f TF/s\n", v == 0 ? "attention (product, round 4):" : "attention (round-3 kernel):", us[v][2], us[v][0], fl / (us[v][2] * 1e-6) / 1e12);
+  }
+  float ms = (float)(us[0][2] * 20 / 1e3);
+  (void)ms;
   {
     long long *d, hres[3];
     CK(hipMalloc(&d, 24));

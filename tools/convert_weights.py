@@ -220,6 +220,150 @@ def convert_clvp(sd, path):
     return depth // 2
 
 
+# ---- what each checkpoint is expected to hold (--list-expected) ---------------------------------------------------------------------
+# name -> PyTorch shape as tortoise-tts stores it, for the upstream architecture (or the one given). Written from the loaders' contracts
+# (main.cpp:682-792, 1244-1536, 1808-1923; csrc/extras.hip for the three containers the reference does not have), NOT from a checkpoint:
+# the trained files are not obtainable offline, so the first person who has them gets a name / shape diff instead of a silent mismatch
+# (check_against below; tests/test_convert_weights.py requires this list and the synthetic writers to agree).
+def expected_tensors(kind, **arch):
+    D = 1024
+    out = {}
+
+    def attn(p, d, rel=True, conv=True):
+        out[p + ".norm.weight"] = (d,); out[p + ".norm.bias"] = (d,)
+        out[p + ".qkv.weight"] = (3 * d, d, 1) if conv else (3 * d, d); out[p + ".qkv.bias"] = (3 * d,)
+        out[p + ".proj_out.weight"] = (d, d, 1) if conv else (d, d); out[p + ".proj_out.bias"] = (d,)
+        if rel:
+            out[p + ".relative_pos_embeddings.relative_attention_bias.weight"] = (32, 16)
+
+    def res(p):
+        out[p + ".in_layers.0.weight"] = (D,); out[p + ".in_layers.0.bias"] = (D,)
+        out[p + ".in_layers.2.weight"] = (D, D, 1); out[p + ".in_layers.2.bias"] = (D,)
+        out[p + ".emb_layers.1.weight"] = (2 * D, D); out[p + ".emb_layers.1.bias"] = (2 * D,)
+        out[p + ".out_layers.0.weight"] = (D,); out[p + ".out_layers.0.bias"] = (D,)
+        out[p + ".out_layers.3.weight"] = (D, D, 3); out[p + ".out_layers.3.bias"] = (D,)
+
+    if kind == "ar":  # autoregressive.pth, inference names (the training-time names gpt.h.N / gpt.ln_f / final_norm / mel_head are mapped onto them)
+        out.update({"text_embedding.weight": (256, D), "text_pos_embedding.emb.weight": (404, D), "mel_embedding.weight": (8194, D),
+                    "mel_pos_embedding.emb.weight": (608, D)})
+        for i in range(arch.get("layers", 30)):
+            p = "inference_model.transformer.h.%d." % i
+            out.update({p + "ln_1.weight": (D,), p + "ln_1.bias": (D,), p + "attn.c_attn.weight": (D, 3 * D), p + "attn.c_attn.bias": (3 * D,),
+                        p + "attn.c_proj.weight": (D, D), p + "attn.c_proj.bias": (D,), p + "ln_2.weight": (D,), p + "ln_2.bias": (D,),
+                        p + "mlp.c_fc.weight": (D, 4 * D), p + "mlp.c_fc.bias": (4 * D,), p + "mlp.c_proj.weight": (4 * D, D), p + "mlp.c_proj.bias": (D,)})
+        out.update({"inference_model.transformer.ln_f.weight": (D,), "inference_model.transformer.ln_f.bias": (D,), "inference_model.lm_head.0.weight": (D,),
+                    "inference_model.lm_head.0.bias": (D,), "inference_model.lm_head.1.weight": (8194, D), "inference_model.lm_head.1.bias": (8194,)})
+    elif kind == "diffusion":  # diffusion_decoder.pth (+ the voice's latent from --diffusion-conditioning-latent)
+        out["latent_conditioner.0.weight"] = (D, D, 3); out["latent_conditioner.0.bias"] = (D,)
+        for i in range(1, 1 + arch.get("lc", 4)):
+            attn("latent_conditioner.%d" % i, D)
+        out.update({"code_norm.weight": (D,), "code_norm.bias": (D,), "time_embed.0.weight": (D, D), "time_embed.0.bias": (D,),
+                    "time_embed.2.weight": (D, D), "time_embed.2.bias": (D,)})
+        for i in range(arch.get("integ", 3)):
+            res("conditioning_timestep_integrator.%d.resblk" % i); attn("conditioning_timestep_integrator.%d.attn" % i, D)
+        out.update({"inp_block.weight": (D, 100, 3), "inp_block.bias": (D,), "integrating_conv.weight": (D, 2 * D, 1), "integrating_conv.bias": (D,)})
+        n_main, n_tail = arch.get("main", 10), arch.get("tail", 3)
+        for i in range(n_main):
+            res("layers.%d.resblk" % i); attn("layers.%d.attn" % i, D)
+        for i in range(n_main, n_main + n_tail):
+            res("layers.%d" % i)
+        out.update({"out.0.weight": (D,), "out.0.bias": (D,), "out.2.weight": (200, D, 3), "out.2.bias": (200,), "unconditioned_embedding": (1, D, 1)})
+    elif kind == "vocoder":  # vocoder.pth ['model_g'], weight_norm pairs fused: shapes of the fused `weight`
+        out["conv_pre.weight"] = (32, 64, 7); out["conv_pre.bias"] = (32,)
+        for i, stride in enumerate((8, 8, 4)):
+            p, kp = "res_stack.%d." % i, "res_stack.%d.kernel_predictor." % i
+            out[kp + "input_conv.0.weight"] = (64, 100, 5); out[kp + "input_conv.0.bias"] = (64,)
+            for c in range(3):
+                for j in (1, 3):
+                    out[kp + "residual_convs.%d.%d.weight" % (c, j)] = (64, 64, 3); out[kp + "residual_convs.%d.%d.bias" % (c, j)] = (64,)
+            out[kp + "kernel_conv.weight"] = (24576, 64, 3); out[kp + "kernel_conv.bias"] = (24576,)
+            out[kp + "bias_conv.weight"] = (256, 64, 3); out[kp + "bias_conv.bias"] = (256,)
+            out[p + "convt_pre.1.weight"] = (32, 32, 2 * stride); out[p + "convt_pre.1.bias"] = (32,)
+            for c in range(4):
+                out[p + "conv_blocks.%d.1.weight" % c] = (32, 32, 3); out[p + "conv_blocks.%d.1.bias" % c] = (32,)
+        out["conv_post.1.weight"] = (1, 32, 7); out["conv_post.1.bias"] = (1,)
+    elif kind == "clvp":  # clvp2.pth (use_xformers=True)
+        dim, heads, ffm = arch.get("dim", 768), arch.get("heads", 12), arch.get("ff_mult", 2)
+        inner, ff = heads * 64, dim * ffm
+        out.update({"text_emb.weight": (256, dim), "speech_emb.weight": (8192, dim), "to_text_latent.weight": (dim, dim), "to_speech_latent.weight": (dim, dim),
+                    "temperature": ()})
+        for enc in ("text_transformer", "speech_transformer"):
+            for i in range(arch.get("depth", 20)):
+                a, f = "%s.transformer.attn_layers.layers.%d." % (enc, 2 * i), "%s.transformer.attn_layers.layers.%d." % (enc, 2 * i + 1)
+                out[a + "0.g"] = (dim,)
+                for nm in ("to_q", "to_k", "to_v"):
+                    out[a + "1.%s.weight" % nm] = (inner, dim)
+                out[a + "1.to_out.weight"] = (dim, inner); out[a + "1.to_out.bias"] = (dim,)
+                out[f + "0.g"] = (dim,)
+                out[f + "1.net.0.proj.weight"] = (2 * ff, dim); out[f + "1.net.0.proj.bias"] = (2 * ff,)
+                out[f + "1.net.3.weight"] = (dim, ff); out[f + "1.net.3.bias"] = (dim,)
+            out[enc + ".transformer.norm.weight"] = (dim,); out[enc + ".transformer.norm.bias"] = (dim,)
+    elif kind == "conditioning-encoder":  # autoregressive.pth: conditioning_encoder.*
+        out["conditioning_encoder.init.weight"] = (D, 80, 1); out["conditioning_encoder.init.bias"] = (D,)
+        for i in range(arch.get("blocks", 6)):
+            attn("conditioning_encoder.attn.%d" % i, D, rel=False)
+    elif kind == "diffusion-conditioning-encoder":  # diffusion_decoder.pth: contextual_embedder.*
+        out["contextual_embedder.0.weight"] = (1024, 100, 3); out["contextual_embedder.0.bias"] = (1024,)
+        out["contextual_embedder.1.weight"] = (2048, 1024, 3); out["contextual_embedder.1.bias"] = (2048,)
+        for i in range(arch.get("blocks", 5)):
+            attn("contextual_embedder.%d" % (2 + i), 2048)
+    else:
+        raise ValueError(kind)
+    return out
+
+
+EXPECTED_KINDS = ("ar", "diffusion", "vocoder", "clvp", "conditioning-encoder", "diffusion-conditioning-encoder")
+
+
+def container_shape(kind, name, shape):
+    """shape of the tensor as the CONTAINER holds it (the reference's loaders: k = 1 convolutions of the diffusion model squeezed to 2-D, conv_post
+    [1, 32, 7] -> [32, 7], unconditioned_embedding flattened, a 0-dim temperature as [1]); everything else as in the checkpoint"""
+    if kind == "diffusion" and SQUEEZE_K1.search(name) and len(shape) == 3:
+        return shape[:2]
+    if kind == "diffusion" and name == "unconditioned_embedding":
+        return (int(np.prod(shape)),)
+    if kind == "vocoder" and name == "conv_post.1.weight":
+        return shape[-2:]
+    if kind == "clvp" and name == "temperature":
+        return (1,)
+    return tuple(shape)
+
+
+def check_against(kind, sd, prefix=""):
+    """name / shape diff of a state dict against expected_tensors(kind) (architecture counts taken from the state dict where they are discoverable);
+    returns a list of human-readable lines, empty when everything expected is there with the expected shape"""
+    have = {k: tuple(getattr(v, "shape", ())) for k, v in sd.items() if k.startswith(prefix)}
+
+    def count(fmt, start=0):
+        n = start
+        while fmt % n in have:
+            n += 1
+        return n - start
+    arch = {}
+    if kind == "ar":
+        arch["layers"] = count("inference_model.transformer.h.%d.ln_1.weight") or count("gpt.h.%d.ln_1.weight") or 30
+    elif kind == "diffusion":
+        arch = {"lc": count("latent_conditioner.%d.norm.weight", 1) or 4, "integ": count("conditioning_timestep_integrator.%d.resblk.in_layers.0.weight") or 3,
+                "main": count("layers.%d.resblk.in_layers.0.weight") or 10}
+        arch["tail"] = (count("layers.%d.in_layers.0.weight", arch["main"])) or 3
+    elif kind == "clvp":
+        n = 0
+        while "text_transformer.transformer.attn_layers.layers.%d.0.g" % (2 * n) in have:
+            n += 1
+        arch["depth"] = n or 20
+    elif kind == "conditioning-encoder":
+        arch["blocks"] = count("conditioning_encoder.attn.%d.norm.weight") or 6
+    elif kind == "diffusion-conditioning-encoder":
+        arch["blocks"] = count("contextual_embedder.%d.norm.weight", 2) or 5
+    lines = []
+    for name, shape in expected_tensors(kind, **arch).items():
+        if name not in have:
+            lines.append("missing  %-80s expected %s" % (name, list(shape)))
+        elif have[name] != tuple(shape) and int(np.prod(have[name] or (1,))) != int(np.prod(shape or (1,))):
+            lines.append("shape    %-80s expected %s, checkpoint has %s" % (name, list(shape), list(have[name])))
+    return lines
+
+
 def main():
     import torch
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
@@ -232,29 +376,61 @@ def main():
     ap.add_argument("--diffusion-conditioning-encoder", help="diffusion_decoder.pth -> ggml-diffusion-conditioning-model.bin (its contextual_embedder.* tensors: "
                                                               "100-band mel -> the diffusion conditioning latent, tts_load_diffusion_conditioning_encoder; not in the reference)")
     ap.add_argument("--clvp", help="clvp2.pth of upstream tortoise-tts -> ggml-clvp-model.bin (candidate re-ranking, tts_load_clvp; not in the reference)")
-    ap.add_argument("--out", required=True)
+    ap.add_argument("--out")
+    ap.add_argument("--list-expected", nargs="*", metavar="KIND", help="print every tensor name / shape the converter looks for per checkpoint kind (%s; "
+                                                                        "default: all, upstream architecture) and exit" % ", ".join(EXPECTED_KINDS))
     a = ap.parse_args()
+    if a.list_expected is not None:
+        for kind in (a.list_expected or EXPECTED_KINDS):
+            exp = expected_tensors(kind)
+            print("# %s: %d tensors" % (kind, len(exp)))
+            for name, shape in exp.items():
+                print("%-28s %-88s %s" % (kind, name, "x".join(map(str, shape)) or "scalar"))
+        return
+    if not a.out:
+        ap.error("--out is required")
     os.makedirs(a.out, exist_ok=True)
     load = lambda p: torch.load(p, map_location="cpu", weights_only=True)
+
+    def checked(kind, sd, what):  # a name / shape diff before the conversion touches anything: no silent mismatch, no bare KeyError
+        if kind == "ar" and not any(k.startswith("inference_model.") for k in sd):
+            sd = dict(sd)
+            for k in list(sd):
+                for pat, rep in AR_TRAIN_TO_INFER:
+                    if re.match(pat, k):
+                        sd[re.sub(pat, rep, k)] = sd[k]
+        if kind == "vocoder":
+            sd = fuse_weight_norm(sd["model_g"] if "model_g" in sd else sd)
+        diff = check_against(kind, sd)
+        if diff:
+            sys.exit("%s does not look like the expected %s checkpoint (python tools/convert_weights.py --list-expected %s prints the full list):\n  "
+                     % (what, kind, kind) + "\n  ".join(diff[:40]) + ("\n  ... %d more" % (len(diff) - 40) if len(diff) > 40 else ""))
+
     if a.ar:
+        checked("ar", load(a.ar), a.ar)
         print("ggml-model.bin: %d transformer layers" % convert_ar(load(a.ar), os.path.join(a.out, "ggml-model.bin")))
     if a.conditioning_encoder:
         if not a.ar:
             sys.exit("--conditioning-encoder needs --ar (the encoder's tensors live in autoregressive.pth)")
+        checked("conditioning-encoder", load(a.ar), a.ar)
         print("ggml-conditioning-model.bin: %d attention blocks" % convert_conditioning_encoder(load(a.ar), os.path.join(a.out, "ggml-conditioning-model.bin")))
     if a.diffusion:
         if not a.diffusion_conditioning_latent:
             sys.exit("--diffusion needs --diffusion-conditioning-latent (the reference bakes the voice's diffusion latent into the weight file)")
+        checked("diffusion", load(a.diffusion), a.diffusion)
         p = a.diffusion_conditioning_latent
         lat = np.load(p) if p.endswith(".npy") else load(p) if p.endswith((".pth", ".pt")) else np.fromfile(p, np.float32)
         print("ggml-diffusion-model.bin: blocks (latent conditioner, integrator, main, tail) = %s"
               % (convert_diffusion(load(a.diffusion), lat, os.path.join(a.out, "ggml-diffusion-model.bin")),))
     if a.diffusion_conditioning_encoder:
+        checked("diffusion-conditioning-encoder", load(a.diffusion_conditioning_encoder), a.diffusion_conditioning_encoder)
         print("ggml-diffusion-conditioning-model.bin: %d attention blocks"
               % convert_diffusion_conditioning_encoder(load(a.diffusion_conditioning_encoder), os.path.join(a.out, "ggml-diffusion-conditioning-model.bin")))
     if a.clvp:
+        checked("clvp", load(a.clvp), a.clvp)
         print("ggml-clvp-model.bin: %d encoder layers" % convert_clvp(load(a.clvp), os.path.join(a.out, "ggml-clvp-model.bin")))
     if a.vocoder:
+        checked("vocoder", load(a.vocoder), a.vocoder)
         print("ggml-vocoder-model.bin: %d res stacks" % convert_vocoder(load(a.vocoder), os.path.join(a.out, "ggml-vocoder-model.bin")))
 
 

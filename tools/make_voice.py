@@ -8,7 +8,11 @@ writes voices/me.bin (1024 f32: `tortoise --voice`) and voices/me.diffusion.bin 
 Clips: mono WAV, PCM16 or float32, any sample rate (resampled to 22.05 kHz for the AR encoder and 24 kHz for the diffusion encoder with
 scipy.signal.resample_poly). The two encoder containers come from upstream tortoise-tts checkpoints through tools/convert_weights.py
 (--ar autoregressive.pth --conditioning-encoder / --diffusion-conditioning-encoder diffusion_decoder.pth); --mel-norms is upstream's
-data/mel_norms.pth saved as 80 floats (.npy or raw f32): without it the 80-band mel is not divided by the per-band norms."""
+data/mel_norms.pth saved as 80 floats (.npy or raw f32): without it the 80-band mel is not divided by the per-band norms.
+Clip length follows upstream's get_conditioning_latents: the AR encoder sees exactly 132 300 samples at 22.05 kHz (format_conditioning: zero-padded,
+or cropped — upstream crops at a random offset; here at --crop-offset, default 0), the diffusion encoder exactly 102 400 samples at 24 kHz
+(pad_or_truncate: zero-padded or the first 102 400) and the UN-normalised log-mel (wav_to_univnet_mel(..., do_normalization=False));
+--full-clips feeds whole clips instead."""
 import argparse
 import os
 import struct
@@ -55,6 +59,14 @@ def resample(x, rate, target):
     return resample_poly(x, fr.numerator, fr.denominator).astype(np.float32)
 
 
+def pad_or_crop(x, length, offset=0):
+    """upstream pad_or_truncate / format_conditioning: zero-pad at the end, or keep `length` samples from `offset`"""
+    if len(x) < length:
+        return np.concatenate([x, np.zeros(length - len(x), np.float32)])
+    offset = max(0, min(offset, len(x) - length))
+    return x[offset:offset + length]
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--clips", nargs="+", required=True)
@@ -63,6 +75,8 @@ def main():
     ap.add_argument("--mel-norms")
     ap.add_argument("--out", required=True)
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--crop-offset", type=int, default=0, help="first sample (22.05 kHz) of the AR encoder's 132 300-sample window in clips longer than that")
+    ap.add_argument("--full-clips", action="store_true", help="do not pad / crop the clips to upstream's 132 300 / 102 400 samples")
     a = ap.parse_args()
     import tortoise_cpp_amd_loader
     pkg = tortoise_cpp_amd_loader.load()
@@ -71,8 +85,9 @@ def main():
         norms = np.load(a.mel_norms) if a.mel_norms.endswith(".npy") else np.fromfile(a.mel_norms, np.float32)
         norms = np.asarray(norms, np.float32).reshape(80)
     clips = [read_wav(p) for p in a.clips]
-    mel80 = [pkg.host_mel_voice80(resample(x, r, 22050), norms) for x, r in clips]
-    mel100 = [pkg.host_mel_diffusion100(resample(x, r, 24000)) for x, r in clips]
+    fit = (lambda x, n, off=0: x) if a.full_clips else pad_or_crop
+    mel80 = [pkg.host_mel_voice80(fit(resample(x, r, 22050), 132300, a.crop_offset), norms) for x, r in clips]
+    mel100 = [pkg.host_mel_diffusion100(fit(resample(x, r, 24000), 102400), normalize=False) for x, r in clips]
     e = pkg.Engine(a.device)
     e.load_voice_encoder(a.conditioning_model)
     e.load_diffusion_conditioning_encoder(a.diffusion_conditioning_model)

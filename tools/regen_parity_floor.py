@@ -8,6 +8,7 @@ distance over the class's samples), nothing multiplied in.
   python tools/regen_parity_floor.py small mid          # seconds to minutes per sample
   python tools/regen_parity_floor.py full               # full depth: ~10 min per sample on 8 cores
   python tools/regen_parity_floor.py --extra small:L=16,seed=21 ...   # add samples
+  python tools/regen_parity_floor.py --problems small mid full   # torch-f32 vs oracle on the exact inputs of the GPU loop tests
 """
 import json
 import os
@@ -68,6 +69,46 @@ def loops(path, L, seed, steps=80, which=("t32", "orc")):
     return T, res
 
 
+def test_problems(kind):
+    """the EXACT inputs of the GPU loop tests (tests/test_diffusion_gpu.py, tests/test_fullsize_gpu.py), by test name: (L, latents, noise, steps)"""
+    def lat(L, seed):
+        return np.random.RandomState(seed).randn(L, 1024).astype(np.float32)
+    T = O.Diffusion.T_of
+    out = {}
+    if kind in ("small", "mid"):
+        out["test_sampling_loop_80_steps[%s]" % kind] = (lat(12, 12), np.random.RandomState(5).randn(81, 100 * T(12)).astype(np.float32), 80)
+    if kind == "small":
+        rs = np.random.RandomState(3)
+        for c, (L, seed) in enumerate(((20, 1), (9, 2))):
+            out["test_sampling_loop_matches_oracle[cand %d]" % c] = (lat(L, seed), rs.randn(81, 100 * T(L)).astype(np.float32), 80)
+        out["test_sampling_loop_200_steps_config5"] = (lat(9, 3), np.random.RandomState(8).randn(201, 100 * T(9)).astype(np.float32), 200)
+    if kind == "full":
+        rs = np.random.RandomState(41)
+        for _ in range(2 * 16):
+            rs.randn(200, 1024)
+        out["test_config5_shape_200_steps"] = (rs.randn(9, 1024).astype(np.float32), np.random.RandomState(8).randn(201, 100 * T(9)).astype(np.float32), 200)
+        out["test_full_size_80_steps_at_bench_length"] = (lat(200, 31), np.random.RandomState(6).randn(81, 100 * T(200)).astype(np.float32), 80)
+    return out
+
+
+def run_problem(path, latents, noise, steps):
+    od = O.Diffusion(O.Model(path))
+    L = latents.shape[0]
+    T = od.T_of(L)
+    tm = O.default_timestep_map(steps)
+    ce = od.code_embedding(latents, T)
+    net = TR.TorchDiffusion(path, O.buckets)
+    x = noise[0].copy()
+    for idx in range(steps):
+        t = steps - 1 - idx
+        te = O.timestep_embedding(int(tm[t]))
+        xc = x.reshape(100, T)
+        x = O.diffusion_update(tm, t, net.forward(ce, xc, te), net.forward(None, xc, te), x, noise[idx + 1], T)
+    want = od.sample(latents, steps, noise=noise.reshape(-1))
+    d = np.abs(x.reshape(100, T) - want)
+    return {"T": int(T), "L": int(L), "steps": int(steps), "oracle_vs_t32": float(d.max()), "oracle_vs_t32_mean": float(d.mean())}
+
+
 def main():
     torch.set_num_threads(int(os.environ.get("TTS_FLOOR_THREADS", "4")))
     O.build()
@@ -80,9 +121,19 @@ def main():
             kind, kv = spec.split(":")
             extra.setdefault(kind, []).append({k: int(v) for k, v in (p.split("=") for p in kv.split(","))})
         args = args[:i]
+    problems = "--problems" in args
+    args = [a for a in args if a != "--problems"]
     kinds = args or ["small", "mid"]
     for kind in kinds:
         path = ensure_models(kind)
+        if problems:  # torch-f32 vs the oracle on the very problems the GPU tests run: recorded next to the samples, part of the class maximum
+            rec = json.load(open(FLOOR_JSON))
+            pr = rec[kind].setdefault("problems", {})
+            for name, (latents, noise, steps) in test_problems(kind).items():
+                if name not in pr:
+                    pr[name] = run_problem(path, latents, noise, steps)
+                    print(kind, name, pr[name], flush=True)
+                    json.dump(rec, open(FLOOR_JSON, "w"), indent=1)
         samples = rec[kind]["samples"]
         for e in extra.get(kind, []):
             if not any(s.get("L") == e["L"] and s.get("seed", 5) == e.get("seed", 5) for s in samples):
@@ -103,6 +154,7 @@ def main():
         f = rec[kind]
         for fld in ("floor_f32", "oracle", "engine_math", "pair", "oracle_vs_t32"):
             f[fld] = max(x[fld] for x in samples)
+        f["oracle_vs_t32"] = max([f["oracle_vs_t32"]] + [p["oracle_vs_t32"] for p in f.get("problems", {}).values()])
         f["gate"] = round(max(1e-3, 2.0 * f["pair"]), 5)
         f["gate_f32"] = round(max(1e-3, f["oracle_vs_t32"]), 5)  # north star's 1e-3, or the measured f32-vs-f32 floor where that is higher
         json.dump(rec, open(FLOOR_JSON, "w"), indent=1)

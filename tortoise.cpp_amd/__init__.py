@@ -71,7 +71,7 @@ def lib():
         "tts_host_schedule": (ci, [ci, _i32p] + [_f32p] * 7), "tts_host_timestep_embedding": (None, [ci, _f32p]),
         "tts_host_rel_bucket": (ci, [ci, ci]), "tts_host_pad_codes": (ci, [_i32p, ci, _i32p]), "tts_host_trimmed_rows": (ci, [_i32p]),
         "tts_host_fp8_e4m3": (C.c_uint8, [cf]), "tts_host_mel_frames": (ci, [C.c_int64]),
-        "tts_host_mel_diffusion100": (ci, [_f32p, C.c_int64, _f32p]), "tts_host_mel_voice80": (ci, [_f32p, C.c_int64, vp, _f32p]),
+        "tts_host_mel_diffusion100": (ci, [_f32p, C.c_int64, ci, _f32p]), "tts_host_mel_voice80": (ci, [_f32p, C.c_int64, vp, _f32p]),
         "tts_prof_reset": (ci, [vp, ci]), "tts_prof_get": (ci, [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
@@ -357,12 +357,13 @@ def host_trimmed_rows(codes502):
     return lib().tts_host_trimmed_rows(np.ascontiguousarray(codes502, np.int32))
 
 
-def host_mel_diffusion100(audio24k):
-    """[100, frames] normalised log-mel of 24 kHz audio: the input of Engine.diffusion_conditioning_latent."""
+def host_mel_diffusion100(audio24k, normalize=False):
+    """[100, frames] log-mel of 24 kHz audio. normalize=False: log(clamp(mel, 1e-5)), the input of Engine.diffusion_conditioning_latent
+    (upstream feeds its contextual_embedder the un-normalised mel); normalize=True: mapped to [-1, 1] like the diffusion stage's output."""
     a = np.ascontiguousarray(audio24k, np.float32)
     frames = lib().tts_host_mel_frames(len(a))
     out = np.empty((100, frames), np.float32)
-    rc = lib().tts_host_mel_diffusion100(a, len(a), out.reshape(-1))
+    rc = lib().tts_host_mel_diffusion100(a, len(a), 1 if normalize else 0, out.reshape(-1))
     if rc < 0:
         raise TtsError("tts_host_mel_diffusion100 failed (%d): the clip must be longer than 512 samples" % rc)
     return out

@@ -367,13 +367,14 @@ int tts_diffusion_forward(tts_ctx *c, const float *latents, int L, const float *
 int tts_diffusion(tts_ctx *c, const float *latents, const int32_t *rows, int B, int n_steps, const float *noise,
                   int noise_mode, float *mel_out) {
   NEED_CTX(c);
-  if (B >= 1) if (int rc = shard_check(c, B)) return rc; // the device noise streams are keyed by the global candidate id
+  // the DEVICE noise streams are keyed by the global candidate id; host / reference noise does not look at the shard options
+  if (B >= 1 && !noise && noise_mode == TTS_NOISE_DEVICE) if (int rc = shard_check(c, B)) return rc;
   return guarded(c, [&] { return diff_sample(c, latents, rows, B, n_steps, noise, noise_mode, mel_out); });
 }
 int tts_vocoder_samples(int T) { return (T + 10) * 256 - 6; }
 int tts_vocoder(tts_ctx *c, const float *mel, const int32_t *frames, int B, const float *noise, int noise_mode, float *audio) {
   NEED_CTX(c);
-  if (B >= 1) if (int rc = shard_check(c, B)) return rc;
+  if (B >= 1 && !noise && noise_mode == TTS_NOISE_DEVICE) if (int rc = shard_check(c, B)) return rc;
   return guarded(c, [&] { return voc_run(c, mel, frames, B, noise, noise_mode, audio); });
 }
 
@@ -432,11 +433,15 @@ int tts_prof_reset(tts_ctx *c, int enable) {
 int tts_prof_get(tts_ctx *c, const char *family, double *ms, int64_t *launches, double *work) {
   if (!c || !family) return TTS_ERR_ARG;
   if (c->device >= 0) prof_resolve(c);
-  auto it = c->prof.find(family);
-  if (it == c->prof.end()) { if (ms) *ms = 0; if (launches) *launches = 0; if (work) *work = 0; return TTS_OK; }
-  if (ms) *ms = it->second.ms;
-  if (launches) *launches = it->second.launches;
-  if (work) *work = it->second.work;
+  // a family name also names its sub-families ("diff_gemm" = diff_gemm_qkv + diff_gemm_k3 + ...: the GEMM launches are recorded per shape class)
+  double tms = 0, tw = 0;
+  int64_t tl = 0;
+  const std::string f(family), pre = f + "_";
+  for (auto &kv : c->prof)
+    if (kv.first == f || kv.first.rfind(pre, 0) == 0) { tms += kv.second.ms; tl += kv.second.launches; tw += kv.second.work; }
+  if (ms) *ms = tms;
+  if (launches) *launches = tl;
+  if (work) *work = tw;
   return TTS_OK;
 }
 

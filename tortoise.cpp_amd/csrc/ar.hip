@@ -410,7 +410,7 @@ __device__ __forceinline__ void dec_layernorm(float4 (&x)[16], const float *__re
 // 3 = OCP fp8 (e4m3) WEIGHTS with a power-of-two scale per output column (a quarter of the bytes): converted to fp16 in
 // registers (exact: every e4m3 value is an fp16 value), multiplied on the fp16 MFMA against the hi + lo split activations.
 template <int EPI, int SPLIT = 0, bool NTW = false>
-__global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
+__global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a_in) {
   constexpr int SP = SPLIT ? 1 : 0;
   constexpr int TSLOT = EPI == DEC_QKV ? 0 : EPI == DEC_GELU ? 3 : 5; (void)TSLOT;
   __shared__ float sred[4][4][16];
@@ -418,13 +418,30 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, q = lane >> 4;
   const int cb = blockIdx.x, row = blockIdx.y * 16 + m;
   DEC_T(0);
+  // EVERY kernel argument is fetched in ONE batch of scalar loads at the top (the empty asm pins the values in SGPRs here). Left to itself
+  // hipcc fetches an argument right before its first use: the 104-byte argument block spans two cache lines and nothing of a fresh launch is
+  // cached, so the QKV variant ran THREE dependent scalar round trips (arguments, the pointer to the step state, n_past) before its first
+  // vector load was issued, and every variant fetched `out` / `lut` (the second line) after the reduction — a cold miss at the very end of
+  // each of the step's 61 launches of this kernel (seen in the ISA and in the per-launch trace, profiles/r4_decode_launch_breakdown.txt).
+  const DecLnArgs &a = a_in;
+  // (input-only operands: the values must be in SGPRs HERE, and the pointers keep their global address space — behind a "+s" they would
+  //  become generic pointers and every load a flat_load, which also counts on lgkmcnt)
+  asm volatile("" ::"s"(a.h), "s"(a.g1), "s"(a.b1), "s"(a.W), "s"(a.Wh), "s"(a.bias), "s"(a.out), "s"(a.kc), "s"(a.vc), "s"(a.ss), "s"(a.wscale));
+  asm volatile("" ::"s"(a.rows), "s"(a.n_valid), "s"(a.ldo), "s"(a.prefill_B), "s"(a.max_pos), "s"(a.lut));
   // Everything the epilogue reads (bias, the step's n_past) is requested FIRST: loaded after the reduction they were one or two
-  // dependent L2 round trips (~0.5 us each) at the end of every one of the step's 91 launches of this kernel.
+  // dependent L2 round trips (~0.5 us each) at the end of every launch. n_past goes through the VECTOR memory path (a zero offset the
+  // compiler cannot see through): as a scalar load it is a dependent round trip that every later s_waitcnt lgkmcnt(0) waits for; as the
+  // first entry of the in-order vmcnt queue it retires before the activations and nothing waits for it until the epilogue.
   const float4 bi = *(const float4 *)(a.bias + cb * 16 + 4 * q);
   float4 wsc = make_float4(1.f, 1.f, 1.f, 1.f);
   if (SPLIT == 3) wsc = *(const float4 *)(a.wscale + cb * 16 + 4 * q);
   int n_past = 0;
-  if (EPI == DEC_QKV) n_past = a.prefill_B == 0 ? a.ss->n_past : 0;
+  if (EPI == DEC_QKV) {
+    unsigned zero = 0;
+    asm volatile("" : "+v"(zero));
+    n_past = *(const int *)((const char *)&a.ss->n_past + zero);
+    n_past = a.prefill_B == 0 ? n_past : 0;
+  }
   // activations next (L2 hits), then the weight slab (HBM): vmcnt retires in order, so the LayerNorm runs on
   // the activations while the 16 x 1 KB-per-wave weight loads are still streaming in
   const int koff = wave * 256 + (SPLIT ? 8 : 4) * q;
@@ -451,6 +468,10 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a) {
       for (int i = 0; i < 16; i++) w[i] = ldw4<NTW>(SPLIT ? wp + ((i >> 1) * 64 + lane) * 2 + (i & 1) : wp + i * 64 + lane);
     }
   }
+  // Every request above stays in front of the first use: without this hipcc sinks the 16 weight loads below the LayerNorm's first
+  // reduction (they would be issued only after `s_waitcnt vmcnt(0)` on the activations: the HBM round trip of the slab serialised
+  // behind the L2 round trip of x instead of overlapping it; seen in the ISA, round 4).
+  __builtin_amdgcn_sched_barrier(0);
   DEC_T(1);
   // the (last) LayerNorm's gamma/beta are folded into W/bias; the head's ln_f keeps its own
   if (EPI == DEC_LOGITS) dec_layernorm<SP, SPLIT ? 32 : 16>(x, a.g1, a.b1, koff, sred, wave, m);
@@ -760,7 +781,11 @@ __global__ __launch_bounds__(256) void attn_decode_fast_kernel(const float *__re
   const int c = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l8 = tid & 7, kg = tid >> 3;
   DEC_T(0);
+  // all arguments in one batch of scalar loads (see dec_ln_gemv_kernel) and the one dependent fetch this kernel cannot avoid: n_past.
+  // (the load of n_past stays IN FRONT of the asm: behind a volatile asm hipcc no longer proves the memory unclobbered and fetches it through
+  //  the vector path, which makes the loop bounds divergent)
   const int nk = ss->n_past + 1;
+  asm volatile("" ::"s"(qbuf), "s"(kc), "s"(vc), "s"(max_pos), "s"(out)); // input-only: the pointers keep their address space
   const __half *kb = kc + (size_t)c * max_pos * D + h * HD;
   const __half *vb = vc + (size_t)c * max_pos * D + h * HD;
   const float4 qa = *(const float4 *)(qbuf + (size_t)c * D + h * HD + l8 * 8), qb = *(const float4 *)(qbuf + (size_t)c * D + h * HD + l8 * 8 + 4);

@@ -136,7 +136,7 @@ struct ProfScope {
   ProfScope(tts_ctx *ctx, const char *family, double work = 0) : c(ctx), fam(family) {
     bool want = c->prof_on && !c->capturing && c->prof_filter.empty();
     if (c->prof_on && !c->capturing && !want)
-      for (const std::string &f : c->prof_filter) want |= (f == fam);
+      for (const std::string &f : c->prof_filter) want |= (f == fam) || (strncmp(fam, f.c_str(), f.size()) == 0 && fam[f.size()] == '_'); // a name also selects its sub-families
     if (want) {
       ProfEntry &e = c->prof[fam];
       if (e.seen++ % c->prof_stride == 0) { // work and time are accumulated over the bracketed launches only

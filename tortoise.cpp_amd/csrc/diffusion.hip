@@ -32,11 +32,16 @@ static constexpr int C = 1024, NHEAD = 16, XTC = 128 /* x_t channels padded 100 
 // rounded to an fp16 GEMM operand right after): libm's expf plus an IEEE division cost ~30 VALU instructions per
 // element and made the GroupNorm kernel VALU-bound instead of HBM-bound (seen in its ISA: 2100 instructions per
 // thread). lut = 1 (option "ggml_lut") keeps the exact fp16-table emulation.
+// lut = 2 (option "attn_f32", the reference-precision mode): x / (1 + expf(-x)) with libm's expf and an IEEE division, the reference's own
+// f32 formula. The fast form is 2-3 ulp off; its result is rounded to an fp16 GEMM operand right away, and an operand that lands on the other
+// side of a rounding boundary is a 5e-4 relative perturbation — the dominant seed of the 80-step loop's chaotic divergence (round 4: the
+// parity mode's distance from the oracle only came down to the torch-f32-vs-oracle level with this switch as well).
 __device__ __forceinline__ float silu_dev(float x, int lut) {
-  if (lut) {
+  if (lut == 1) {
     float xr = __half2float(__float2half_rn(x));
     return __half2float(__float2half_rn(xr / (1.0f + expf(-xr))));
   }
+  if (lut == 2) return x / (1.0f + expf(-x));
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896f));
 }
 
@@ -230,6 +235,14 @@ __device__ __forceinline__ float rows4_sum(float x) {
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
+// The key tiles of a wave fall into four classes that depend only on (tile, wave): far below the diagonal (every key at least 63 before
+// every query of the wave: the bias is ONE constant), near the diagonal (bias by distance from the LDS table), far above it (the other
+// constant), and the last tile of a sequence whose length is not a multiple of 64 (masked). Round 4: the tile loop is split into those four
+// ranges with one straight-line body each (`tile<MODE>`), instead of one body with three data paths and a per-tile branch: the branch joins
+// cost 44 register copies per tile (v_mov of the 32 score registers: the MFMA results are register tuples, the near path rewrote them, the
+// far path did not) and the PMC pass says the kernel is bound by VALU issue, not by the matrix pipe (profiles/r4_pmc_attention.json:
+// VALU pipe 66 % busy, matrix pipe 35 %, 6.6 VALU instructions per MFMA). Same arithmetic in the same order: bit-identical output.
+enum { ATT_FAR = 0, ATT_NEAR = 1, ATT_TAIL = 2 };
 template <int NR> // K/V ring depth: 3 = two tiles in flight, 3 workgroups per CU; 2 = one tile in flight, 4 workgroups per CU
 __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const __half *__restrict__ qk, const __half *__restrict__ vt, int ldvt,
                                                         const int *__restrict__ seq_start, const int *__restrict__ seq_len,
@@ -237,7 +250,7 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
   // ONE LDS object: with a second __shared__ variable hipcc puts an s_waitcnt vmcnt(0) in front of the first
   // ds_read of every tile, which drains the DMA prefetch (seen in the ISA; cdna_hip_programming.md §5 trap (a)).
   // (dynamic LDS: with a static array the DMA writes and the fragment reads alias for the waitcnt pass as well)
-  extern __shared__ __attribute__((aligned(16))) char smem[]; // 3 x (K tile 8 KB | V^T tile 8 KB) + bias table
+  extern __shared__ __attribute__((aligned(16))) char smem[]; // NR x (K tile 8 KB | V^T tile 8 KB) + bias table
   float *tab = (float *)(smem + NR * 16384);
   // XCD-aware block order: workgroup id b runs on XCD b % 8, so all q-blocks of one (sequence, head) pair
   // get ids congruent mod 8 and reuse that pair's K/V tiles from one L2 (16 heads => pairs % 8 == 0).
@@ -280,7 +293,7 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
   const int prow = lane >> 3, pslot = lane & 7;
   const __half *kbase = qk + (size_t)r0 * 2048 + h * 128 + 64;
   const __half *vbase = vt + (size_t)(h * 64) * ldvt + r0;
-  // K and V^T tiles live in a 3-deep ring of (K 8 KB | V^T 8 KB) slots filled by LDS-DMA two tiles ahead.
+  // K and V^T tiles live in an NR-deep ring of (K 8 KB | V^T 8 KB) slots filled by LDS-DMA NR - 1 tiles ahead.
   // Wave w moves rows w*16 .. w*16+15 of both tiles; swizzle on the source chunk.
   // The K tile is stored with its key rows permuted: LDS row jt*16 + x holds key SIG(jt, x) =
   // (jt>>1)*32 + (x>>2)*8 + (jt&1)*4 + (x&3). The score accumulator (jt, fq, r) then belongs to key
@@ -326,7 +339,10 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
   half8 ones;
 #pragma unroll
   for (int e = 0; e < 8; e++) ones[e] = (_Float16)1.0f;
-  for (int kb = 0; kb < nkb; kb++) {
+  // one key tile; MODE is compile-time, cidx = table index of the constant bias of a far tile (read AFTER the tile's barrier: the table is
+  // filled by the whole workgroup in front of the loop)
+  auto tile = [&](int kb, auto mode_c, int cidx) {
+    constexpr int MODE = decltype(mode_c)::value;
     // Tile kb must have landed; the 4 DMA pieces of tile kb+1 may stay in flight across the barrier
     // (counted vmcnt + raw s_barrier: __syncthreads() would drain the prefetch).
     ATT_T(0);
@@ -343,21 +359,20 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
     scores(Ks, sc);
     ATT_T(4);
     const int kmin = kb * 64;
-    const bool far_hi = kmin - (qw + 31) >= 63, far_lo = qw - (kmin + 63) >= 63, tail = kmin + 64 > T;
     half8 pf[2][2]; // P^T in B-operand layout: slot e of step ks2 = key 32 ks2 + 8 fq + e
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int qi = qw + i * 16 + fr;
       float mx = -INFINITY, boff = 0.f; // v = sc*SC + bias; far tiles: bias is one constant (folded below)
-      if ((far_hi || far_lo) && !tail) {
-        boff = (far_hi ? tab[ATT_TAB / 2 + 63] : tab[ATT_TAB / 2 - 63]) * SC;
+      if (MODE == ATT_FAR) {
+        boff = tab[cidx] * SC;
 #pragma unroll
         for (int jt = 0; jt < 4; jt++) { // two v_max3 per accumulator register quad
           mx = fmaxf(fmaxf(mx, sc[i][jt][0]), sc[i][jt][1]);
           mx = fmaxf(fmaxf(mx, sc[i][jt][2]), sc[i][jt][3]);
         }
         mx = fmaf(mx, SC, boff);
-      } else if (!tail) {
+      } else if (MODE == ATT_NEAR) {
         // key of (jt, r) = kmin + fq*8 + off, off = (jt>>1)*32 + (jt&1)*4 + r  =>  d = (kmin + fq*8 - qi) + off
         const float *tp = tab + (kmin + fq * 8 - qi + ATT_TAB / 2); // in range: |d| < 160 on near-diagonal tiles
 #pragma unroll
@@ -371,7 +386,7 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
         mx *= SC;
       } else { // last tile of the sequence: keys >= T are masked
         const int left = T - kmin - fq * 8; // keys of this lane with off < left exist
-        const bool far = far_hi || far_lo;  // then the bias is one constant (and the table base would be out of range)
+        const bool far_hi = kmin - (qw + 31) >= 63, far = far_hi || qw - (kmin + 63) >= 63; // then the bias is one constant (and the table base would be out of range)
         const float cb = far_hi ? tab[ATT_TAB / 2 + 63] : tab[ATT_TAB / 2 - 63];
         const float *tp = tab + (far ? 0 : kmin + fq * 8 - qi + ATT_TAB / 2);
         float bv[4][4]; // all table reads first, unconditionally (a load under a per-element select is branched around)
@@ -423,6 +438,16 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
       for (int i = 0; i < 2; i++) lacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[i][ks2], lacc[i], 0, 0, 0);
     }
     ATT_T(6);
+  };
+  {
+    // tiles [0, a): every key at least 63 before every query of the wave (qw - (kmin + 63) >= 63); [b, ..): at least 63 after (kmin - (qw + 31) >= 63)
+    const int last = (T & 63) ? nkb - 1 : nkb; // the masked tile, if any, is handled on its own
+    const int a = min(max((qw - 126) >= 0 ? (qw - 126) / 64 + 1 : 0, 0), last), b = min((qw + 94 + 63) / 64, last);
+    int kb = 0;
+    for (; kb < a; kb++) tile(kb, std::integral_constant<int, ATT_FAR>{}, ATT_TAB / 2 - 63);
+    for (; kb < b; kb++) tile(kb, std::integral_constant<int, ATT_NEAR>{}, 0);
+    for (; kb < last; kb++) tile(kb, std::integral_constant<int, ATT_FAR>{}, ATT_TAB / 2 + 63);
+    if (last < nkb) tile(last, std::integral_constant<int, ATT_TAIL>{}, 0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // trailing (clamped) DMA pieces must land before the LDS is released
   ATT_CLK(1);
@@ -1109,7 +1134,7 @@ __global__ __launch_bounds__(NT) void gn_reg_kernel(const float *__restrict__ x,
   const float ge[4] = {gg.x, gg.y, gg.z, gg.w}, be[4] = {bb.x, bb.y, bb.z, bb.w};
   // the activation mode is workgroup-uniform: one copy of the unrolled store loop per mode, no per-element branch
   auto apply = [&](auto mode) {
-    constexpr int MODE = decltype(mode)::value; // 0 none, 1 SiLU, 2 SiLU through the fp16 table emulation
+    constexpr int MODE = decltype(mode)::value; // 0 none, 1 SiLU (hardware exp2 / rcp), 2 SiLU through the fp16 table emulation, 3 SiLU exact (libm expf, IEEE division)
     // Straight-line stores: a row past the sequence end was loaded from (and is written back to) row T - 1 — the same value from
     // every thread that holds it. Under `if (t < T)` hipcc's wait-count pass loses track at every exec-mask join and puts a
     // vmcnt(0) in front of each block, i.e. each of the NJ stores waited for the previous one's acknowledgement.
@@ -1124,7 +1149,7 @@ __global__ __launch_bounds__(NT) void gn_reg_kernel(const float *__restrict__ x,
         u = u + be[i];
         u = u * sc4[i]; // (1, 0 without scale/shift: exact no-ops)
         u = u + sh4[i];
-        if (MODE) u = silu_dev(u, MODE == 2);
+        if (MODE) u = silu_dev(u, MODE - 1);
         e[i] = u;
       }
       const __half2 p0 = __floats2half2_rn(e[0], e[1]), p1 = __floats2half2_rn(e[2], e[3]);
@@ -1135,8 +1160,9 @@ __global__ __launch_bounds__(NT) void gn_reg_kernel(const float *__restrict__ x,
     }
   };
   if (!do_silu) apply(std::integral_constant<int, 0>{});
-  else if (!lut) apply(std::integral_constant<int, 1>{});
-  else apply(std::integral_constant<int, 2>{});
+  else if (lut == 0) apply(std::integral_constant<int, 1>{});
+  else if (lut == 1) apply(std::integral_constant<int, 2>{});
+  else apply(std::integral_constant<int, 3>{});
   // zero the guard/padding rows that follow this sequence (and those before the first one)
   const int gend = (s + 1 < ns) ? seq_start[s + 1] : rows_total;
   for (int r = r0 + T + t0; r < gend; r += SWEEP) *(uint2 *)(y + (size_t)r * C + c) = make_uint2(0u, 0u);
@@ -1154,12 +1180,13 @@ static int gn_fused(tts_ctx *ctx, const Layout &lay, const float *x, const float
   // measured (round 3): one utterance 165.2 -> 156.6 ms per diffusion stage with the touch; the 16-candidate batch 864.8 -> 874.0 ms
   // (its GEMMs re-use every weight line from thousands of tiles: the touch only adds requests) -> small problems only
   if (lay.rows > 4096) { wa_bytes = 0; wb_bytes = 0; }
-#define GN_ARGS x, lay.d_start.as<int>(), lay.d_len.as<int>(), lay.rows, lay.ns, ctx->gn_eps, g, b, ss, do_silu, ctx->ggml_lut, y, \
+  const int silu_mode = ctx->ggml_lut ? 1 : ctx->attn_f32 ? 2 : 0; // see silu_dev
+#define GN_ARGS x, lay.d_start.as<int>(), lay.d_len.as<int>(), lay.rows, lay.ns, ctx->gn_eps, g, b, ss, do_silu, silu_mode, y, \
                 (const char *)wa, (int)(wa_bytes >> 7), (const char *)wb, (int)(wb_bytes >> 7)
   if (tmax <= 14 * 64) gn_reg_kernel<512, 14><<<dim3(32, lay.ns), 512, 0, ctx->stream>>>(GN_ARGS);
   else if (tmax <= 18 * 128) gn_reg_kernel<1024, 18><<<dim3(32, lay.ns), 1024, 0, ctx->stream>>>(GN_ARGS);
   else gn_fused_kernel<0><<<dim3(32, lay.ns), 256, 0, ctx->stream>>>(x, lay.d_start.as<int>(), lay.d_len.as<int>(), lay.rows, lay.ns, ctx->gn_eps, g, b, ss,
-                                                                    do_silu, ctx->ggml_lut, y); // two sweeps over global memory
+                                                                    do_silu, silu_mode, y); // two sweeps over global memory
 #undef GN_ARGS
   TTS_HIP(ctx, hipGetLastError());
   return TTS_OK;

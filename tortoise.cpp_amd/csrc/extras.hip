@@ -94,12 +94,14 @@ __global__ __launch_bounds__(256) void clvp_attn_kernel(const __half *__restrict
       if (key < n) {
         const __half *kp = qkv + (size_t)(r0 + key) * ld + inner + h * DH + part * 32;
         const __half *vp = qkv + (size_t)(r0 + key) * ld + 2 * inner + h * DH + part * 32;
-        float t[32];
+        float t[32], u[32];
 #pragma unroll
-        for (int d = 0; d < 32; d++) t[d] = __half2float(kp[d]);
-        if (ROT && part == 0) rot(t, key);
+        for (int d = 0; d < 32; d++) { t[d] = __half2float(kp[d]); u[d] = __half2float(vp[d]); }
+        // the x-transformers copy vendored in upstream tortoise-tts rotates the first 32 dims of q, k AND v (Attention.forward:
+        // `ql, kl, vl = map(lambda t: apply_rotary_pos_emb(t, rotary_pos_emb), (ql, kl, vl))`), v at its own (key) position
+        if (ROT && part == 0) { rot(t, key); rot(u, key); }
 #pragma unroll
-        for (int d = 0; d < 32; d++) { sk[kj][part * 32 + d] = __float2half_rn(t[d]); sv[kj][part * 32 + d] = vp[d]; }
+        for (int d = 0; d < 32; d++) { sk[kj][part * 32 + d] = __float2half_rn(t[d]); sv[kj][part * 32 + d] = __float2half_rn(u[d]); }
       }
     }
     __syncthreads();

@@ -510,7 +510,7 @@ extern "C" int tts_host_trimmed_rows(const int32_t *codes502) { return tts::trim
 // STFT with a periodic Hann window, centre = true (reflect padding of n_fft / 2), frames = n / hop + 1; triangular mel filterbank with
 // Slaney area normalisation on the Slaney ("librosa") or HTK mel scale.
 //   TacotronSTFT(1024, 256, 1024, 100, 24000, 0, 12000) -> magnitude, librosa filterbank, log(clamp 1e-5), normalised to [-1, 1] with the
-//     constants the vocoder driver de-normalises with (main.cpp:6044-6060)                                   = tts_host_mel_diffusion100
+//     constants the vocoder driver de-normalises with (main.cpp:6044-6060)                                   = tts_host_mel_diffusion100 (normalize = 1; upstream feeds the conditioning encoder the UN-normalised log-mel: normalize = 0)
 //   torchaudio MelSpectrogram(n_fft 1024, hop 256, power 2, sample_rate 22050, f_max 8000, n_mels 80, norm "slaney", mel_scale "htk"),
 //     log(clamp 1e-5), divided by the per-band mel_norms of the upstream data directory (optional here)       = tts_host_mel_voice80
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -588,12 +588,18 @@ static int mel_spectrogram(const float *audio, int64_t n, int n_fft, int hop, in
 }
 } // namespace tts
 extern "C" int tts_host_mel_frames(int64_t n_samples) { return n_samples < 0 ? TTS_ERR_ARG : (int)(n_samples / 256) + 1; }
-extern "C" int tts_host_mel_diffusion100(const float *audio24k, int64_t n, float *mel_out) {
+// normalize = 0: log(clamp(mel, 1e-5)) as upstream's get_conditioning_latents feeds the contextual_embedder (wav_to_univnet_mel(...,
+// do_normalization=False)): the input of tts_diffusion_conditioning_latent. normalize = 1: mapped to [-1, 1] with the constants the vocoder
+// driver de-normalises with (normalize_tacotron_mel; the inverse is main.cpp:6044-6060): the scale of the diffusion stage's OUTPUT.
+extern "C" int tts_host_mel_diffusion100(const float *audio24k, int64_t n, int normalize, float *mel_out) {
   std::vector<double> mel;
   const int frames = tts::mel_spectrogram(audio24k, n, 1024, 256, 100, 24000.0, 0.0, 12000.0, /*htk=*/false, /*power=*/1, mel);
   if (frames < 0) return frames;
-  const double mel_max = 2.3143386840820312, mel_min = -11.512925148010254; // normalize_tacotron_mel; the inverse is main.cpp:6044-6060
-  for (size_t i = 0; i < mel.size(); i++) mel_out[i] = (float)(2.0 * ((std::log(std::max(mel[i], 1e-5)) - mel_min) / (mel_max - mel_min)) - 1.0);
+  const double mel_max = 2.3143386840820312, mel_min = -11.512925148010254;
+  for (size_t i = 0; i < mel.size(); i++) {
+    const double lm = std::log(std::max(mel[i], 1e-5));
+    mel_out[i] = (float)(normalize ? 2.0 * ((lm - mel_min) / (mel_max - mel_min)) - 1.0 : lm);
+  }
   return frames;
 }
 extern "C" int tts_host_mel_voice80(const float *audio22k, int64_t n, const float *mel_norms80, float *mel_out) {
