@@ -167,3 +167,49 @@ def test_bench_force_dist_one_rank_gloo():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["collective_backend"] == "gloo" and out["collective_ranks"] == 1
     assert out["gathered_samples"] == out["dry_engine"]["gathered_samples"] > 0
+
+
+def test_cli_devices_worker_bookkeeping_without_a_gpu(tmp_path):
+    """`tortoise --devices 2 --exchange files` on a machine without a GPU (--dry-run 1: host-only contexts, the host sampler on fixed synthetic
+    logits stands in for the stages): the parent re-executes itself once per shard with --shard r/2 and ONE seed, worker r draws exactly its
+    candidates' uniforms from the one mt19937 stream and writes its candidates under their GLOBAL names — the four files of the two-worker run are
+    the four files of the single process; with --clvp the parent keeps the best of the workers' winners (the single process's winner); a failing
+    worker makes the parent fail."""
+    exe = os.path.join(ROOT, "tortoise.cpp_amd", "tortoise")
+    if not os.path.exists(exe):
+        pytest.skip("CLI binary not built")
+    models = os.path.join(ROOT, "models")
+    base = [exe, "--dry-run", "1", "--models", models, "--voice", os.path.join(models, "mol.bin"), "--seed", "11", "--codes", "9", "--candidates", "4"]
+
+    def wav(p):
+        return np.frombuffer(open(p, "rb").read()[44:], np.float32)
+
+    runs = {}
+    for tag, extra in (("one", []), ("two", ["--devices", "2"]), ("four", ["--devices", "4"])):
+        out = str(tmp_path / (tag + ".wav"))
+        r = subprocess.run(base + ["--output", out] + extra, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout + r.stderr
+        files = [out] + ["%s.%d.wav" % (out, c) for c in range(1, 4)]
+        assert all(os.path.exists(f) for f in files), (tag, os.listdir(tmp_path))
+        runs[tag] = [wav(f) for f in files]
+        assert all(len(x) == 9 and (x >= 0).all() and (x < 8194).all() for x in runs[tag])
+    for tag in ("two", "four"):
+        for c in range(4):
+            assert (runs[tag][c] == runs["one"][c]).all(), (tag, c)
+    assert len({tuple(x) for x in runs["one"]}) > 1  # the candidates differ (their draws do)
+    # re-ranking: the parent's pick among the workers' winners = the single process's winner; no per-candidate files are left behind
+    picks = {}
+    for tag, extra in (("one", []), ("two", ["--devices", "2"])):
+        out = str(tmp_path / ("rr_" + tag + ".wav"))
+        r = subprocess.run(base + ["--output", out, "--clvp", "unused-in-dry-run"] + extra, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "clvp: candidate" in r.stdout, r.stdout + r.stderr
+        picks[tag] = (r.stdout.split("clvp: candidate")[1].split()[0], tuple(wav(out)))
+        assert not [f for f in os.listdir(tmp_path) if f.startswith("rr_" + tag + ".wav.")], os.listdir(tmp_path)
+    assert picks["one"] == picks["two"]
+    # a worker that cannot start its work (unreadable --voice) fails the parent
+    r = subprocess.run(base[:6] + [str(tmp_path / "missing.bin")] + base[7:] + ["--devices", "2", "--output", str(tmp_path / "x.wav")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    # candidates must divide over the devices
+    r = subprocess.run(base + ["--devices", "3", "--output", str(tmp_path / "y.wav")], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "does not divide" in r.stderr

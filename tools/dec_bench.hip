@@ -4,6 +4,7 @@
 //         tortoise.cpp_amd/csrc/host_logic.cpp -o tools/dec_bench_bin
 #include "../tortoise.cpp_amd/csrc/ar.hip"
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <vector>
 using namespace tts;
@@ -12,6 +13,7 @@ hipEvent_t tts::prof_event(tts_ctx *) { return nullptr; } // profiling is off in
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 static void dump_trace(const char *tag, int nblocks, int nph, int slot) {
+#ifdef TTS_DEC_TRACE
   std::vector<long long> all(6 * 1024 * 8);
   hipError_t e = hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(tts::tts_dec_trace), all.size() * 8);
   if (e != hipSuccess) printf("memcpyFromSymbol: %s\n", hipGetErrorString(e));
@@ -30,8 +32,16 @@ static void dump_trace(const char *tag, int nblocks, int nph, int slot) {
   long long last = 0;
   for (int b = 0; b < nblocks; b++) last = std::max(last, t[b * 8 + nph - 1]);
   printf("  last workgroup's final stamp: %.2f us\n", (last - t0) * 0.01);
+#else
+  (void)tag; (void)nblocks; (void)nph; (void)slot;
+#endif
 }
 
+#ifdef TTS_DEC_TRACE
+static const char *kBuild = "TRACED";
+#else
+static const char *kBuild = "plain";
+#endif
 int main(int argc, char **argv) {
   const int L = argc > 1 ? atoi(argv[1]) : 30, B = 16; // L = 1: same slab every launch (is it still in L2 / MALL?)
   float *h, *ff, *att, *g, *bvec, *q;
@@ -88,24 +98,24 @@ int main(int argc, char **argv) {
     timeit(tag, [&](int l) { attn_decode_fast_kernel<<<dim3(B, 16), 256, 0, st>>>(q, kc, vc, ss, 256, att); }, 0);
   }
   CK(hipMemcpy(ss, &hs, sizeof(hs), hipMemcpyHostToDevice));
-#ifdef TTS_DEC_TRACE
 
   // ---- the decode step as it runs: 30 layers x {LN1+QKV, attention, projection, LN2+FC, MLP projection} + head, captured in a hipGraph ----
   // Per kernel of the LAST layer (every layer overwrites its slot): first workgroup start, the median workgroup's phase stamps, last workgroup end,
   // relative to the layer's first stamp; "gap" = first start of this kernel - last end of its predecessor (the dependent kernel boundary).
-  {
+  auto run_chain = [&](auto ht_c) -> int {
+    constexpr bool HT = decltype(ht_c)::value;
     CK(hipMemcpy(ss, &hs, sizeof(hs), hipMemcpyHostToDevice)); // n_past = 20: keys of the attention
     StepState hs3{164, 3}; CK(hipMemcpy(ss, &hs3, sizeof(hs3), hipMemcpyHostToDevice)); // mid-sequence context (P + 96)
     hipGraph_t graph; hipGraphExec_t exec;
     CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     for (int l = 0; l < L; l++) {
       { DecLnArgs a{h, nullptr, nullptr, wqkv[l], (const __half *)wqkv[l], bvec, B, 3072, 1024, 0, q, kc, vc, ss, 256, 0};
-        dec_ln_gemv_kernel<DEC_QKV, 1, true><<<dim3(192, 1), 256, 0, st>>>(a); }
+        dec_ln_gemv_kernel<DEC_QKV, 1, true, HT><<<dim3(192, 1), 256, 0, st>>>(a); }
       attn_decode_fast_kernel<<<dim3(B, 16), 256, 0, st>>>(q, kc, vc, ss, 256, att);
-      dec_gemv_resid_kernel<1, 256, 0, true><<<dim3(256, 1), 256, 0, st>>>(att, B, wproj[l], bvec, h);
+      dec_gemv_resid_kernel<1, 256, 0, true, HT><<<dim3(256, 1), 256, 0, st>>>(att, B, wproj[l], bvec, h);
       { DecLnArgs a{h, nullptr, nullptr, wfc[l], (const __half *)wfc[l], bvec, B, 4096, 0, 0, ff, nullptr, nullptr, ss, 0, 0};
-        dec_ln_gemv_kernel<DEC_GELU, 1, true><<<dim3(256, 1), 256, 0, st>>>(a); }
-      dec_gemv_resid_kernel<4, 512, 0, true><<<dim3(256, 1), 512, 0, st>>>(ff, B, wfc2[l], bvec, h);
+        dec_ln_gemv_kernel<DEC_GELU, 1, true, HT><<<dim3(256, 1), 256, 0, st>>>(a); }
+      dec_gemv_resid_kernel<4, 512, 0, true, HT><<<dim3(256, 1), 512, 0, st>>>(ff, B, wfc2[l], bvec, h);
     }
     CK(hipStreamEndCapture(st, &graph));
     CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
@@ -115,8 +125,9 @@ int main(int argc, char **argv) {
     for (int i = 0; i < reps; i++) CK(hipGraphLaunch(exec, st));
     CK(hipEventRecord(e1, st)); CK(hipStreamSynchronize(st));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("\nlayer chain in a hipGraph (%d layers x 5 launches, B = %d, %d keys, TRACED build): %.1f us per replay = %.2f us per layer\n", L, B, hs3.n_past + 1,
+    printf("\nlayer chain in a hipGraph (%d layers x 5 launches, B = %d, %d keys, %s build, residual stream %s): %.1f us per replay = %.2f us per layer\n", L, B, hs3.n_past + 1, kBuild, HT ? "in the h4 layout (round 4)" : "as [row][1024] (round 3)",
            1e3 * ms / reps, 1e3 * ms / reps / L);
+#ifdef TTS_DEC_TRACE
     std::vector<long long> all(6 * 1024 * 8);
     CK(hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(tts::tts_dec_trace), all.size() * 8));
     struct K { const char *name; int slot, nwg, nph; const char *phases; };
@@ -143,7 +154,10 @@ int main(int argc, char **argv) {
       printf("    (%s)\n", ks[k].phases);
       prev_end = last;
     }
-  }
 #endif
+    return 0;
+  };
+  if (run_chain(std::false_type{})) return 1;
+  if (run_chain(std::true_type{})) return 1;
   return 0;
 }

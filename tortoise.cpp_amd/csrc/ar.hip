@@ -305,15 +305,26 @@ __global__ __launch_bounds__(64) void attention_kernel(const float *__restrict__
 // position counters live in device memory so the same graph is replayed for every step.
 // ---------------------------------------------------------------------------------------------
 struct StepState { int n_past; int pos_id; };
+// index of (candidate r, channel k) in the decode step's interleaved residual-stream layout h4 (described in front of the decode kernels)
+__host__ __device__ __forceinline__ size_t h4_index(int r, int k) { return ((((size_t)(r >> 4) * 256 + (k >> 2)) * 16 + (r & 15)) << 2) + (k & 3); }
 
 __global__ __launch_bounds__(256) void embed_step_kernel(const float *__restrict__ mel_emb, const float *__restrict__ mel_pos,
                                                          const int *__restrict__ toks, const StepState *__restrict__ ss,
-                                                         float *__restrict__ h) {
+                                                         float *__restrict__ h4) {
   const int r = blockIdx.x;
   const float4 a = ((const float4 *)(mel_emb + (size_t)toks[r] * D))[threadIdx.x];
   const float4 b = ((const float4 *)(mel_pos + (size_t)ss->pos_id * D))[threadIdx.x];
-  ((float4 *)(h + (size_t)r * D))[threadIdx.x] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  *(float4 *)(h4 + h4_index(r, 4 * threadIdx.x)) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); // h4 layout, see below
 }
+
+// Round 4 — the residual stream of the DECODE step lives in an interleaved layout, `h4`:
+//     element (candidate r, channel k)  ->  h4[r / 16][k / 4][r % 16][k % 4]       (16-byte groups of 4 channels, the 16 candidates of a tile adjacent)
+// The LayerNorm-GEMV kernels feed the activations to the matrix pipe as the B operand: lane (m = candidate, q) holds 8 consecutive channels, so with the
+// natural [r][1024] layout one wave-level load touched 16 rows x 64 B — sixteen half-used cache lines per instruction, twice each. That is the pattern
+// cdna_hip_programming.md warns about ("fragment-shaped loads (16 rows x 64 B per instruction) straight to VGPRs ... TA_BUSY 2x") and the per-launch trace
+// shows its price: ~3 us until the 64 KB of activations are in, against <1 us for the same 64 KB read as 1 KB-contiguous instructions by
+// dec_gemv_resid_kernel (profiles/r4_decode_launch_breakdown.txt). In h4 the same instruction covers 4 x 256 contiguous bytes = 8 full lines, nothing twice;
+// the projection kernels' 64 outputs per workgroup (16 candidates x 4 columns) become ONE contiguous 256-byte block. The prompt pass keeps [row][1024].
 
 // ---- decode step: five launches per layer, no split-K partials ---------------------------------------
 // Every weight matrix is packed at load for the workgroup that streams it (one contiguous slab per
@@ -409,7 +420,7 @@ __device__ __forceinline__ void dec_layernorm(float4 (&x)[16], const float *__re
 // half the bytes streamed; the activations keep their hi + lo split) — the throughput mode of SURVEY 8d, option "ar_weights";
 // 3 = OCP fp8 (e4m3) WEIGHTS with a power-of-two scale per output column (a quarter of the bytes): converted to fp16 in
 // registers (exact: every e4m3 value is an fp16 value), multiplied on the fp16 MFMA against the hi + lo split activations.
-template <int EPI, int SPLIT = 0, bool NTW = false>
+template <int EPI, int SPLIT = 0, bool NTW = false, bool HT = false> // HT: a.h is in the h4 layout (decode step); otherwise [row][1024] (prompt pass)
 __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a_in) {
   constexpr int SP = SPLIT ? 1 : 0;
   constexpr int TSLOT = EPI == DEC_QKV ? 0 : EPI == DEC_GELU ? 3 : 5; (void)TSLOT;
@@ -439,7 +450,8 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a_in) {
   if (EPI == DEC_QKV) {
     unsigned zero = 0;
     asm volatile("" : "+v"(zero));
-    n_past = *(const int *)((const char *)&a.ss->n_past + zero);
+    const int *np_ptr = a.prefill_B == 0 ? &a.ss->n_past : (const int *)a.bias; // the prompt pass has no step state (ss may be null): read a valid dummy, drop it
+    n_past = *(const int *)((const char *)np_ptr + zero);
     n_past = a.prefill_B == 0 ? n_past : 0;
   }
   // activations next (L2 hits), then the weight slab (HBM): vmcnt retires in order, so the LayerNorm runs on
@@ -447,10 +459,18 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a_in) {
   const int koff = wave * 256 + (SPLIT ? 8 : 4) * q;
   float4 x[16];
   {
-    // rows past the batch re-read the last candidate (branch-free); their results are never stored
-    const float *hp = a.h + (size_t)min(row, a.rows - 1) * D + koff;
+    if (HT) {
+      // h4: the float4 of (candidate m, channels k .. k+3) sits at ((tile * 256 + k / 4) * 16 + m) * 4; a wave-level load = 4 runs of 256 contiguous
+      // bytes (the 16 candidates of one channel group), 8 full cache lines. Rows past the batch are padding of the tile (allocated, never stored).
+      const float *hp = a.h + (((size_t)blockIdx.y * 256 + (koff >> 2)) * 16 + m) * 4;
 #pragma unroll
-    for (int i = 0; i < 16; i++) x[i] = *(const float4 *)(hp + (SPLIT ? (i >> 1) * 32 + (i & 1) * 4 : i * 16));
+      for (int i = 0; i < 16; i++) x[i] = *(const float4 *)(hp + (SPLIT ? (i >> 1) * 8 + (i & 1) : i * 4) * 64);
+    } else {
+      // rows past the batch re-read the last candidate (branch-free); their results are never stored
+      const float *hp = a.h + (size_t)min(row, a.rows - 1) * D + koff;
+#pragma unroll
+      for (int i = 0; i < 16; i++) x[i] = *(const float4 *)(hp + (SPLIT ? (i >> 1) * 32 + (i & 1) * 4 : i * 16));
+    }
   }
   float4 w[16]; // SPLIT: step s = (w[2s] = 8 fp16 hi, w[2s+1] = 8 fp16 lo) of 64*W[k = koff + 32 s + e][col]
   {
@@ -568,7 +588,7 @@ __global__ __launch_bounds__(256) void dec_ln_gemv_kernel(DecLnArgs a_in) {
 // many of those loads the CU keeps in flight.
 // WH: the slab holds fp16 weights (pack_cols4 order, 8 bytes per (k, 4 columns): option ar_weights = 1), converted to f32 in registers.
 // WH = 2: OCP fp8 (e4m3) weights, 4 bytes per (k, 4 columns), times the power-of-two wscale[column] after the reduction (option ar_weights = 2).
-template <int KG, int NT = 256, int WH = 0, bool NTW = false>
+template <int KG, int NT = 256, int WH = 0, bool NTW = false, bool HT = false> // HT: h is in the h4 layout (decode step)
 __global__ __launch_bounds__(NT) void dec_gemv_resid_kernel(const float *__restrict__ X, int rows, const float *__restrict__ W,
                                                             const float *__restrict__ bias, float *__restrict__ h,
                                                             const float *__restrict__ wscale = nullptr) {
@@ -581,7 +601,9 @@ __global__ __launch_bounds__(NT) void dec_gemv_resid_kernel(const float *__restr
   // the residual element and the bias this thread adds at the very end (threads 0-63: output 4 * candidate + column) are requested
   // first instead of after the reduction (a dependent L2 round trip at the end of 60 launches per step)
   const int er = min(row0 + ((tid & 63) >> 2), rows - 1), ecol = cb * 4 + (tid & 3);
-  const float h_old = h[(size_t)er * D + ecol], b_old = bias[ecol];
+  // h4: the workgroup's 16 candidates x 4 columns are 64 consecutive floats (thread t < 64 owns float t of the block)
+  const size_t hidx = HT ? (((size_t)blockIdx.y * 256 + cb) * 64 + (tid & 63)) : (size_t)er * D + ecol;
+  const float h_old = h[hidx], b_old = bias[ecol];
   float s_old = 1.0f;
   if (WH == 2) s_old = wscale[ecol];
   float4 xa0[8]; // candidates 0-7 of K group 0: requested before the weight stream
@@ -691,7 +713,7 @@ __global__ __launch_bounds__(NT) void dec_gemv_resid_kernel(const float *__restr
       float t = red[0][tid];
 #pragma unroll
       for (int w2 = 1; w2 < NW; w2++) t += red[w2][tid];
-      h[(size_t)r * D + col] = h_old + ((WH == 2 ? t * s_old : t) + b_old);
+      h[HT ? hidx : (size_t)r * D + col] = h_old + ((WH == 2 ? t * s_old : t) + b_old);
     }
   }
   DEC_T(4);
@@ -1385,10 +1407,10 @@ static int launch_mfma_matmul(tts_ctx *ctx, ArState *st, const float *X, int row
 }
 
 #define CHECK(x) do { int _r = (x); if (_r) return _r; } while (0)
-#define DEC_LN_LAUNCH(EPI_, GRID_)                                                         \
-  do {                                                                                     \
-    if (st->f32_mfma) dec_ln_gemv_kernel<EPI_, 0><<<GRID_, 256, 0, ctx->stream>>>(a);       \
-    else dec_ln_gemv_kernel<EPI_, 1, true><<<GRID_, 256, 0, ctx->stream>>>(a);              \
+#define DEC_LN_LAUNCH(EPI_, GRID_, HT_)                                                            \
+  do {                                                                                             \
+    if (st->f32_mfma) dec_ln_gemv_kernel<EPI_, 0, false, HT_><<<GRID_, 256, 0, ctx->stream>>>(a);   \
+    else dec_ln_gemv_kernel<EPI_, 1, true, HT_><<<GRID_, 256, 0, ctx->stream>>>(a);                 \
   } while (0)
 
 
@@ -1476,7 +1498,10 @@ int ar_begin(tts_ctx *ctx, const int32_t *text_ids, int n_text, const float *voi
     st->h_cap_B = B;
   }
   // the decode-step graph is kept: ar_step re-captures it only if a buffer moved or the batch shape changed (GraphSig)
-  return reserve_rows(ctx, st, std::max(B, st->P));
+  // the decode step's h4 layout holds whole tiles of 16 candidates: the padding rows of the last tile are read (never stored), keep them finite
+  CHECK(reserve_rows(ctx, st, std::max((B + 15) / 16 * 16, st->P)));
+  TTS_HIP(ctx, hipMemsetAsync(st->h.p, 0, st->h.cap, ctx->stream));
+  return TTS_OK;
 }
 
 // Prefill (main.cpp:2586-2665): [voice | text_emb+pos | mel_emb(8192)+mel_pos(0)] — identical for all
@@ -1500,14 +1525,14 @@ int ar_prefill(tts_ctx *ctx, float *logits_out) {
     __half *kc = st->kcache.as<__half>() + l * layer_stride, *vc = st->vcache.as<__half>() + l * layer_stride;
     { ProfScope ps(ctx, "ar_gemv", 3.0 * D * D * 4.0 * tiles);
       DecLnArgs a{h, nullptr, nullptr, w.d_attn, w.dh_attn, w.db_attn, P, 3 * D, 3 * D, st->B, qkv, kc, vc, nullptr, st->max_pos, ctx->ggml_lut};
-      DEC_LN_LAUNCH(DEC_QKV, dim3(3 * D / 16, tiles)); }
+      DEC_LN_LAUNCH(DEC_QKV, dim3(3 * D / 16, tiles), false); }
     { ProfScope ps(ctx, "ar_attention");
       attention_kernel<<<dim3(P, NH), 64, 0, ctx->stream>>>(qkv, kc, vc, att, P, 0, st->max_pos, ctx->ggml_lut); }
     { ProfScope ps(ctx, "ar_gemv", 1.0 * D * D * 4.0 * tiles);
       dec_gemv_resid_kernel<1><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, P, w.d_proj, w.b_proj, h); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * 4.0 * tiles);
       DecLnArgs a{h, nullptr, nullptr, w.d_fc, w.dh_fc, w.db_fc, P, FF, 0, 0, ff, nullptr, nullptr, nullptr, 0, ctx->ggml_lut};
-      DEC_LN_LAUNCH(DEC_GELU, dim3(FF / 16, tiles)); }
+      DEC_LN_LAUNCH(DEC_GELU, dim3(FF / 16, tiles), false); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * 4.0 * tiles);
       dec_gemv_resid_kernel<4, 512><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, P, w.d_fc2, w.b_fc2, h); }
   }
@@ -1515,7 +1540,7 @@ int ar_prefill(tts_ctx *ctx, float *logits_out) {
   { ProfScope ps(ctx, "ar_gemv", (double)D * VPAD * 4.0);
     DecLnArgs a{h + (size_t)(P - 1) * D, st->lnf_g, st->lnf_b, st->d_lm, st->dh_lm, st->d_lmb, 1, V, V, 0, st->logits.as<float>(),
                 nullptr, nullptr, nullptr, 0, ctx->ggml_lut};
-    DEC_LN_LAUNCH(DEC_LOGITS, dim3(VPAD / 16, 1)); }
+    DEC_LN_LAUNCH(DEC_LOGITS, dim3(VPAD / 16, 1), false); }
   TTS_HIP(ctx, hipGetLastError());
   if (logits_out) {
     TTS_HIP(ctx, hipMemcpyAsync(logits_out, st->logits.p, (size_t)V * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1533,7 +1558,7 @@ int ar_prefill(tts_ctx *ctx, float *logits_out) {
 // per tile of 16 candidates.
 static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
   const int B = st->B, tiles = (B + 15) / 16;
-  float *h = st->h.as<float>(), *q = st->qkv.as<float>(), *att = st->att.as<float>(), *ff = st->ff.as<float>();
+  float *h = st->h.as<float>() /* h4 layout inside the step */, *q = st->qkv.as<float>(), *att = st->att.as<float>(), *ff = st->ff.as<float>();
   const StepState *ss = (const StepState *)(st->d_toks.as<int>() + B);
   const size_t layer_stride = (size_t)B * st->max_pos * D;
   const int wm = ctx->ar_weights; // 1 / 2: fp16 / fp8 weights, a half / a quarter of the bytes per step (throughput modes, not f32-exact); checked by ar_step
@@ -1546,33 +1571,33 @@ static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
     { ProfScope ps(ctx, "ar_gemv", 3.0 * D * D * wb * tiles);
       DecLnArgs a{h, nullptr, nullptr, w.d_attn, wm == 2 ? (const __half *)w.o_attn : wm == 1 ? w.q_attn : w.dh_attn, w.db_attn, B, 3 * D, D, 0, q, kc, vc, ss,
                   st->max_pos, ctx->ggml_lut, w.os_attn};
-      if (wm == 2) dec_ln_gemv_kernel<DEC_QKV, 3, true><<<dim3(3 * D / 16, tiles), 256, 0, ctx->stream>>>(a);
-      else if (wm == 1) dec_ln_gemv_kernel<DEC_QKV, 2><<<dim3(3 * D / 16, tiles), 256, 0, ctx->stream>>>(a);
-      else DEC_LN_LAUNCH(DEC_QKV, dim3(3 * D / 16, tiles)); }
+      if (wm == 2) dec_ln_gemv_kernel<DEC_QKV, 3, true, true><<<dim3(3 * D / 16, tiles), 256, 0, ctx->stream>>>(a);
+      else if (wm == 1) dec_ln_gemv_kernel<DEC_QKV, 2, false, true><<<dim3(3 * D / 16, tiles), 256, 0, ctx->stream>>>(a);
+      else DEC_LN_LAUNCH(DEC_QKV, dim3(3 * D / 16, tiles), true); }
     { ProfScope ps(ctx, "ar_attention");
       if (ctx->ggml_lut) attn_decode_kernel<<<dim3(B, NH), 256, 0, ctx->stream>>>(q, kc, vc, ss, st->max_pos, att, 1);
       else attn_decode_fast_kernel<<<dim3(B, NH), 256, 0, ctx->stream>>>(q, kc, vc, ss, st->max_pos, att); }
     { ProfScope ps(ctx, "ar_gemv", 1.0 * D * D * wb * tiles);
-      if (wm == 2) dec_gemv_resid_kernel<1, 256, 2><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, (const float *)w.o_proj, w.b_proj, h, w.os_proj);
-      else if (wm == 1) dec_gemv_resid_kernel<1, 256, 1><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, (const float *)w.q_proj, w.b_proj, h);
-      else dec_gemv_resid_kernel<1, 256, 0, true><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, w.d_proj, w.b_proj, h); }
+      if (wm == 2) dec_gemv_resid_kernel<1, 256, 2, false, true><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, (const float *)w.o_proj, w.b_proj, h, w.os_proj);
+      else if (wm == 1) dec_gemv_resid_kernel<1, 256, 1, false, true><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, (const float *)w.q_proj, w.b_proj, h);
+      else dec_gemv_resid_kernel<1, 256, 0, true, true><<<dim3(D / 4, tiles), 256, 0, ctx->stream>>>(att, B, w.d_proj, w.b_proj, h); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * wb * tiles);
       DecLnArgs a{h, nullptr, nullptr, w.d_fc, wm == 2 ? (const __half *)w.o_fc : wm == 1 ? w.q_fc : w.dh_fc, w.db_fc, B, FF, 0, 0, ff, nullptr, nullptr, ss, 0,
                   ctx->ggml_lut, w.os_fc};
-      if (wm == 2) dec_ln_gemv_kernel<DEC_GELU, 3, true><<<dim3(FF / 16, tiles), 256, 0, ctx->stream>>>(a);
-      else if (wm == 1) dec_ln_gemv_kernel<DEC_GELU, 2><<<dim3(FF / 16, tiles), 256, 0, ctx->stream>>>(a);
-      else DEC_LN_LAUNCH(DEC_GELU, dim3(FF / 16, tiles)); }
+      if (wm == 2) dec_ln_gemv_kernel<DEC_GELU, 3, true, true><<<dim3(FF / 16, tiles), 256, 0, ctx->stream>>>(a);
+      else if (wm == 1) dec_ln_gemv_kernel<DEC_GELU, 2, false, true><<<dim3(FF / 16, tiles), 256, 0, ctx->stream>>>(a);
+      else DEC_LN_LAUNCH(DEC_GELU, dim3(FF / 16, tiles), true); }
     { ProfScope ps(ctx, "ar_gemv", 4.0 * D * D * wb * tiles);
-      if (wm == 2) dec_gemv_resid_kernel<4, 512, 2><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, (const float *)w.o_fc2, w.b_fc2, h, w.os_fc2);
-      else if (wm == 1) dec_gemv_resid_kernel<4, 512, 1><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, (const float *)w.q_fc2, w.b_fc2, h);
-      else dec_gemv_resid_kernel<4, 512, 0, true><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, w.d_fc2, w.b_fc2, h); }
+      if (wm == 2) dec_gemv_resid_kernel<4, 512, 2, false, true><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, (const float *)w.o_fc2, w.b_fc2, h, w.os_fc2);
+      else if (wm == 1) dec_gemv_resid_kernel<4, 512, 1, false, true><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, (const float *)w.q_fc2, w.b_fc2, h);
+      else dec_gemv_resid_kernel<4, 512, 0, true, true><<<dim3(D / 4, tiles), 512, 0, ctx->stream>>>(ff, B, w.d_fc2, w.b_fc2, h); }
   }
   { ProfScope ps(ctx, "ar_gemv", (double)D * VPAD * wb * tiles);
     DecLnArgs a{h, st->lnf_g, st->lnf_b, st->d_lm, wm == 2 ? (const __half *)st->o_lm : wm == 1 ? st->q_lm : st->dh_lm, st->d_lmb, B, V, V, 0, st->logits.as<float>(),
                 nullptr, nullptr, ss, 0, ctx->ggml_lut, st->os_lm};
-    if (wm == 2) dec_ln_gemv_kernel<DEC_LOGITS, 3, true><<<dim3(VPAD / 16, tiles), 256, 0, ctx->stream>>>(a);
-    else if (wm == 1) dec_ln_gemv_kernel<DEC_LOGITS, 2><<<dim3(VPAD / 16, tiles), 256, 0, ctx->stream>>>(a);
-    else DEC_LN_LAUNCH(DEC_LOGITS, dim3(VPAD / 16, tiles)); }
+    if (wm == 2) dec_ln_gemv_kernel<DEC_LOGITS, 3, true, true><<<dim3(VPAD / 16, tiles), 256, 0, ctx->stream>>>(a);
+    else if (wm == 1) dec_ln_gemv_kernel<DEC_LOGITS, 2, false, true><<<dim3(VPAD / 16, tiles), 256, 0, ctx->stream>>>(a);
+    else DEC_LN_LAUNCH(DEC_LOGITS, dim3(VPAD / 16, tiles), true); }
   TTS_HIP(ctx, hipMemcpyAsync(st->h_logits, st->logits.p, (size_t)B * V * 4, hipMemcpyDeviceToHost, ctx->stream));
   TTS_HIP(ctx, hipGetLastError());
   return TTS_OK;

@@ -27,6 +27,7 @@
 #include "tortoise_mi355x.h"
 #include "cli_rccl.h"
 #include <algorithm>
+#include <cmath>
 #include <csignal>
 #include <cstdio>
 #include <cstdlib>
@@ -52,6 +53,7 @@ int main(int argc, char **argv) {
   bool have_seed = false;
   int seed = 0, candidates = 1, steps = 80, device = 0, fixed_codes = 0, devices = 1, shard = -1, nshards = 1;
   std::string device_map, clvpPath, exchange = "files", rccl_id, diffLatentPath;
+  bool dry = false;
   for (int i = 1; i < argc - 1; ++i) {
     std::string a(argv[i]);
     if (a == "--voice") voicePath = argv[i + 1];
@@ -67,6 +69,7 @@ int main(int argc, char **argv) {
     else if (a == "--device-map") device_map = argv[i + 1];
     else if (a == "--clvp") clvpPath = argv[i + 1];
     else if (a == "--exchange") exchange = argv[i + 1];
+    else if (a == "--dry-run") dry = argv[i + 1][0] != '0'; // plumbing check without a device, see below
     else if (a == "--diffusion-latent") diffLatentPath = argv[i + 1];
     else if (a == "--rccl-id") rccl_id = argv[i + 1]; // worker mode (set by the parent)
     else if (a == "--shard") { // worker mode (set by the parent): "r/N"
@@ -153,7 +156,7 @@ int main(int argc, char **argv) {
   }
   const int total_candidates = candidates;
   if (shard >= 0) candidates = total_candidates / nshards;
-  tts_ctx *ctx = tts_create(device);
+  tts_ctx *ctx = tts_create(dry ? -1 : device); // --dry-run: a host-only context (tokenizer, RNG, sampler; every stage call would fail)
   if (!ctx) {
     fprintf(stderr, "tts_create(%d) failed: no HIP device (this engine has no CPU path)\n", device);
     return 1;
@@ -188,8 +191,42 @@ int main(int argc, char **argv) {
     tokens.assign(cond.ids, cond.ids + n);
     memcpy(voice.data(), cond.voice, 4096);
   }
-  if (tts_load_ar(ctx, (modelsDir + "/ggml-model.bin").c_str())) return die(ctx, "autoregressive_model_load");
+  // results of the three stages (or of their stand-in under --dry-run): B output candidates, candidate c has nsamp[c] samples in `audio`
+  int B = candidates, kept_gc = -1;
+  double kept_score = 0;
+  std::vector<float> audio;
+  std::vector<size_t> nsamp;
+  std::vector<int32_t> frames;
   const int B_ar = candidates;
+  if (dry) {
+    // Plumbing check without a device (tests/test_distributed_cpu.py): the host sampler on fixed synthetic logits stands in for the AR stage (so the
+    // RNG stream partition of a --devices run is the real one), a candidate's "audio" is its sampled ids, its CLVP score a function of them. Exercises
+    // the parent's fork / exec / --shard / --seed hand-over, the per-candidate file names, the parent's pick among the workers' winners and its exit code.
+    const int nsteps_dry = fixed_codes > 0 ? fixed_codes : 8, V = TTS_VOCAB_MEL;
+    std::vector<float> logits((size_t)B_ar * V);
+    std::vector<int32_t> prev(B_ar, 8192), ids(B_ar);
+    std::vector<std::vector<float>> seqs(B_ar);
+    for (int st = 0; st < nsteps_dry; st++) {
+      for (int c = 0; c < B_ar; c++)
+        for (int v = 0; v < V; v++) logits[(size_t)c * V + v] = 3.0f * std::sin(0.37f * (float)v + 0.11f * (float)st); // the same for every candidate: only the draws differ
+      if (tts_sample(ctx, logits.data(), prev.data(), 1, B_ar, ids.data())) return die(ctx, "sample");
+      for (int c = 0; c < B_ar; c++) { seqs[c].push_back((float)ids[c]); prev[c] = ids[c]; }
+    }
+    int best = 0;
+    std::vector<double> scores(B_ar, 0.0);
+    for (int c = 0; c < B_ar; c++)
+      for (float v : seqs[c]) scores[c] = std::fmod(scores[c] * 31.0 + (double)v, 1009.0);
+    for (int c = 1; c < B_ar; c++)
+      if (scores[c] > scores[best]) best = c;
+    if (!clvpPath.empty()) {
+      kept_gc = (shard >= 0 ? shard * B_ar : 0) + best; kept_score = scores[best]; B = 1;
+      audio = seqs[best]; nsamp.assign(1, audio.size());
+      if (shard < 0) printf("clvp: candidate %d kept (score %.5f)\n", kept_gc, kept_score);
+    } else {
+      for (int c = 0; c < B_ar; c++) { audio.insert(audio.end(), seqs[c].begin(), seqs[c].end()); nsamp.push_back(seqs[c].size()); }
+    }
+  } else {
+  if (tts_load_ar(ctx, (modelsDir + "/ggml-model.bin").c_str())) return die(ctx, "autoregressive_model_load");
   std::vector<int32_t> codes((size_t)B_ar * 502), rows(B_ar);
   std::vector<float> latents((size_t)B_ar * 500 * 1024);
   int32_t nsteps = 0;
@@ -208,9 +245,8 @@ int main(int argc, char **argv) {
   }
 
   // CLVP re-ranking (extension): keep the candidate whose codes (the rows the diffusion stage would consume) score best against the text
-  int B = B_ar, kept_gc = -1;
+  B = B_ar;
   const float *lat_in = latents.data();
-  double kept_score = 0;
   if (!clvpPath.empty()) {
     if (tts_load_clvp(ctx, clvpPath.c_str())) return die(ctx, "clvp_model_load");
     std::vector<float> scores(B_ar);
@@ -243,18 +279,21 @@ int main(int argc, char **argv) {
     if (tts_set_diffusion_conditioning_latent(ctx, dl.data())) return die(ctx, "diffusion_conditioning_latent");
   }
   size_t mel_total = 0, audio_total = 0;
-  std::vector<int32_t> frames(B);
+  frames.assign(B, 0);
   for (int c = 0; c < B; c++) {
     frames[c] = tts_diffusion_frames(rows[c]);
     mel_total += (size_t)100 * frames[c];
     audio_total += (size_t)tts_vocoder_samples(frames[c]);
   }
-  std::vector<float> mel(mel_total), audio(audio_total);
+  std::vector<float> mel(mel_total);
+  audio.assign(audio_total, 0.f);
   // B == 1: the reference's exact RNG order (AR uniforms, x_T, per-step noise, vocoder noise)
   const int noise_mode = (total_candidates == 1) ? TTS_NOISE_REFERENCE : TTS_NOISE_DEVICE;
   if (tts_diffusion(ctx, lat_in, rows.data(), B, steps, nullptr, noise_mode, mel.data())) return die(ctx, "diffusion");
   if (tts_load_vocoder(ctx, (modelsDir + "/ggml-vocoder-model.bin").c_str())) return die(ctx, "vocoder_model_load");
   if (tts_vocoder(ctx, mel.data(), frames.data(), B, nullptr, noise_mode, audio.data())) return die(ctx, "vocoder");
+  for (int c = 0; c < B; c++) nsamp.push_back((size_t)tts_vocoder_samples(frames[c]));
+  } // !dry
   auto write_one = [&](const float *samples, int64_t ns, int gc, bool is_output) {
     const std::string path = is_output ? outputPath : outputPath + "." + std::to_string(gc) + ".wav";
     if (tts_write_wav(path.c_str(), samples, ns, 24000)) std::cerr << "Error opening output file." << std::endl;
@@ -301,7 +340,7 @@ int main(int argc, char **argv) {
   } else {
     size_t off = 0;
     for (int c = 0; c < B; c++) {
-      size_t ns = (size_t)tts_vocoder_samples(frames[c]);
+      size_t ns = nsamp[c];
       const int gc = kept_gc >= 0 ? kept_gc : (shard >= 0 ? shard * B_ar : 0) + c; // global candidate index
       // the re-ranked winner of a single process IS the output; a worker's winner waits for the parent's pick under its candidate name
       write_one(audio.data() + off, (int64_t)ns, gc, kept_gc >= 0 ? shard < 0 : gc == 0);

@@ -33,9 +33,9 @@ static constexpr int C = 1024, NHEAD = 16, XTC = 128 /* x_t channels padded 100 
 // element and made the GroupNorm kernel VALU-bound instead of HBM-bound (seen in its ISA: 2100 instructions per
 // thread). lut = 1 (option "ggml_lut") keeps the exact fp16-table emulation.
 // lut = 2 (option "attn_f32", the reference-precision mode): x / (1 + expf(-x)) with libm's expf and an IEEE division, the reference's own
-// f32 formula. The fast form is 2-3 ulp off; its result is rounded to an fp16 GEMM operand right away, and an operand that lands on the other
-// side of a rounding boundary is a 5e-4 relative perturbation — the dominant seed of the 80-step loop's chaotic divergence (round 4: the
-// parity mode's distance from the oracle only came down to the torch-f32-vs-oracle level with this switch as well).
+// f32 formula (the fast form is 2-3 ulp off). Measured on the 80-step loop: no effect on the distance from the oracle (mean abs 4.67e-5 / 5.70e-5 /
+// 6.05e-5 on the small / mid / full-size problems with either form) — kept in the parity mode because it is the reference's arithmetic, not because it
+// buys anything.
 __device__ __forceinline__ float silu_dev(float x, int lut) {
   if (lut == 1) {
     float xr = __half2float(__float2half_rn(x));
