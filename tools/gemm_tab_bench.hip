@@ -2,16 +2,14 @@
 // benchmark's shapes. Policies: `arith=<h>` = the product's arithmetic tile walk (h = tile height in 16-row blocks, 0 = automatic), `<name>=h,h,..[/cn][/order]` = an
 // explicit per-XCD tile table (tools/gemm_tile_tables.h) of cyclic heights, `big=0` = the rejected 256-column 8-phase kernel (tools/gemm_f16_big.h; build with
 // -DBIG_STAGGER=0/1 -DBIG_PREFETCH=0/1 for its variants). Every output is compared bit for bit with the round-2 kernel's; timings are interleaved rounds in one
-// process (median and min). -DTTS_GEMM_TRACE adds per-tile phase stamps (K loop / epilogue issue / store drain by tile height; per-phase cycles of the 256-column kernel).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I tortoise.cpp_amd/csrc -I tools [-DTTS_GEMM_TRACE] tools/gemm_tab_bench.hip -o tools/bin/gemm_tab_bench
+// process (median and min). (The per-tile phase stamps and the K-loop ablation builds of round 3 — profiles/r3_gemm_epilogue.txt, r3_gemm_kloop_ablation.txt — needed instrumentation
+// inside csrc/gemm_f16.h; it was removed from the product header in round 4, the results stay in profiles/.)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I tortoise.cpp_amd/csrc -I tools tools/gemm_tab_bench.hip -o tools/bin/gemm_tab_bench
 //   tools/bin/gemm_tab_bench [shape-filter] [policy ...]      e.g.  tools/bin/gemm_tab_bench conv3 arith=0 u7=7 mix=8,6/8/0 big=0
 //   results: profiles/r3_gemm_tile_tables.txt, r3_gemm_epilogue.txt, r3_gemm_256col_kernel.txt
 #define tts tts_r2 // the round-2 one-tile-per-workgroup kernels, for reference output and timing
 #include "gemm_f16_onetile.h"
 #undef tts
-#undef GEMM_TR_DECL
-#undef GEMM_TR
-#undef GEMM_TR_FLUSH
 #include "gemm_f16.h"
 #include "gemm_tile_tables.h"
 #include "gemm_f16_big.h" // the rejected 256-column kernel: policy name "big"
@@ -212,73 +210,6 @@ int main(int argc, char **argv) {
       printf("  %-12s med %8.1f us  min %8.1f  %7.1f TF/s   cold-W %6.1f us   %s\n", v < 0 ? "round-2" : pols[v].name.c_str(), med, u[0], fl / (med * 1e-6) / 1e12,
              cold[v + 1], v < 0 ? "" : status[v].c_str());
     }
-#ifdef TTS_GEMM_TRACE
-    if (gemm_use_big(mk(dC2, dH2, dVt2))) { // per-phase shader-clock stamps of the 256-column kernel (two K tiles of workgroup 64)
-      GemmArgs g = mk(dC2, dH2, dVt2);
-      CK(launch_gemm_f16_big(g, s)); CK(hipStreamSynchronize(s));
-      std::vector<unsigned> bt(8 * 64);
-      CK(hipMemcpyFromSymbol(bt.data(), HIP_SYMBOL(tts_big_trace), bt.size() * 4));
-      printf("  [256-column kernel, workgroup 64, K tiles 4-5; cycles: load part | barrier | fragment wait | MFMA issue | barrier]\n");
-      for (int w : {0, 1, 4, 5}) {
-        printf("    wave %d:", w);
-        const unsigned *q = &bt[w * 64];
-        for (int ph = 0; ph < 8; ph++) {
-          const unsigned *c = q + ph * 5;
-          const unsigned prev_end = ph ? c[-1] : c[0];
-          printf("  %u|%u|%u|%u|%u", c[0] - prev_end, c[1] - c[0], c[2] - c[1], c[3] - c[2], c[4] - c[3]);
-        }
-        printf("   (8 phases: %u cycles)\n", q[7 * 5 + 4] - q[0]);
-      }
-    }
-    for (size_t pi = 0; pi < pols.size(); pi++) {
-      if (pols[pi].name == "big") continue;
-      static std::vector<unsigned long long> tr(65536 * 8);
-      std::fill(tr.begin(), tr.end(), 0ull);
-      CK(hipMemcpyToSymbol(HIP_SYMBOL(tts_gemm_trace), tr.data(), tr.size() * 8));
-      GemmArgs g = mk(dC2, dH2, dVt2);
-      g.tiles = plans[pi].dev; g.tab_len = plans[pi].len; g.th = pols[pi].name.rfind("arith", 0) == 0 ? pols[pi].sp.h[0] : 0;
-      CK(launch_gemm_f16(g, s)); CK(hipStreamSynchronize(s));
-      CK(hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(tts_gemm_trace), tr.size() * 8));
-      unsigned long long tmin = ~0ull, tmax = 0;
-      double kl[9] = {0}, ep[9] = {0}, dr[9] = {0}; int cnt[9] = {0};
-      std::vector<unsigned long long> starts, ends;
-      for (size_t w = 0; w < 65536; w++) {
-        const unsigned long long *p = &tr[w * 8];
-        if (!p[0] || !p[4]) continue;
-        tmin = std::min(tmin, p[0]); tmax = std::max(tmax, p[5]);
-        starts.push_back(p[0]); ends.push_back(p[3]);
-        const int nb = (int)p[2];
-        if (nb >= 0 && nb <= 8) { kl[nb] += (p[3] - p[1]) * 0.01; ep[nb] += (p[4] - p[3]) * 0.01; dr[nb] += (p[5] - p[4]) * 0.01; cnt[nb]++; }
-      }
-      { // which workgroups shared a CU (XCD 0 only): per CU the block ids / 8 in start order with (row tile, column tile)
-        std::map<int, std::vector<std::pair<unsigned long long, size_t>>> percu;
-        for (size_t w = 0; w < 65536; w++) {
-          const unsigned long long *p = &tr[w * 8];
-          if (!p[0] || !p[4] || (p[6] >> 32) != 0) continue;
-          const unsigned hw = (unsigned)p[6];
-          percu[((hw >> 13) & 7) * 32 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 0xf)].push_back({p[0], w});
-        }
-        int shown = 0;
-        for (auto &kv : percu) {
-          if (shown++ >= 6) break;
-          std::sort(kv.second.begin(), kv.second.end());
-          printf("    xcd0 cu %3d:", kv.first);
-          for (auto &e : kv.second) { const unsigned long long *p = &tr[e.second * 8]; printf(" %zu@%.0f(r%u,c%u)", e.second >> 3, (p[0] - tmin) * 0.01, (unsigned)(p[7] >> 32) >> 7, (unsigned)p[7] >> 7); }
-          printf("\n");
-        }
-      }
-      printf("  [trace %s] span %.1f us;", pols[pi].name.c_str(), (tmax - tmin) * 0.01);
-      for (int nb = 2; nb <= 8; nb++) if (cnt[nb]) printf("  h%d: n=%d K-loop %.1f epilogue issue %.1f store drain %.1f us;", nb, cnt[nb], kl[nb] / cnt[nb], ep[nb] / cnt[nb], dr[nb] / cnt[nb]);
-      printf("\n    starts per 5 us:");
-      std::vector<int> hist((size_t)((tmax - tmin) / 500) + 1, 0), hend(hist.size(), 0);
-      for (auto t : starts) hist[(size_t)((t - tmin) / 500)]++;
-      for (auto t : ends) hend[(size_t)((t - tmin) / 500)]++;
-      for (int h : hist) printf(" %d", h);
-      printf("\n    K-loop ends per 5 us:");
-      for (int h : hend) printf(" %d", h);
-      printf("\n");
-    }
-#endif
     for (auto &p : plans) if (p.dev) CK(hipFree(p.dev));
   }
   return 0;

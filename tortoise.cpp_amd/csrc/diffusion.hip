@@ -320,6 +320,9 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
   };
   // S^T of one key tile: sc[i][jt][r] = S[query i*16+fr][key SIG(jt, fq*4 + r)]
   auto scores = [&](const char *Ks, floatx4 (&sc)[2][4]) {
+#ifdef ATT_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int jt = 0; jt < 4; jt++) {
       const half8 kf0 = *(const half8 *)(Ks + attn_off(jt * 16 + fr, fq));
@@ -332,6 +335,9 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
         sc[i][jt] = a;
       }
     }
+#ifdef ATT_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
   ATT_CLK(0);
   stage(0, 0);
@@ -426,6 +432,9 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
     }
     ATT_T(5);
     // O^T += V^T P^T : A = V^T[d = dt*16 + fr][keys 32 ks2 + 8 fq ..+7], B = P^T; row sums: A = ones
+#ifdef ATT_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int ks2 = 0; ks2 < 2; ks2++) {
 #pragma unroll
@@ -437,6 +446,9 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
 #pragma unroll
       for (int i = 0; i < 2; i++) lacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[i][ks2], lacc[i], 0, 0, 0);
     }
+#ifdef ATT_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     ATT_T(6);
   };
   {

@@ -33,10 +33,6 @@
 #include <cstdlib>
 #include <type_traits>
 
-#ifndef TTS_GEMM_ABLATE
-#define TTS_GEMM_ABLATE 0
-#endif
-
 namespace tts {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -73,20 +69,6 @@ struct GemmArgs {
   const int4 *tiles; int tab_len;
 };
 
-#ifdef TTS_GEMM_TRACE // developer build (tools/gemm_tab_bench.hip): phase timestamps (100 MHz wall clock) of every workgroup / tile
-__device__ unsigned long long tts_gemm_trace[65536 * 8];
-#define GEMM_TR_DECL unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define GEMM_TR(i) do { tr_[i] = wall_clock64(); } while (0)
-#define GEMM_TR_FLUSH(slot) do { if (threadIdx.x == 0 && (slot) < 65536) { for (int q_ = 0; q_ < 8; q_++) tts_gemm_trace[(size_t)(slot) * 8 + q_] = tr_[q_]; } } while (0)
-#define GEMM_TR_PARAM , unsigned long long *tr_
-#define GEMM_TR_ARG , tr_
-#else
-#define GEMM_TR_DECL
-#define GEMM_TR(i)
-#define GEMM_TR_FLUSH(slot)
-#define GEMM_TR_PARAM
-#define GEMM_TR_ARG
-#endif
 
 // LDS image of an operand tile: 128-byte rows (64 halves), the eight 16-byte chunks of row r stored at chunk ^ lds_swz(r). A ds_read_b128 is
 // served in groups of 16 lanes = 16 CONSECUTIVE rows, eight of them reading chunk c (fq even) and eight chunk c + 1 (fq odd): the two sets differ in
@@ -267,7 +249,7 @@ __device__ __forceinline__ void gemm_epilogue_vh(const GemmArgs &g, floatx4 (&ac
 // The body is instantiated per number of 16-row blocks of the calling WAVE (0..4): the waves of a workgroup may run different
 // instantiations; all of them issue the same DMA pieces and pass the same two barriers per K tile.
 template <int MODE, int MI>
-__device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, int nblk, int lane, int wave GEMM_TR_PARAM) {
+__device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, int nblk, int lane, int wave) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[]; // named here: an LDS pointer passed in would become a generic pointer
   char *smem = smem_dyn;
   constexpr int MA = MI > 0 ? MI : 1;
@@ -312,7 +294,6 @@ __device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, 
   char *sa = smem, *sb = smem + 16384;
   // operand order (see gemm_epilogue_vh): natural only for the V columns of a QKV projection (wave-uniform)
   const bool natural = gemm_mode_qkv(MODE) && (((n0 + wn * 64) % 192) >= 128);
-  GEMM_TR(1);
   // the K loop is instantiated once per operand order so the choice costs nothing inside it
   auto kloop = [&](auto nat) {
     constexpr bool NAT = decltype(nat)::value;
@@ -322,16 +303,13 @@ __device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, 
       const __half *wseg = g.W + (g.custom_w ? g.w_off_[seg] : seg * g.kseg);
       for (int kt = 0; kt < tiles_per_seg; kt++) {
         const __half *abase = aseg + (kt << 6), *wbase = wseg + (kt << 6);
-#if TTS_GEMM_ABLATE != 1 // (developer ablation builds, tools/gemm_tab_bench.hip: 1 = no operand DMA, 2 = no MFMAs, 3 = DMA and barriers only)
 #pragma unroll
         for (int i = 0; i < 4; i++)
           if (i < my_pa) __builtin_amdgcn_global_load_lds((gptr_t)(abase + aoff[i]), (lptr_t)(sa + (wave + 4 * i) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; i++)
           __builtin_amdgcn_global_load_lds((gptr_t)(wbase + boff[i]), (lptr_t)(sb + (wave * 4 + i) * 1024), 16, 0, 0);
-#endif
         __syncthreads(); // waits vmcnt(0) for the DMA, then barrier
-#if TTS_GEMM_ABLATE != 3
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
           half8 af[MA], bf[4];
@@ -341,12 +319,6 @@ __device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, 
 #pragma unroll
             for (int i = 0; i < 4; i++) bf[i] = *(const half8 *)(sb + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
           }
-#if TTS_GEMM_ABLATE == 2
-#pragma unroll
-          for (int i = 0; i < MI; i++) asm volatile("" ::"v"(af[i]));
-#pragma unroll
-          for (int i = 0; i < 4; i++) asm volatile("" ::"v"(bf[i]));
-#else
 #pragma unroll
           for (int i = 0; i < MI; i++)
 #pragma unroll
@@ -354,20 +326,16 @@ __device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, 
               if (NAT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
               else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
             }
-#endif
         }
-#endif
         __syncthreads();
       }
     }
   };
   if (gemm_mode_qkv(MODE) && natural) kloop(std::true_type{});
   else kloop(std::false_type{});
-  GEMM_TR(3);
   if (resid_first) gemm_epilogue_vh<MODE, MI, EPI_RESID_IN_ACC>(g, acc, m0, n0, wm, wn, fr, fq);
   else if (MODE == GEMM_OUT_F32_SCALED && g.resid) gemm_epilogue_vh<MODE, MI, EPI_RESID_LOAD>(g, acc, m0, n0, wm, wn, fr, fq);
   else gemm_epilogue_vh<MODE, MI, EPI_NO_RESID>(g, acc, m0, n0, wm, wn, fr, fq);
-  GEMM_TR(4);
 }
 
 // Tile walk, shared by both kernels. L2-aware: workgroup b runs on XCD b % 8 (each XCD has its own 4 MB L2). An XCD owns a
@@ -399,22 +367,12 @@ static __global__ __launch_bounds__(256, WGS) void gemm_f16_vh_kernel(GemmArgs g
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: LDS-DMA bases stay in SGPRs
   int m0, n0, nblk;
   if (!gemm_vh_tile(g, m0, n0, nblk)) return;
-  GEMM_TR_DECL;
-  GEMM_TR(0);
   const int my_mi = (nblk - (wave >> 1) + 1) >> 1; // 16-row blocks of this wave
-  if (my_mi == 4) gemm_vh_body<MODE, 4>(g, m0, n0, nblk, lane, wave GEMM_TR_ARG);
-  else if (my_mi == 3) gemm_vh_body<MODE, 3>(g, m0, n0, nblk, lane, wave GEMM_TR_ARG);
-  else if (my_mi == 2) gemm_vh_body<MODE, 2>(g, m0, n0, nblk, lane, wave GEMM_TR_ARG);
-  else if (my_mi == 1) gemm_vh_body<MODE, 1>(g, m0, n0, nblk, lane, wave GEMM_TR_ARG);
-  else gemm_vh_body<MODE, 0>(g, m0, n0, nblk, lane, wave GEMM_TR_ARG); // 1-block tile: this wave only moves operands
-#ifdef TTS_GEMM_TRACE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // stamp 5: the epilogue's stores have been acknowledged
-  GEMM_TR(5);
-  tr_[2] = (unsigned long long)nblk;
-  tr_[6] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf) << 32); // HW_ID | XCC_ID << 32
-  tr_[7] = ((unsigned long long)(unsigned)m0 << 32) | (unsigned)n0;
-#endif
-  GEMM_TR_FLUSH(blockIdx.x);
+  if (my_mi == 4) gemm_vh_body<MODE, 4>(g, m0, n0, nblk, lane, wave);
+  else if (my_mi == 3) gemm_vh_body<MODE, 3>(g, m0, n0, nblk, lane, wave);
+  else if (my_mi == 2) gemm_vh_body<MODE, 2>(g, m0, n0, nblk, lane, wave);
+  else if (my_mi == 1) gemm_vh_body<MODE, 1>(g, m0, n0, nblk, lane, wave);
+  else gemm_vh_body<MODE, 0>(g, m0, n0, nblk, lane, wave); // 1-block tile: this wave only moves operands
 }
 
 // k = 3 convolution as ONE GEMM with a shared activation slab. The three taps are three row-shifted GEMM
@@ -428,7 +386,7 @@ static __global__ __launch_bounds__(256, WGS) void gemm_f16_vh_kernel(GemmArgs g
 // LDS: 17 KB slab + 2 x 16 KB -> 3 workgroups per CU.
 static constexpr int CONV3_VH_LDS = (128 + 8) * 128 + 2 * 16384;
 template <int MODE, int MI>
-__device__ __forceinline__ void gemm_conv3_vh_body(const GemmArgs &g, int m0, int n0, int nblk, int lane, int wave GEMM_TR_PARAM) {
+__device__ __forceinline__ void gemm_conv3_vh_body(const GemmArgs &g, int m0, int n0, int nblk, int lane, int wave) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   char *smem = smem_dyn;
   constexpr int MA = MI > 0 ? MI : 1;
@@ -497,7 +455,6 @@ __device__ __forceinline__ void gemm_conv3_vh_body(const GemmArgs &g, int m0, in
   };
   stageA(0);
   stageB(0);
-  GEMM_TR(1);
   for (int kc = 0; kc < nchunks; kc++) {
     const int p = 3 * kc;
     phase(kc, p, std::integral_constant<int, 0>{});
@@ -505,10 +462,8 @@ __device__ __forceinline__ void gemm_conv3_vh_body(const GemmArgs &g, int m0, in
     phase(kc, p + 2, std::integral_constant<int, 2>{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // trailing (clamped) pieces must land before the LDS is released
-  GEMM_TR(3);
   if (MODE == GEMM_OUT_F32 && g.resid) gemm_epilogue_vh<MODE, MI, EPI_RESID_LOAD>(g, acc, m0, n0, wm, wn, fr, fq);
   else gemm_epilogue_vh<MODE, MI, EPI_NO_RESID>(g, acc, m0, n0, wm, wn, fr, fq);
-  GEMM_TR(4);
 }
 
 template <int MODE>
@@ -516,20 +471,12 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_vh_kernel(GemmAr
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int m0, n0, nblk;
   if (!gemm_vh_tile(g, m0, n0, nblk)) return;
-  GEMM_TR_DECL;
-  GEMM_TR(0);
   const int my_mi = (nblk - (wave >> 1) + 1) >> 1;
-  if (my_mi == 4) gemm_conv3_vh_body<MODE, 4>(g, m0, n0, nblk, lane, wave GEMM_TR_ARG);
-  else if (my_mi == 3) gemm_conv3_vh_body<MODE, 3>(g, m0, n0, nblk, lane, wave GEMM_TR_ARG);
-  else if (my_mi == 2) gemm_conv3_vh_body<MODE, 2>(g, m0, n0, nblk, lane, wave GEMM_TR_ARG);
-  else if (my_mi == 1) gemm_conv3_vh_body<MODE, 1>(g, m0, n0, nblk, lane, wave GEMM_TR_ARG);
-  else gemm_conv3_vh_body<MODE, 0>(g, m0, n0, nblk, lane, wave GEMM_TR_ARG);
-#ifdef TTS_GEMM_TRACE
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  GEMM_TR(5);
-  tr_[2] = (unsigned long long)nblk;
-#endif
-  GEMM_TR_FLUSH(blockIdx.x);
+  if (my_mi == 4) gemm_conv3_vh_body<MODE, 4>(g, m0, n0, nblk, lane, wave);
+  else if (my_mi == 3) gemm_conv3_vh_body<MODE, 3>(g, m0, n0, nblk, lane, wave);
+  else if (my_mi == 2) gemm_conv3_vh_body<MODE, 2>(g, m0, n0, nblk, lane, wave);
+  else if (my_mi == 1) gemm_conv3_vh_body<MODE, 1>(g, m0, n0, nblk, lane, wave);
+  else gemm_conv3_vh_body<MODE, 0>(g, m0, n0, nblk, lane, wave);
 }
 
 // k = 3 convolution (three row-shifted segments of one activation buffer, tap-major weights): shared-slab kernel
