@@ -45,8 +45,8 @@ def test_clvp_oracle_vs_torch(oracle, clvp_models):
 @pytest.mark.gpu
 @pytest.mark.parametrize("which", ["small", "full"])
 def test_clvp_engine_vs_oracle(pkg, oracle, clvp_models, which):
-    """fp16-operand GEMMs with f32 accumulation against the f32 oracle: the score is a cosine x e, tolerance 3e-3 absolute (measured
-    ~1e-4 at depth 2, ~5e-4 at depth 20), and the ranking of candidates whose scores differ by more than that is the oracle's."""
+    """fp16-operand GEMMs with f32 accumulation against the f32 oracle: the score is a cosine x e, tolerance 1e-3 absolute (north star; measured
+    ~1e-4 at depth 2, ~2-5e-4 at depth 20), and the ranking of candidates whose scores differ by more than that is the oracle's."""
     text, sp = _inputs(seed=3, lens=(40, 57, 13, 200, 301, 7) if which == "small" else (60, 187, 200))
     e = pkg.Engine(0)
     e.load_clvp(clvp_models[which])
@@ -55,7 +55,7 @@ def test_clvp_engine_vs_oracle(pkg, oracle, clvp_models, which):
     want = oracle.Clvp(oracle.Model(clvp_models[which])).score(text, sp)
     print("CLVP %s: engine" % which, got, "oracle", want, "max abs diff %.1e" % np.abs(got - want).max())
     assert (got == again).all(), "not deterministic"
-    assert np.abs(got - want).max() < 3e-3
+    assert np.abs(got - want).max() < 1e-3
     order_o = np.argsort(-want)
     if want[order_o[0]] - want[order_o[1]] > 6e-3:
         assert int(np.argmax(got)) == int(order_o[0])

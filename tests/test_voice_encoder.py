@@ -45,7 +45,7 @@ def test_voice_encoder_oracle_vs_torch(oracle, venc_models):
 @pytest.mark.gpu
 @pytest.mark.parametrize("which,lens", [("small", (50, 33, 7)), ("full", (517, 301))])
 def test_voice_encoder_engine_vs_oracle(pkg, oracle, venc_models, which, lens):
-    """fp16-operand GEMMs (f32 accumulate) against the f32 oracle: 3e-3 of the latent's range; deterministic; a clip's contribution does not
+    """fp16-operand GEMMs (f32 accumulate) against the f32 oracle: 1e-3 of the latent's range (north star; measured 3-4e-4); deterministic; a clip's contribution does not
     depend on the other clips (mean of single-clip latents == the multi-clip latent)."""
     mels = _mels(4, lens)
     e = pkg.Engine(0)
@@ -54,7 +54,7 @@ def test_voice_encoder_engine_vs_oracle(pkg, oracle, venc_models, which, lens):
     want = oracle.VoiceEncoder(oracle.Model(venc_models[which])).latent(mels)
     err = float(np.abs(got - want).max() / np.abs(want).max())
     print("voice encoder %s: max err %.1e of range %.2f" % (which, err, np.abs(want).max()))
-    assert np.isfinite(got).all() and err < 3e-3
+    assert np.isfinite(got).all() and err < 1e-3
     assert (got == e.voice_latent(mels)).all()
     singles = np.mean([e.voice_latent([m]).astype(np.float64) for m in mels], axis=0)
     assert np.abs(singles - got).max() < 1e-5 * np.abs(want).max()
@@ -91,7 +91,8 @@ def dcond_models(pkg):
 
 def _mels100(seed, lens):
     rs = np.random.RandomState(seed)
-    return [(rs.randn(100, n) * 1.5 - 2.0).astype(np.float32) for n in lens]
+    # the scale upstream feeds this encoder: UN-normalised log(clamp(mel, 1e-5)) in [-11.51, 2.31] (tts_host_mel_diffusion100(..., normalize = 0))
+    return [np.clip(rs.randn(100, n) * 2.5 - 4.5, -11.512925, 2.3143387).astype(np.float32) for n in lens]
 
 
 def test_diffusion_conditioning_oracle_vs_torch(oracle, dcond_models):
@@ -113,7 +114,7 @@ def test_diffusion_conditioning_engine_vs_oracle(pkg, oracle, dcond_models, whic
     want = oracle.DiffusionConditioning(oracle.Model(dcond_models[which])).latent(mels)
     err = float(np.abs(got - want).max() / np.abs(want).max())
     print("diffusion conditioning %s: max err %.1e of range %.2f" % (which, err, np.abs(want).max()))
-    assert np.isfinite(got).all() and err < 3e-3
+    assert np.isfinite(got).all() and err < 1e-3
     assert (got == e.diffusion_conditioning_latent(mels)).all()
     e.close()
 

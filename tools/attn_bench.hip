@@ -6,6 +6,7 @@
 #include "attn_r3_kernel.h"
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <vector>
 using namespace tts;
@@ -48,8 +49,12 @@ int main() {
     std::vector<__half> a((size_t)(rows + 256) * 1024), b(a.size());
     CK(hipMemcpy(a.data(), out, a.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), out2, b.size() * 2, hipMemcpyDeviceToHost));
     size_t bad = 0, nz = 0;
-    for (size_t i = 0; i < a.size(); i++) { bad += memcmp(&a[i], &b[i], 2) != 0; nz += __half2float(a[i]) != 0.f; }
-    printf("product kernel vs round-3 kernel: %zu of %zu outputs differ (%zu non-zero)\n", bad, a.size(), nz);
+    float worst = 0.f, range = 0.f;
+    for (size_t i = 0; i < a.size(); i++) {
+      bad += memcmp(&a[i], &b[i], 2) != 0; nz += __half2float(a[i]) != 0.f;
+      worst = std::max(worst, fabsf(__half2float(a[i]) - __half2float(b[i]))); range = std::max(range, fabsf(__half2float(b[i])));
+    }
+    printf("product kernel vs round-3 kernel: %zu of %zu outputs differ (%zu non-zero), max abs difference %.2e of range %.2f\n", bad, a.size(), nz, worst, range);
   }
   double us[2][5];
   for (int r = 0; r < 5; r++)
