@@ -423,6 +423,34 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
 #pragma unroll
         for (int e = 0; e < 8; e++)
           pf[i][ks2][e] = (_Float16)__builtin_amdgcn_exp2f(fmaf(sc[i][2 * ks2 + (e >> 2)][e & 3], SC, sub));
+    }
+    ATT_T(5);
+    // O^T += V^T P^T : A = V^T[d = dt*16 + fr][keys 32 ks2 + 8 fq ..+7], B = P^T; row sums: A = ones
+#pragma unroll
+    for (int ks2 = 0; ks2 < 2; ks2++) {
+#pragma unroll
+      for (int dt = 0; dt < 4; dt++) {
+        const half8 vf = *(const half8 *)(Vs + attn_off(dt * 16 + fr, 4 * ks2 + fq));
+#pragma unroll
+        for (int i = 0; i < 2; i++) o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[i][ks2], o[i][dt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++) lacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[i][ks2], lacc[i], 0, 0, 0);
+    }
+    ATT_T(6);
+  };
+  {
+    // tiles [0, a): every key at least 63 before every query of the wave (qw - (kmin + 63) >= 63); [b, ..): at least 63 after (kmin - (qw + 31) >= 63)
+    const int last = (T & 63) ? nkb - 1 : nkb; // the masked tile, if any, is handled on its own
+    const int a = min(max((qw - 126) >= 0 ? (qw - 126) / 64 + 1 : 0, 0), last), b = min((qw + 94 + 63) / 64, last);
+    int kb = 0;
+    for (; kb < a; kb++) tile(kb, std::integral_constant<int, ATT_FAR>{}, ATT_TAB / 2 - 63);
+    for (; kb < b; kb++) tile(kb, std::integral_constant<int, ATT_NEAR>{}, 0);
+    for (; kb < last; kb++) tile(kb, std::integral_constant<int, ATT_FAR>{}, ATT_TAB / 2 + 63);
+    if (last < nkb) tile(last, std::integral_constant<int, ATT_TAIL>{}, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // trailing (clamped) DMA pieces must land before the LDS is released
+  ATT_CLK(1);
   float lrow[2] = {lacc[0][0], lacc[1][0]};
 #pragma unroll
   for (int i = 0; i < 2; i++) {
