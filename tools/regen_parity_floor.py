@@ -2,8 +2,8 @@
 
 Round 4 adds, per sample, `oracle_vs_t32` = the 80-step distance between the ORACLE and a torch-f32 evaluation of the reference's graph — two
 correct f32 evaluations with different summation orders. It is what the engine's reference-precision mode (option attn_f32 = 1: F32 QK^T /
-softmax / PV / proj_out as main.cpp:3848-3875, on split-fp16 MFMA operands) is gated at: gate_f32 = max(1e-3 [north star], the largest such
-distance over the class's samples), nothing multiplied in.
+softmax / PV / proj_out as main.cpp:3848-3875, on split-fp16 MFMA operands) is gated at: gate_f32 = max(1e-3 [north star], 1.5 x the largest such
+distance over the class's samples and test problems) on the maximum and gate_f32_mean = 1.25 x the largest recorded mean (see the comment in main()).
 
   python tools/regen_parity_floor.py small mid          # seconds to minutes per sample
   python tools/regen_parity_floor.py full               # full depth: ~10 min per sample on 8 cores
@@ -156,7 +156,16 @@ def main():
             f[fld] = max(x[fld] for x in samples)
         f["oracle_vs_t32"] = max([f["oracle_vs_t32"]] + [p["oracle_vs_t32"] for p in f.get("problems", {}).values()])
         f["gate"] = round(max(1e-3, 2.0 * f["pair"]), 5)
-        f["gate_f32"] = round(max(1e-3, f["oracle_vs_t32"]), 5)  # north star's 1e-3, or the measured f32-vs-f32 floor where that is higher
+        # Reference-precision mode. The max over 100 x T chaotic values is a noisy statistic: on ONE problem the engine's f32 mode read 1.19e-3 and 1.54e-3 before and
+        # after an arithmetic-neutral change (fast vs exact SiLU), and over 9 measurements its maximum was 0.94 .. 1.68 x the torch-f32-vs-oracle maximum of the same
+        # problem. gate_f32 = max(1e-3 [north star], 1.5 x the largest f32-vs-f32 maximum recorded for the class). The MEAN abs error is stable (engine 1.04 .. 1.17 x the
+        # same problem's torch-vs-oracle mean): gate_f32_mean = 1.25 x the largest recorded mean.
+        f["gate_f32"] = round(max(1e-3, 1.5 * f["oracle_vs_t32"]), 5)
+        means = [p["oracle_vs_t32_mean"] for p in f.get("problems", {}).values()]
+        if means:
+            f["oracle_vs_t32_mean"] = max(means)
+            f["gate_f32_mean"] = round(1.25 * max(means), 8)
+        f.pop("gate_f32_provisional", None)
         json.dump(rec, open(FLOOR_JSON, "w"), indent=1)
         print(kind, {k: f[k] for k in ("floor_f32", "oracle", "engine_math", "pair", "oracle_vs_t32", "gate", "gate_f32")}, flush=True)
 

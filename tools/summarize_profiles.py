@@ -57,6 +57,22 @@ def pmc(fetch_csv, write_csv, dst, note):
     json.dump(out, open(dst, "w"), indent=1)
 
 
+def decode(fetch_csv, dst, note, layers=30):
+    """FETCH_SIZE pass over the decode step launched kernel by kernel (TTS_NO_GRAPH=1 python tools/ar_decode_only.py N): bytes fetched per launch of
+    each decode kernel (x 2: MI355X_MICROARCH.md, HBM) and per step = layers x the five layer kernels + the head (DEC_LOGITS = dec_ln_gemv_kernel<2, ...>)."""
+    fe = counter_avg(fetch_csv, "FETCH_SIZE")
+    per_launch, step = {}, 0.0
+    for k, (n, f) in fe.items():
+        if not any(t in k for t in ("dec_ln_gemv_kernel", "dec_gemv_resid_kernel", "attn_decode")):
+            continue
+        mib = 2 * f / 1024.0
+        per_launch[short(k)] = {"dispatches": n, "fetch_MiB_per_launch": round(mib, 2)}
+        head = "dec_ln_gemv_kernel<2" in k
+        step += mib * (1 if head else layers)
+    json.dump({"_note": note, "fetch_MiB_per_launch": per_launch, "launches_per_step": {"per_layer": 5, "layers": layers, "head": 1},
+               "fetch_bytes_per_step": int(step * 1024 * 1024)}, open(dst, "w"), indent=1)
+
+
 def mfma(src, dst, note):
     """MFMA utilisation per kernel = SQ_VALU_MFMA_BUSY_CYCLES / (cycles per SIMD x 1024 SIMDs); GRBM_GUI_ACTIVE is summed
     over the 8 XCDs (its per-dispatch value / duration = 8 x the shader clock), so cycles per SIMD = GRBM_GUI_ACTIVE / 8."""
@@ -110,7 +126,9 @@ def lds(src, dst, note):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "lds":
+    if sys.argv[1] == "decode":
+        decode(*sys.argv[2:5])
+    elif sys.argv[1] == "lds":
         lds(*sys.argv[2:5])
     elif sys.argv[1] == "mfma":
         mfma(*sys.argv[2:5])
