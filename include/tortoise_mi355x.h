@@ -70,7 +70,14 @@ const char *tts_last_error(const tts_ctx *ctx);
  * TTS_NOISE_DEVICE streams are keyed by the global candidate id — so G ranks x B/G candidates reproduce one rank x B,
  * "stream_cus" (0 default = whole chip; set BEFORE any model is loaded): n > 0 puts this context's stream on the n lowest CUs of every
  * XCD, n < 0 on all but those (hipExtStreamCreateWithCUMask), so that two contexts of one process can split the GPU. Results do not
- * depend on it. Measured use: profiles/r3_stage_overlap_probe.txt (the AR stage does not tolerate a partition; kept as a tool). */
+ * depend on it. Measured use: profiles/r3_stage_overlap_probe.txt (the AR stage does not tolerate a partition; kept as a tool).
+ * "attn_f32" (0 default): 1 = the diffusion stage's AttentionBlock in REFERENCE PRECISION. The reference evaluates QK^T, softmax, PV and proj_out as F32
+ * ggml_mul_mat / ggml_soft_max (main.cpp:3848-3875); the default feeds them to the matrix cores as fp16 operands (the throughput mode). With 1 every one of
+ * those products runs on split-precision fp16 pairs (x = hi + lo, three MFMAs per product, 2^-22 relative) and SiLU is the reference's f32 formula: the
+ * 80-step sampling loop then stays as close to the CPU restatement as a second f32 evaluation of the reference's graph does (tests/golden/parity_floor.json).
+ * Costs about 1.5x the diffusion stage's time; may be switched between calls.
+ * "dec_f32_mfma" (0 default; set BEFORE tts_load_ar): the decode step's LayerNorm-GEMV kernels multiply on v_mfma_f32_16x16x4_f32 (exact f32 products)
+ * instead of split-precision fp16 pairs. */
 int tts_set_option(tts_ctx *ctx, const char *key, double value);
 
 /* ---- weight files (drop-in format: magic 0x67676d6c + name-keyed F32 records) ------------- */
@@ -243,7 +250,9 @@ uint8_t tts_host_fp8_e4m3(float v);
 /* Accumulated device time (ms; HIP event pairs recorded on the ctx stream around every launch, resolved
  * lazily so the timed region is not synchronised) and launch count of the named kernel family since the
  * last reset: "ar_gemv", "ar_attention", "ar_decode_step" (one whole decode-step graph replay; work = bytes streamed), "diff_gemm",
- * "diff_attn", "diff_gn_apply", "voc_lvc", ...
+ * "diff_attn", "diff_gn_fused", "voc_lvc", ... The diffusion GEMM launches are recorded per shape class ("diff_gemm_qkv", "diff_gemm_k3", "diff_gemm_k3r",
+ * "diff_gemm_k1", "diff_gemm_k1r", "diff_gemm_misc"); a family name also names its sub-families, so "diff_gemm" returns their sum
+ * (tts_prof_get) and selects all of them ("prof_only:diff_gemm").
  * The totals cover the BRACKETED launches only: every "prof_stride"-th launch of a family, and — for the "diff_*" families, whose step
  * otherwise replays a captured hipGraph in which an event record would become a node — only the launches of the steps that run eagerly
  * (every "prof_eager_every"-th diffusion step while such a family is selected, 8 by default). ms / launches is therefore a per-launch

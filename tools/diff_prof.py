@@ -19,7 +19,7 @@ for prof in (False, True):
     t0 = time.time(); mels = eng.diffusion(lats, n_steps=steps, noise_mode=pkg.NOISE_DEVICE); t1 = time.time()
     print("diffusion %d steps prof=%s: %.1f ms/step" % (steps, prof, 1e3 * (t1 - t0) / steps))
     if prof:
-        for f in ["diff_gemm", "diff_attn", "diff_gn_fused", "diff_gn_stats", "diff_gn_apply", "diff_update"]:
+        for f in ["diff_gemm", "diff_gemm_k3r", "diff_gemm_qkv", "diff_gemm_k1", "diff_gemm_k1r", "diff_attn", "diff_gn_fused", "diff_gn_stats", "diff_update"]:
             ms, n, w = eng.prof_get(f)
             print("   %-14s %8.2f ms/step %6d launches/step %7.1f us/launch  %s" % (f, ms / steps, n // steps, 1e3 * ms / max(n, 1),
                   ("%.0f TF/s" % (w / (ms * 1e-3) / 1e12)) if w > 0 and ms > 0 else ""))
