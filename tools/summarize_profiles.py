@@ -65,6 +65,8 @@ def decode(fetch_csv, dst, note, layers=30):
     for k, (n, f) in fe.items():
         if not any(t in k for t in ("dec_ln_gemv_kernel", "dec_gemv_resid_kernel", "attn_decode")):
             continue
+        if "attn_decode" not in k and ", true>(" not in k:  # the prompt pass runs the same kernels on the [row][1024] layout (last template flag false): not a decode step
+            continue
         mib = 2 * f / 1024.0
         per_launch[short(k)] = {"dispatches": n, "fetch_MiB_per_launch": round(mib, 2)}
         head = "dec_ln_gemv_kernel<2" in k
