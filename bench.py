@@ -419,7 +419,7 @@ def main():
     # throughput options ar_weights = 1 (fp16: 0.77 GB instead of 1.54 GB of weights per decode step) and 2 (OCP fp8 e4m3 with a
     # power-of-two scale per output column: 0.39 GB), measured beside the default f32 mode on the same prompt and seed:
     # AR stage time, decode-step bandwidth, first sampled id that differs from the f32 run
-    f16 = fp8 = f32_rerun = None
+    f16 = fp8 = f32_rerun = topk = None
     if world == 1 and not a.no_ab and not a.dry_engine:
         eng.seed(4242)
         t0 = time.time()
@@ -432,6 +432,21 @@ def main():
         d32 = np.argwhere(c32[:, 1:1 + S] != c32b[:, 1:1 + S])
         f32_rerun = {"first_divergent_step_vs_first_f32_run": int(d32[:, 1].min()) if len(d32) else None,
                      "candidates_identical_through_all_steps": int((c32[:, 1:1 + S] == c32b[:, 1:1 + S]).all(axis=1).sum())}
+        # option device_topk (default 1: the sampler's top-k runs on the device, lists instead of logits cross PCIe) against 0 (the reference's
+        # full-logits hand-over): same seed -> the codes must be identical; each setting is timed on its second call (the first re-captures the graph)
+        tk = {}
+        for on in (0, 1):
+            eng.set_option("device_topk", on)
+            for rep in range(2):
+                eng.seed(4242)
+                t0 = time.time()
+                ck, _, _, _ = eng.autoregressive(prompts[0], voice, B, S, mask_stop=True)
+                tk[on] = time.time() - t0
+            if on == 0:
+                c_off = ck
+        topk = {"ar_stage_ms_device_topk": round(1e3 * tk[1], 1), "ar_stage_ms_full_logits": round(1e3 * tk[0], 1),
+                "codes_identical": bool((ck == c_off).all() and (ck == c32).all()), "full_row_fallbacks": int(eng.topk_fallbacks()),
+                "d2h_bytes_per_step": {"device_topk": B * 1040, "full_logits": B * 8194 * 4}}
         reports = {}
         for mode, tag in ((1, "f16"), (2, "fp8")):
             e2 = pkg.Engine(device)
@@ -505,6 +520,7 @@ def main():
         "stage_ms_per_step": stages,
         "other_share_uncond_setting": other,
         "ar_f32_default_rerun": f32_rerun,
+        "ar_device_topk_option": topk,
         "ar_weights_f16_option": f16,
         "ar_weights_fp8_option": fp8,
         "reference_precision_option": ref_prec,

@@ -76,6 +76,8 @@ const char *tts_last_error(const tts_ctx *ctx);
  * those products runs on split-precision fp16 pairs (x = hi + lo, three MFMAs per product, 2^-22 relative) and SiLU is the reference's f32 formula: the
  * 80-step sampling loop then stays as close to the CPU restatement as a second f32 evaluation of the reference's graph does (tests/golden/parity_floor.json).
  * Costs about 1.5x the diffusion stage's time; may be switched between calls.
+ * "device_topk" (1 default): tts_autoregressive's decode loop samples from the device prefilter's lists (tts_ar_step_sample); 0 = every step copies
+ * the [B][8194] logits to the host as the reference does (main.cpp:4766-4768). Sampled ids are identical either way.
  * "dec_f32_mfma" (0 default; set BEFORE tts_load_ar): the decode step's LayerNorm-GEMV kernels multiply on v_mfma_f32_16x16x4_f32 (exact f32 products)
  * instead of split-precision fp16 pairs. */
 int tts_set_option(tts_ctx *ctx, const char *key, double value);
@@ -146,6 +148,14 @@ int tts_ar_latents(tts_ctx *ctx, const int32_t *codes502, int n_candidates, int 
  * multinomial (2 draws). */
 int tts_sample(tts_ctx *ctx, const float *logits, const int32_t *penalty_ids, int ids_per_cand,
                int n_candidates, int32_t *samples_out);
+/* One decode step + its sampling in one call = tts_ar_step followed by tts_sample(penalty_ids = prev_ids, ids_per_cand = 1) (main.cpp:5227-5247 +
+ * 4753-4806; flags & TTS_AR_MASK_STOP: logit 8193 forced to -1e30 first), with the sampler's top-k selected on the DEVICE: per candidate only the
+ * 64..128 largest logits cross PCIe (16 KB per step of 16 candidates instead of 524 KB) and the host runs the same float tail over them — the ids
+ * and the RNG consumption are those of the two-call sequence, bit for bit. A candidate whose list cannot decide (ties around the cut, see
+ * host_logic.cpp: sample_one_list) is sampled from its full row, fetched on demand; tts_ar_topk_fallbacks counts those (candidates x steps of the last
+ * tts_ar_step_sample / tts_autoregressive call). tts_autoregressive's loop runs on this path unless option "device_topk" is 0. */
+int tts_ar_step_sample(tts_ctx *ctx, const int32_t *prev_ids, int step_i, unsigned flags, int32_t *samples_out);
+int tts_ar_topk_fallbacks(const tts_ctx *ctx);
 /* The whole autoregressive() driver (main.cpp:5042-5367): prefill, sample/decode loop with the
  * reference's stop rule, apply_padding, latent pass, trim_latents.
  *   flags: TTS_AR_MASK_STOP -> stop token never sampled, exactly max_steps codes (bench workload).
@@ -228,6 +238,11 @@ int tts_host_schedule(int n_steps, int32_t *timestep_map, float *max_log, float 
                       float *sqrt_recipm1, float *coef1, float *coef2);
 void tts_host_timestep_embedding(int t, float *out1024);
 int tts_host_rel_bucket(int query, int key);
+/* The sampler as a pure function of one candidate's row and its used uniform (what tts_sample runs per candidate), and the same decision taken
+ * from a host restatement of the device prefilter's list (the `keep` <= 128 largest logits plus the ties of the smallest): the sampled id, or -1
+ * where the engine would fetch the full row. For tests of the list logic without a GPU. */
+int tts_host_sample_row(const float *row8194, const int32_t *penalty_ids, int n_ids, float uniform);
+int tts_host_sample_prefiltered(const float *row8194, const int32_t *penalty_ids, int n_ids, float uniform, int keep);
 int tts_host_pad_codes(const int32_t *codes, int n, int32_t *out502);
 int tts_host_trimmed_rows(const int32_t *codes502);
 /* Mel front-end of the two voice-conditioning encoders (host arithmetic, f64 inside; no counterpart in the reference, which has no audio input):

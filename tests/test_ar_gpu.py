@@ -222,3 +222,97 @@ def test_maximum_sizes(engine, oracle, small_models, voice):
     lg, lo = engine.ar_latents(codes, 502), ar.latents(codes, 502)
     assert lg.shape == lo.shape == (B, 500, 1024)
     assert rel_err(lg, lo) < 1e-4
+
+
+def _prompt_ids(toks, B):
+    return np.tile(np.array([1] * (len(toks) + 1) + [8192], np.int32), (B, 1))
+
+
+def _sampled_run(engine, toks, voice, B, S, seed, mask, fused):
+    """The decode loop spelled with the stepwise ABI. fused(i) -> True: tts_ar_step_sample (device top-k), False: tts_ar_step + tts_sample."""
+    engine.seed(seed)
+    engine.ar_begin(toks, voice, B, S)
+    lg = engine.ar_prefill()
+    if mask:
+        lg[:, 8193] = -1e30
+    s = engine.sample(lg, _prompt_ids(toks, B))
+    out, fb = [s], 0
+    for i in range(S - 1):
+        if fused(i):
+            s = engine.ar_step_sample(s, i, mask_stop=mask)
+            fb += engine.topk_fallbacks()
+        else:
+            lg = engine.ar_step(s, i)
+            if mask:
+                lg[:, 8193] = -1e30
+            s = engine.sample(lg, s.reshape(B, 1))
+        out.append(s)
+    return np.stack(out), engine.rng_uniform(), fb
+
+
+@pytest.mark.parametrize("B,mask", [(16, True), (16, False), (3, False), (1, True)])
+def test_device_topk_step_is_step_then_sample(engine, small_models, voice, B, mask):
+    """tts_ar_step_sample (the sampler's top-k selected by sample_prefilter_kernel, 64..128 logits per candidate cross PCIe) returns exactly what
+    tts_ar_step + tts_sample return from the full rows: same ids, same RNG position; also when the two step graphs alternate."""
+    engine.load(ar=small_models + "/ggml-model.bin")
+    toks, S, seed = DEFAULT_TOKENS, 28, 4242 + B
+    want, u_want, _ = _sampled_run(engine, toks, voice, B, S, seed, mask, lambda i: False)
+    got, u_got, fb = _sampled_run(engine, toks, voice, B, S, seed, mask, lambda i: True)
+    assert (got == want).all() and u_got == u_want
+    assert fb == 0  # continuous logits: no list ever needed its full row
+    mixed, u_mixed, _ = _sampled_run(engine, toks, voice, B, S, seed, mask, lambda i: i % 3 != 1)
+    assert (mixed == want).all() and u_mixed == u_want
+    if mask:
+        assert (got != 8193).all()
+
+
+@pytest.mark.parametrize("kind", ["all_equal", "coarse", "sparse_ties"])
+def test_device_topk_falls_back_to_the_full_row_on_ties(pkg, engine, small_models, voice, tmp_path, kind):
+    """A head whose logits tie: the prefilter finds no threshold keeping 64..128 of them (all_equal, coarse) or the survivors tie (sparse_ties), the
+    host fetches the rows it cannot decide and still returns the ids of the two-call path."""
+    from tortoise_cpp_amd import synth_weights as SW
+    t = SW.read_ggml(small_models + "/ggml-model.bin")
+    rs = np.random.RandomState(3)
+    t["inference_model.lm_head.1.weight"][:] = 0
+    bias = {"all_equal": np.zeros(8194), "coarse": np.round(rs.randn(8194) * 2), "sparse_ties": np.round(rs.randn(8194) * 300) / 16}[kind]
+    t["inference_model.lm_head.1.bias"][:] = bias.astype(np.float32)
+    path = str(tmp_path / "ar_ties.bin")
+    w = SW.GgmlWriter(path)
+    for name, arr in t.items():
+        w.add(name, arr)
+    w.close()
+    eng = engine
+    eng.load(ar=path)
+    toks, B, S = DEFAULT_TOKENS, 4, 5
+    want, u_want, _ = _sampled_run(eng, toks, voice, B, S, 11, False, lambda i: False)
+    got, u_got, fb = _sampled_run(eng, toks, voice, B, S, 11, False, lambda i: True)
+    assert (got == want).all() and u_got == u_want
+    if kind != "sparse_ties":
+        assert fb == B * (S - 1)  # every list was refused
+    print("%s: %d of %d candidate-steps sampled from their full row" % (kind, fb, B * (S - 1)))
+
+
+@pytest.mark.parametrize("flags", [dict(mask_stop=True), dict(retire=True), dict()])
+def test_autoregressive_driver_device_topk_on_off(pkg, engine, small_models, voice, flags):
+    """Option device_topk only moves the top-k selection onto the device: codes, rows, latents and the RNG position of tts_autoregressive do not change."""
+    engine.load(ar=small_models + "/ggml-model.bin")
+    toks, B, S = DEFAULT_TOKENS, 16, 48
+    res = []
+    for on in (1, 0):
+        engine.set_option("device_topk", on)
+        engine.seed(77)
+        try:
+            codes, rows, lats, steps = engine.autoregressive(toks, voice, B, S, **flags)
+        except pkg.TtsError as e:  # strict mode may legitimately run out of steps: then both modes must
+            res.append(("err", str(e)))
+            continue
+        res.append((codes, rows, lats, steps, engine.rng_uniform(), engine.topk_fallbacks()))
+    engine.set_option("device_topk", 1)
+    failed = [isinstance(r[0], str) for r in res]
+    if any(failed):
+        assert all(failed), res
+        return
+    assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all() and res[0][3] == res[1][3] and res[0][4] == res[1][4]
+    for a, b in zip(res[0][2], res[1][2]):
+        assert np.array_equal(a, b)
+    assert res[0][5] == 0

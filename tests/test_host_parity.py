@@ -121,6 +121,54 @@ def test_sampler_fuzz_vs_reference(host, oracle):
         assert host.rng_uniform() == R.ref_uniform()
 
 
+def test_sampler_from_prefiltered_list_equals_full_row(pkg, host):
+    """Option device_topk (tts_ar_step_sample): the decode step hands the host only each candidate's 64..128 largest logits. Whatever the list decides
+    must be what the full row decides; where it cannot know (ties among the survivors, the cut within 4 ulps of the list's smallest entry) it must say
+    so (-1 -> the engine fetches the row) instead of guessing."""
+    rs = np.random.RandomState(7)
+    undecided = decided = 0
+    for trial in range(400):
+        scale = rs.choice([0.3, 1.0, 3.0, 8.0])
+        row = (rs.randn(8194) * scale).astype(np.float32)
+        kind = trial % 8
+        if kind == 1:  # coarse values: ties everywhere, also across the threshold
+            row = np.round(row * 4) / 4
+        elif kind == 2:  # the logits around the top-k cut are consecutive floats: the 4-ulp window of sample_one reaches below the list
+            order = np.argsort(-row)
+            v = row[order[40]]
+            for r in range(41, 75):
+                v = np.nextafter(v, np.float32(-np.inf))
+                row[order[r]] = v
+        elif kind == 3:  # mostly negative rows (penalty = x * 2), zeros of both signs
+            row = -np.abs(row)
+            row[rs.randint(0, 8194, 40)] = 0.0
+            row[rs.randint(0, 8194, 40)] = -0.0
+        order = np.argsort(-row)
+        pick = rs.randint(5)
+        ids = [[order[0]], [order[rs.randint(50)]], [order[49], order[50]], [rs.randint(8194)], list(order[rs.randint(0, 60, 4)])][pick]
+        if trial % 50 == 49:
+            ids = list(order[:6])  # more than four distinct penalty ids: only the literal path knows
+        u = 0.0 if trial % 37 == 0 else float(rs.rand())
+        keep = int(rs.choice([54, 64, 64, 100, 128]))
+        want = pkg.host_sample_row(row, ids, u)
+        got = pkg.host_sample_prefiltered(row, ids, u, keep)
+        assert got in (want, -1), (trial, kind, keep, got, want)
+        if kind in (0, 4, 5, 6, 7) and len(set(ids)) <= 4 and keep >= 64:
+            assert got == want, (trial, kind, keep)  # continuous random logits, the device's list sizes: the list always decides
+            # (keep = 54 with four penalised top logits puts the 50th survivor AT the list's end: undecidable by design)
+        undecided += got == -1
+        decided += got == want
+        # the pure function is the sampler tts_sample runs: same id from the ctx RNG's second uniform
+        if trial % 10 == 0:
+            host.seed(trial)
+            ref = host.sample(row[None], np.asarray(ids, np.int32)[None])[0]
+            host.seed(trial)
+            host.rng_uniform()
+            assert pkg.host_sample_row(row, ids, host.rng_uniform()) == ref
+    assert decided > 200 and undecided > 50, (decided, undecided)  # both branches were exercised
+    assert pkg.host_sample_prefiltered(np.zeros(8194, np.float32), [0], 0.5, 64) == -1  # 8194-way tie: no list
+
+
 def test_schedule_scalars_golden_and_oracle(pkg, oracle):
     """The diffusion driver's schedule arithmetic (host_logic.cpp: DiffSchedule) against the committed golden vectors of
     the reference's own code (80 steps) and against the oracle for other step counts (SURVEY 8d config 5 uses 200)."""

@@ -59,6 +59,8 @@ def lib():
         "tts_ar_begin": (ci, [vp, _i32p, ci, _f32p, ci, ci]), "tts_ar_prefill": (ci, [vp, _f32p]),
         "tts_ar_step": (ci, [vp, _i32p, ci, _f32p]), "tts_ar_latents": (ci, [vp, _i32p, ci, ci, _f32p]),
         "tts_sample": (ci, [vp, _f32p, _i32p, ci, ci, _i32p]),
+        "tts_ar_step_sample": (ci, [vp, _i32p, ci, C.c_uint, _i32p]), "tts_ar_topk_fallbacks": (ci, [vp]),
+        "tts_host_sample_row": (ci, [_f32p, _i32p, ci, cf]), "tts_host_sample_prefiltered": (ci, [_f32p, _i32p, ci, cf, ci]),
         "tts_autoregressive": (ci, [vp, _i32p, ci, _f32p, ci, ci, C.c_uint, _i32p, _i32p, vp, _i32p]),
         "tts_ar_stop_status": (ci, [vp, _i32p, ci]),
         "tts_diffusion_frames": (ci, [ci]),
@@ -175,6 +177,15 @@ class Engine:
         out = np.empty((self.B, VOCAB_MEL), np.float32)
         self._ck(self.L.tts_ar_step(self.h, np.ascontiguousarray(prev_ids, np.int32), i, out.reshape(-1)))
         return out
+
+    def ar_step_sample(self, prev_ids, i, mask_stop=False):
+        """tts_ar_step + tts_sample(penalty ids = prev_ids) with the sampler's top-k selected on the device."""
+        out = np.empty(self.B, np.int32)
+        self._ck(self.L.tts_ar_step_sample(self.h, np.ascontiguousarray(prev_ids, np.int32), i, 1 if mask_stop else 0, out))
+        return out
+
+    def topk_fallbacks(self):
+        return self.L.tts_ar_topk_fallbacks(self.h)
 
     def ar_latents(self, codes502, n_mel=502):
         codes502 = np.ascontiguousarray(codes502, np.int32).reshape(-1, 502)
@@ -337,6 +348,19 @@ def host_timestep_embedding(t):
     out = np.empty(1024, np.float32)
     lib().tts_host_timestep_embedding(int(t), out)
     return out
+
+
+def host_sample_row(row, ids, uniform):
+    """The sampler's pure per-candidate function on a full logits row (host_logic.cpp: sample_one)."""
+    ids = np.ascontiguousarray(ids, np.int32)
+    return lib().tts_host_sample_row(np.ascontiguousarray(row, np.float32), ids, len(ids), float(uniform))
+
+
+def host_sample_prefiltered(row, ids, uniform, keep=64):
+    """The same from a host restatement of the device prefilter's list (the `keep` largest logits + ties of the smallest). -1: the list
+    cannot decide and the engine would fetch the full row."""
+    ids = np.ascontiguousarray(ids, np.int32)
+    return lib().tts_host_sample_prefiltered(np.ascontiguousarray(row, np.float32), ids, len(ids), float(uniform), keep)
 
 
 def host_rel_buckets(n):

@@ -8,7 +8,10 @@
 namespace tts {
 int ar_begin(tts_ctx *, const int32_t *, int, const float *, int, int);
 int ar_prefill(tts_ctx *, float *);
-int ar_step(tts_ctx *, const int32_t *, int, float *);
+int ar_step(tts_ctx *, const int32_t *, int, float *, int mode);
+const int32_t *ar_host_lists(tts_ctx *);
+const float *ar_fetch_logits_row(tts_ctx *, int);
+int ar_batch(const tts_ctx *);
 int ar_latents(tts_ctx *, const int32_t *, int, int, float *);
 int ar_layers(const tts_ctx *);
 float *ar_host_logits(tts_ctx *);
@@ -102,6 +105,7 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
     if (value != 0) c->prof_filter.push_back(k.substr(10));
     else c->prof_filter.clear();
   }
+  else if (k == "device_topk") c->device_topk = value != 0; // 1 default: see tts_ar_step_sample
   else if (k == "sampler_threads") { // worker threads for the per-candidate sampler scans (0 = run them on the caller)
     if (c->sampler_pool) { sampler_pool_free(c->sampler_pool); c->sampler_pool = nullptr; }
     c->sampler_threads = value < 0 ? -1 : (int)value;
@@ -239,7 +243,35 @@ int tts_ar_begin(tts_ctx *c, const int32_t *ids, int n, const float *voice, int 
 int tts_ar_prefill(tts_ctx *c, float *logits) { NEED_CTX(c); return guarded(c, [&] { return ar_prefill(c, logits); }); }
 int tts_ar_step(tts_ctx *c, const int32_t *prev, int i, float *logits) {
   NEED_CTX(c);
-  return guarded(c, [&] { return ar_step(c, prev, i, logits); });
+  return guarded(c, [&] { return ar_step(c, prev, i, logits, 0); });
+}
+// decode step + sampler in one call: the device prefilter's lists cross PCIe instead of the logits (ar.hip: sample_prefilter_kernel)
+static int step_sample(tts_ctx *c, const int32_t *prev, int i, bool mask_stop, int32_t *out, int *fallbacks) {
+  if (int rc = ar_step(c, prev, i, nullptr, mask_stop ? 2 : 1)) return rc;
+  const int B = ar_batch(c);
+  if (sample_candidates_list(c, ar_host_lists(c), prev, 1, B, out, [&](int b) { return ar_fetch_logits_row(c, b); }, fallbacks))
+    return fail(c, TTS_ERR_HIP, "tts_ar_step_sample: fetching a logits row failed");
+  return TTS_OK;
+}
+int tts_ar_step_sample(tts_ctx *c, const int32_t *prev, int i, unsigned flags, int32_t *samples_out) {
+  NEED_CTX(c);
+  if (!prev || !samples_out) return TTS_ERR_ARG;
+  return guarded(c, [&] {
+    if (int rc = shard_check(c, ar_batch(c))) return rc;
+    c->topk_fallbacks = 0;
+    return step_sample(c, prev, i, (flags & TTS_AR_MASK_STOP) != 0, samples_out, &c->topk_fallbacks);
+  });
+}
+int tts_ar_topk_fallbacks(const tts_ctx *c) { return c ? c->topk_fallbacks : -1; }
+int tts_host_sample_row(const float *row, const int32_t *ids, int ids_per_cand, float uniform) {
+  if (!row || !ids || ids_per_cand < 1) return -1;
+  return sample_one_row(row, ids, ids_per_cand, uniform);
+}
+int tts_host_sample_prefiltered(const float *row, const int32_t *ids, int ids_per_cand, float uniform, int keep) {
+  if (!row || !ids || ids_per_cand < 1 || keep < 1 || keep > TTS_PF_MAX) return -2;
+  std::vector<int32_t> list(TTS_PF_WORDS);
+  if (host_prefilter_row(row, keep, list.data()) < 0) return -1;
+  return sample_one_from_list(list.data(), ids, ids_per_cand, uniform);
 }
 int tts_ar_latents(tts_ctx *c, const int32_t *codes, int nb, int n_mel, float *out) {
   NEED_CTX(c);
@@ -286,13 +318,19 @@ static int autoregressive_impl(tts_ctx *c, const int32_t *text_ids, int n_text, 
   const bool retire = (flags & TTS_AR_RETIRE) != 0;
   if ((rc = shard_check(c, B))) return rc;
   std::vector<char> done(B, 0);
+  std::vector<int32_t> next; // the samples of the coming iteration when the device-top-k step already produced them
+  bool have_next = false;
+  c->topk_fallbacks = 0;
   int i = 0;
   for (;;) {
-    if (flags & TTS_AR_MASK_STOP)
-      for (int b = 0; b < B; b++) logits[(size_t)b * V + 8193] = -1e30f;
     double t0 = now();
-    sample_candidates(c, logits, ids.data(), ids_per_cand, B, samples.data());
-    t_sample += now() - t0;
+    if (have_next) { samples = next; have_next = false; }
+    else {
+      if (flags & TTS_AR_MASK_STOP)
+        for (int b = 0; b < B; b++) logits[(size_t)b * V + 8193] = -1e30f;
+      sample_candidates(c, logits, ids.data(), ids_per_cand, B, samples.data());
+      t_sample += now() - t0;
+    }
     int stops = 0;
     for (int b = 0; b < B; b++) {
       if (retire && done[b]) { samples[b] = 8193; stops++; continue; }
@@ -308,9 +346,21 @@ static int autoregressive_impl(tts_ctx *c, const int32_t *text_ids, int n_text, 
       return fail(c, TTS_ERR_LIMIT, "no stop token within %d steps", max_steps);
     }
     t0 = now();
-    if ((rc = ar_step(c, samples.data(), i - 1, nullptr))) return rc;
-    logits = ar_host_logits(c);
+    if (!c->device_topk) {
+      if ((rc = ar_step(c, samples.data(), i - 1, nullptr, 0))) return rc;
+      logits = ar_host_logits(c);
+      t_step += now() - t0;
+      continue;
+    }
+    // device top-k: the step hands back each candidate's ~64..128 largest logits and the sampler runs on those (same uniforms, same ids)
+    if ((rc = ar_step(c, samples.data(), i - 1, nullptr, (flags & TTS_AR_MASK_STOP) ? 2 : 1))) return rc;
     t_step += now() - t0;
+    t0 = now();
+    next.resize(B);
+    if (sample_candidates_list(c, ar_host_lists(c), ids.data(), 1, B, next.data(), [&](int b) { return ar_fetch_logits_row(c, b); }, &c->topk_fallbacks))
+      return fail(c, TTS_ERR_HIP, "tts_autoregressive: fetching a logits row failed");
+    t_sample += now() - t0;
+    have_next = true;
   }
   const double t_after_loop = now();
   if (steps_out) *steps_out = i;

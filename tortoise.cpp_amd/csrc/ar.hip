@@ -952,6 +952,80 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const float *__restric
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Device top-k prefilter (option "device_topk"): the sampler (process_logits_and_sample, main.cpp:4753-4806) keeps the 50 largest
+// penalised logits of 8194. Instead of 16 x 8194 floats per step crossing PCIe, every candidate's row is reduced on the device to the
+// logits >= a threshold that keeps TTS_PF_MIN .. TTS_PF_MAX of them, in index order; the host runs the bit-exact float tail over that
+// list (host_logic.cpp: sample_one_list, which also states why the list is sufficient and when the full row is fetched instead).
+// One workgroup per candidate, 33 logits per thread in registers as order-preserving integer keys; the threshold is found by bisection
+// on the key (one ballot-popcount pass over the registers + one barrier per probe, <= 32 probes), then an index-ordered compaction.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned pf_key(float v) {
+  unsigned u = __float_as_uint(v);
+  if (u == 0x80000000u) u = 0; // -0 and +0 compare equal as floats: one key
+  return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void sample_prefilter_kernel(const float *__restrict__ logits, int mask_stop, int32_t *__restrict__ out) {
+  constexpr int NJ = (V + 255) / 256; // 33
+  __shared__ int red[2][4];
+  __shared__ int4 tab[NJ];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *src = logits + (size_t)c * V;
+  int32_t *o = out + (size_t)c * TTS_PF_WORDS;
+  unsigned key[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const int i = j * 256 + tid;
+    float v = i < V ? src[i] : 0.f;
+    if (mask_stop && i == V - 1) v = -1e30f; // TTS_AR_MASK_STOP: the stop token 8193 is never sampled
+    key[j] = i < V ? pf_key(v) : 0u;          // padding: key 0 is below every probe (probes are > 0)
+  }
+  unsigned lo = 0u, hi = 0xffffffffu, t = 0u; // count(lo) > PF_MAX, count(hi) < PF_MIN
+  int n = -1, it = 0;
+  while (hi - lo > 1u) {
+    const unsigned mid = lo + ((hi - lo) >> 1);
+    int cw = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) cw += __popcll(__ballot(key[j] >= mid));
+    if (lane == 0) red[it & 1][wave] = cw;
+    __syncthreads(); // double-buffered: one barrier per probe
+    const int cnt = red[it & 1][0] + red[it & 1][1] + red[it & 1][2] + red[it & 1][3];
+    it++;
+    if (cnt > TTS_PF_MAX) lo = mid;
+    else if (cnt < TTS_PF_MIN) hi = mid;
+    else { n = cnt; t = mid; break; }
+  }
+  if (n < 0) { // more than PF_MAX - PF_MIN + 1 logits tie at the 64th place: the host takes the full row
+    if (tid == 0) o[0] = -1;
+    return;
+  }
+  const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const int cw = __popcll(__ballot(key[j] >= t));
+    if (lane == 0) ((int *)&tab[j])[wave] = cw;
+  }
+  __syncthreads();
+  int base = 0;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const int4 r = tab[j];
+    const unsigned long long m = __ballot(key[j] >= t);
+    if (key[j] >= t) {
+      const int i = j * 256 + tid;
+      const int pos = base + (wave > 0 ? r.x : 0) + (wave > 1 ? r.y : 0) + (wave > 2 ? r.z : 0) + __popcll(m & below);
+      float v = src[i];
+      if (mask_stop && i == V - 1) v = -1e30f;
+      o[4 + pos] = i;
+      o[4 + TTS_PF_MAX + pos] = __float_as_int(v);
+    }
+    base += r.x + r.y + r.z + r.w;
+  }
+  if (tid == 0) { o[0] = n; o[1] = 0; o[2] = 0; o[3] = 0; }
+}
+
+
 struct ArLayerDev {
   float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
   float *w_attn, *b_attn, *w_proj, *b_proj, *w_fc, *b_fc, *w_fc2, *b_fc2;
@@ -989,22 +1063,25 @@ struct ArState {
   DevBuf d_toks;
   int32_t *h_toks = nullptr;   // pinned
   float *h_logits = nullptr;   // pinned [B][8194]
+  int32_t *h_pf = nullptr;     // pinned [B][TTS_PF_WORDS]: the device prefilter's lists (step_mode != 0)
+  DevBuf pf;
+  int step_mode = 0;           // what the step hands to the host: 0 = the logits, 1 = the prefilter's lists, 2 = lists with the stop token masked
   int h_cap_B = 0;             // candidates the pinned buffers were sized for
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   // everything the captured step bakes into its nodes: the graph of the previous utterance is replayed when nothing moved
   struct GraphSig {
-    int B = 0, max_pos = 0, lut = 0, wmode = 0;
-    const void *p[10] = {};
+    int B = 0, max_pos = 0, lut = 0, wmode = 0, mode = 0;
+    const void *p[12] = {};
     bool operator==(const GraphSig &o) const {
-      return B == o.B && max_pos == o.max_pos && lut == o.lut && wmode == o.wmode && std::equal(p, p + 10, o.p);
+      return B == o.B && max_pos == o.max_pos && lut == o.lut && wmode == o.wmode && mode == o.mode && std::equal(p, p + 12, o.p);
     }
   } graph_sig;
   GraphSig current_sig(int lut, int wmode) const {
     GraphSig g;
-    g.B = B; g.max_pos = max_pos; g.lut = lut; g.wmode = wmode;
-    const void *q[10] = {h.p, qkv.p, att.p, ff.p, kcache.p, vcache.p, d_toks.p, logits.p, h_toks, h_logits};
-    std::copy(q, q + 10, g.p);
+    g.B = B; g.max_pos = max_pos; g.lut = lut; g.wmode = wmode; g.mode = step_mode;
+    const void *q[12] = {h.p, qkv.p, att.p, ff.p, kcache.p, vcache.p, d_toks.p, logits.p, h_toks, h_logits, pf.p, h_pf};
+    std::copy(q, q + 12, g.p);
     return g;
   }
   void drop_graph() {
@@ -1016,6 +1093,7 @@ struct ArState {
     drop_graph();
     if (h_toks) (void)hipHostFree(h_toks);
     if (h_logits) (void)hipHostFree(h_logits);
+    if (h_pf) (void)hipHostFree(h_pf);
     for (void *p : owned) (void)hipFree(p);
   }
 };
@@ -1489,12 +1567,15 @@ int ar_begin(tts_ctx *ctx, const int32_t *text_ids, int n_text, const float *voi
   TTS_HIP(ctx, st->vcache.reserve(cache));
   TTS_HIP(ctx, st->d_toks.reserve((size_t)(B + 2) * 4)); // [tokens | n_past, pos_id]
   TTS_HIP(ctx, st->logits.reserve((size_t)B * V * 4));
+  TTS_HIP(ctx, st->pf.reserve((size_t)B * TTS_PF_WORDS * 4));
   if (B > st->h_cap_B) { // pinned allocations are slow (milliseconds): keep them across utterances
     if (st->h_toks) (void)hipHostFree(st->h_toks);
     if (st->h_logits) (void)hipHostFree(st->h_logits);
-    st->h_toks = nullptr; st->h_logits = nullptr; st->h_cap_B = 0;
+    if (st->h_pf) (void)hipHostFree(st->h_pf);
+    st->h_toks = nullptr; st->h_logits = nullptr; st->h_pf = nullptr; st->h_cap_B = 0;
     TTS_HIP(ctx, hipHostMalloc((void **)&st->h_toks, (size_t)(B + 2) * 4));
     TTS_HIP(ctx, hipHostMalloc((void **)&st->h_logits, (size_t)B * V * 4));
+    TTS_HIP(ctx, hipHostMalloc((void **)&st->h_pf, (size_t)B * TTS_PF_WORDS * 4));
     st->h_cap_B = B;
   }
   // the decode-step graph is kept: ar_step re-captures it only if a buffer moved or the batch shape changed (GraphSig)
@@ -1598,15 +1679,25 @@ static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
     if (wm == 2) dec_ln_gemv_kernel<DEC_LOGITS, 3, true, true><<<dim3(VPAD / 16, tiles), 256, 0, ctx->stream>>>(a);
     else if (wm == 1) dec_ln_gemv_kernel<DEC_LOGITS, 2, false, true><<<dim3(VPAD / 16, tiles), 256, 0, ctx->stream>>>(a);
     else DEC_LN_LAUNCH(DEC_LOGITS, dim3(VPAD / 16, tiles), true); }
-  TTS_HIP(ctx, hipMemcpyAsync(st->h_logits, st->logits.p, (size_t)B * V * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (st->step_mode == 0) {
+    TTS_HIP(ctx, hipMemcpyAsync(st->h_logits, st->logits.p, (size_t)B * V * 4, hipMemcpyDeviceToHost, ctx->stream));
+  } else { // the sampler's top-k prefilter on the device: 16 KB instead of 524 KB back to the host per step of 16 candidates
+    ProfScope ps(ctx, "ar_prefilter", (double)B * V * 4.0);
+    sample_prefilter_kernel<<<B, 256, 0, ctx->stream>>>(st->logits.as<float>(), st->step_mode == 2, st->pf.as<int32_t>());
+    TTS_HIP(ctx, hipMemcpyAsync(st->h_pf, st->pf.p, (size_t)B * TTS_PF_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
   TTS_HIP(ctx, hipGetLastError());
   return TTS_OK;
 }
 
 // Decode step i (main.cpp:2667-2693, 5227-5247): mel_emb[tok] + mel_pos[i+2], n_past = P + i.
-int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out) {
+// mode 0: the logits come back ([B][8194], logits_out may be null: ar_host_logits); mode 1 / 2: the device prefilter's lists come back
+// instead (ar_host_lists; 2 = stop token masked first) and the logits stay in HBM (ar_fetch_logits_row). Each mode is its own graph.
+int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out, int mode) {
   ArState *st = ctx->ar;
   if (!st || st->B == 0) return fail(ctx, TTS_ERR_STATE, "tts_ar_begin not called");
+  if (mode < 0 || mode > 2 || (mode && logits_out)) return fail(ctx, TTS_ERR_ARG, "ar_step: bad mode");
+  st->step_mode = mode;
   if (step_i < 0 || st->P + step_i >= st->max_pos) return fail(ctx, TTS_ERR_LIMIT, "step %d beyond the KV cache", step_i);
   for (int c = 0; c < st->B; c++) {
     if (prev_ids[c] < 0 || prev_ids[c] >= V) return fail(ctx, TTS_ERR_ARG, "mel token %d out of range", prev_ids[c]);
@@ -1645,6 +1736,20 @@ int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out
   TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (logits_out) memcpy(logits_out, st->h_logits, (size_t)st->B * V * 4);
   return TTS_OK;
+}
+
+// The pinned lists of the last mode 1 / 2 step ([B][TTS_PF_WORDS]).
+const int32_t *ar_host_lists(tts_ctx *ctx) { return ctx->ar ? ctx->ar->h_pf : nullptr; }
+
+// One candidate's logits of the last step, from HBM (the sampler's fallback when a list cannot decide). Returns the pinned row or null.
+const float *ar_fetch_logits_row(tts_ctx *ctx, int c) {
+  ArState *st = ctx->ar;
+  if (!st || c < 0 || c >= st->B) return nullptr;
+  float *dst = st->h_logits + (size_t)c * V;
+  if (hipMemcpyAsync(dst, st->logits.as<float>() + (size_t)c * V, (size_t)V * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return nullptr;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return nullptr;
+  if (st->step_mode == 2) dst[V - 1] = -1e30f;
+  return dst;
 }
 
 // Latent pass (main.cpp:2053-2519, 5280-5352): full causal forward without the decode cache.
@@ -1701,6 +1806,7 @@ int ar_latents(tts_ctx *ctx, const int32_t *codes502, int nb, int n_mel, float *
 }
 
 int ar_layers(const tts_ctx *ctx) { return ctx->ar ? ctx->ar->n_layers : 0; }
+int ar_batch(const tts_ctx *ctx) { return ctx->ar ? ctx->ar->B : 0; }
 
 // The pinned buffer the decode graph copies the logits into ([B][8194]); valid after ar_step returns.
 float *ar_host_logits(tts_ctx *ctx) { return ctx->ar ? ctx->ar->h_logits : nullptr; }

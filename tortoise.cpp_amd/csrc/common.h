@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <random>
@@ -83,6 +84,8 @@ struct tts_ctx {
   tts::DiffCondEncState *dcond = nullptr; // diffusion conditioning encoder (extras.hip; not in the reference)
   tts::Tokenizer *tok = nullptr;
   tts::SamplerPool *sampler_pool = nullptr; // worker threads for the per-candidate sampler scans (host_logic.cpp)
+  int device_topk = 1;                      // option "device_topk": tts_autoregressive's loop samples from the device prefilter's lists
+  int topk_fallbacks = 0;                   // candidates x steps of the last tts_autoregressive call that needed their full row
   int sampler_threads = -1;                 // -1: min(7, hardware threads - 1); option "sampler_threads"
   bool share_uncond = true;                 // option "share_uncond": see DiffState::share_integ (diffusion.hip)
   // candidate-parallel sharding: this context runs candidates [rng_shard_offset, +B) of a batch of rng_shard_total
@@ -163,6 +166,15 @@ struct Tokenizer {
 };
 void sample_candidates(tts_ctx *ctx, const float *logits, const int32_t *ids, int ids_per_cand, int B,
                        int32_t *out);
+// Device top-k prefilter of the decode step (ar.hip: sample_prefilter_kernel; option "device_topk"): per candidate TTS_PF_WORDS
+// 32-bit words {n, 0, 0, 0, idx[TTS_PF_MAX], logit bits[TTS_PF_MAX]} = every logit >= a threshold that keeps TTS_PF_MIN..TTS_PF_MAX
+// of the 8194, in index order (n = -1: no such threshold, the host samples from the full row).
+enum { TTS_PF_MIN = 64, TTS_PF_MAX = 128, TTS_PF_WORDS = 4 + 2 * TTS_PF_MAX };
+int sample_candidates_list(tts_ctx *ctx, const int32_t *lists, const int32_t *ids, int ids_per_cand, int B, int32_t *out,
+                           const std::function<const float *(int)> &full_row, int *n_fallbacks);
+int host_prefilter_row(const float *row, int keep, int32_t *list);
+int sample_one_row(const float *row, const int32_t *ids, int ids_per_cand, float uniform);
+int sample_one_from_list(const int32_t *list, const int32_t *ids, int ids_per_cand, float uniform);
 void pad_codes(std::vector<int> &codes);            // apply_padding
 int trimmed_latent_rows(const int32_t *codes502);   // trim_latents row count
 struct DiffSchedule {

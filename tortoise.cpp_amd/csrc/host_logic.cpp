@@ -202,12 +202,44 @@ static int multinomial_literal(std::vector<float> &l, float sample) {
   return V - 1;
 }
 
+struct Surv { float v; int idx; float e; };
+
+// Tail shared by the full-row scan and the device-prefiltered list: `s` = the top-k survivors in INDEX order with their tempered
+// values. top-p over the ascending order, final softmax + multinomial in index order. Returns -1 when two survivors tie (the
+// caller falls back to the literal formulation to inherit std::sort's tie order).
+static int sample_survivors(std::vector<Surv> &s, std::vector<Surv> &asc, float sample) {
+  const int V = TTS_VOCAB_MEL;
+  const float LOWEST = std::numeric_limits<float>::lowest();
+  asc = s;
+  std::sort(asc.begin(), asc.end(), [](const Surv &a, const Surv &b) { return a.v < b.v; });
+  for (size_t i = 1; i < asc.size(); i++)
+    if (asc[i].v == asc[i - 1].v) return -1;
+  // top-p over the ascending survivors (non-survivors contribute exp(lowest) = +0)
+  float sum = 0;
+  for (auto &a : asc) { a.e = exp_like_reference(a.v); sum += a.e; }
+  float cum = 0;
+  for (size_t i = 0; i < asc.size(); i++) {
+    cum += asc[i].e / sum;
+    if (i + 1 < asc.size() && cum <= 0.2)
+      for (auto &b : s) if (b.idx == asc[i].idx) b.v = LOWEST; // cut
+  }
+  // final softmax + multinomial in index order
+  sum = 0;
+  for (auto &a : s) { a.e = (a.v == LOWEST) ? 0.f : exp_like_reference(a.v); sum += a.e; }
+  if (!(0.0f < sample)) return 0; // cumulative(=0) >= sample already at index 0
+  cum = 0;
+  for (auto &a : s) {
+    cum += a.e / sum;
+    if (cum >= sample) return a.idx;
+  }
+  return V - 1;
+}
+
 // One candidate, given its uniform draw: pure function of its arguments (runs on the sampler pool's threads).
 static int sample_one(const float *src, const int32_t *ids, int ids_per_cand, float sample) {
   const int V = TTS_VOCAB_MEL, TOPK = 50;
   const float LOWEST = std::numeric_limits<float>::lowest();
   const float temp = 0.8;
-  struct Surv { float v; int idx; float e; };
   thread_local std::vector<Surv> s, asc;
   thread_local std::vector<float> l; // only materialised for the (rare) literal fallback
   // gather -> apply_penalty(2.0) -> scatter touches at most a few distinct ids (the prompt-shaped
@@ -267,33 +299,58 @@ static int sample_one(const float *src, const int32_t *ids, int ids_per_cand, fl
     const float v = val(i) / temp;
     if (v >= kth) s.push_back({v, i, 0.f});
   }
-  asc = s;
-  std::sort(asc.begin(), asc.end(), [](const Surv &a, const Surv &b) { return a.v < b.v; });
-  bool tie = false;
-  for (size_t i = 1; i < asc.size(); i++) tie |= (asc[i].v == asc[i - 1].v);
-  if (tie) return literal(); // inherit std::sort's tie order from the literal formulation
-  // top-p over the ascending survivors (non-survivors contribute exp(lowest) = +0)
-  float sum = 0;
-  for (auto &a : asc) { a.e = exp_like_reference(a.v); sum += a.e; }
-  float cum = 0;
-  // final softmax + multinomial in index order
-  for (size_t i = 0; i < asc.size(); i++) {
-    cum += asc[i].e / sum;
-    if (i + 1 < asc.size() && cum <= 0.2)
-      for (auto &b : s) if (b.idx == asc[i].idx) b.v = LOWEST; // cut
+  const int pick = sample_survivors(s, asc, sample);
+  return pick < 0 ? literal() : pick; // a tie: inherit std::sort's tie order from the literal formulation
+}
+
+// The same candidate from the decode step's device prefilter (ar.hip: sample_prefilter_kernel): `n` (index, logit) pairs in index
+// order holding EVERY logit >= the smallest one listed, 54 <= n. Returns the id sample_one would return on the full row, or -1 when
+// that cannot be guaranteed from the list alone (the caller then fetches the row):
+//   - penalised values never exceed their source (x * 2 < x < 0, x / 2 <= x otherwise), so an unlisted logit stays below
+//     thr = min(list) after the penalty, while at least n - 4 >= 50 listed ones keep their value >= thr: the 50th largest penalised
+//     value `hmin` is >= thr and is found among the listed ones;
+//   - sample_one keeps i when src[i] >= cut (= hmin - 4 ulps) and val(i) / temp >= hmin / temp: with thr <= cut every such i is listed.
+//     thr > cut (the ~14 logits between rank 50 and rank n within 4 ulps of each other) -> -1;
+//   - more than 4 distinct penalty ids or a tie among the survivors need the literal formulation over the full row -> -1.
+static int sample_one_list(int n, const int32_t *idx, const float *lv, const int32_t *ids, int ids_per_cand, float sample) {
+  const int TOPK = 50;
+  const float LOWEST = std::numeric_limits<float>::lowest();
+  const float temp = 0.8;
+  thread_local std::vector<Surv> s, asc;
+  thread_local std::vector<float> pv;
+  if (n < TOPK + 4) return -1;
+  int pid[4]; int np = 0;
+  for (int j = 0; j < ids_per_cand; j++) {
+    bool seen = false;
+    for (int q = 0; q < np; q++) seen |= (pid[q] == ids[j]);
+    if (seen) continue;
+    if (np == 4) return -1;
+    pid[np++] = ids[j];
   }
-  sum = 0;
-  for (auto &a : s) { a.e = (a.v == LOWEST) ? 0.f : exp_like_reference(a.v); sum += a.e; }
-  int pick = V - 1;
-  if (!(0.0f < sample)) pick = 0; // cumulative(=0) >= sample already at index 0
-  else {
-    cum = 0;
-    for (auto &a : s) {
-      cum += a.e / sum;
-      if (cum >= sample) { pick = a.idx; break; }
-    }
+  pv.resize(n);
+  float thr = lv[0];
+  for (int i = 0; i < n; i++) {
+    const float g = lv[i];
+    thr = std::min(thr, g);
+    bool pen = false;
+    for (int q = 0; q < np; q++) pen |= (pid[q] == idx[i]);
+    pv[i] = pen ? ((g < 0) ? g * 2.0f : g / 2.0f) : g;
   }
-  return pick;
+  asc.resize(n); // scratch: the 50th largest penalised value
+  for (int i = 0; i < n; i++) asc[i].v = pv[i];
+  std::nth_element(asc.begin(), asc.begin() + (TOPK - 1), asc.end(), [](const Surv &a, const Surv &b) { return a.v > b.v; });
+  const float hmin = asc[TOPK - 1].v;
+  const float kth = hmin / temp;
+  float cut = hmin;
+  for (int q = 0; q < 4; q++) cut = std::nextafter(cut, LOWEST);
+  if (!(thr <= cut)) return -1;
+  s.clear();
+  for (int i = 0; i < n; i++) {
+    if (lv[i] < cut) continue;
+    const float v = pv[i] / temp;
+    if (v >= kth) s.push_back({v, idx[i], 0.f});
+  }
+  return sample_survivors(s, asc, sample);
 }
 
 // Small persistent pool for the per-candidate sampler work (16 independent scans of 8194 logits between two
@@ -365,15 +422,13 @@ struct SamplerPool {
 };
 void sampler_pool_free(SamplerPool *p) { delete p; }
 
-void sample_candidates(tts_ctx *ctx, const float *logits, const int32_t *ids, int ids_per_cand, int B,
-                       int32_t *out) {
-  const int V = TTS_VOCAB_MEL;
-  // the RNG is consumed in candidate order exactly as the reference does; the scans then run in parallel.
-  // Sharded batch (options "rng_shard_offset" / "rng_shard_total"): this context holds candidates
-  // [offset, offset + B) of a batch of `total`; the used uniform of (step s, global candidate c) is output 2 (s total + c) + 1
-  // of the one mt19937 stream, so the draws of the other ranks' candidates are skipped (each uniform is one 32-bit output).
+// The RNG is consumed in candidate order exactly as the reference does; the scans then run in parallel.
+// Sharded batch (options "rng_shard_offset" / "rng_shard_total"): this context holds candidates
+// [offset, offset + B) of a batch of `total`; the used uniform of (step s, global candidate c) is output 2 (s total + c) + 1
+// of the one mt19937 stream, so the draws of the other ranks' candidates are skipped (each uniform is one 32-bit output).
+static void draw_uniforms(tts_ctx *ctx, int B, std::vector<float> &samples) {
   const int total = ctx->rng_shard_total > 0 ? ctx->rng_shard_total : B, c0 = shard_base(ctx);
-  std::vector<float> samples(B);
+  samples.resize(B);
   if (c0 > 0) ctx->generator.discard(2ull * c0);
   for (int c = 0; c < B; c++) {
     float sample = ctx->distribution(ctx->generator); // first draw discarded (main.cpp:4708-4709)
@@ -381,7 +436,9 @@ void sample_candidates(tts_ctx *ctx, const float *logits, const int32_t *ids, in
     samples[c] = sample;
   }
   if (total - c0 - B > 0) ctx->generator.discard(2ull * (total - c0 - B));
-  auto one = [&](int c) { out[c] = sample_one(logits + (size_t)c * V, ids + (size_t)c * ids_per_cand, ids_per_cand, samples[c]); };
+}
+
+static void run_on_pool(tts_ctx *ctx, int B, const std::function<void(int)> &one) {
   if (B < 4 || ctx->sampler_threads == 0) { for (int c = 0; c < B; c++) one(c); return; }
   if (!ctx->sampler_pool) {
     const int hw = (int)std::thread::hardware_concurrency();
@@ -389,6 +446,67 @@ void sample_candidates(tts_ctx *ctx, const float *logits, const int32_t *ids, in
     ctx->sampler_pool = new SamplerPool(n);
   }
   ctx->sampler_pool->run(B, one);
+}
+
+void sample_candidates(tts_ctx *ctx, const float *logits, const int32_t *ids, int ids_per_cand, int B,
+                       int32_t *out) {
+  const int V = TTS_VOCAB_MEL;
+  std::vector<float> samples;
+  draw_uniforms(ctx, B, samples);
+  run_on_pool(ctx, B, [&](int c) { out[c] = sample_one(logits + (size_t)c * V, ids + (size_t)c * ids_per_cand, ids_per_cand, samples[c]); });
+}
+
+// The decode loop's sampler over the device prefilter's lists (ar.hip: [B][TTS_PF_WORDS] = {n, 0, 0, 0, idx[128], logit[128]}), same
+// uniforms, same ids. A candidate whose list cannot decide (n < 0: the device found no threshold keeping 64..128 logits; or
+// sample_one_list's -1) is sampled from its full row, fetched through `full_row` (which applies the stop mask itself).
+int sample_candidates_list(tts_ctx *ctx, const int32_t *lists, const int32_t *ids, int ids_per_cand, int B, int32_t *out,
+                           const std::function<const float *(int)> &full_row, int *n_fallbacks) {
+  std::vector<float> samples;
+  draw_uniforms(ctx, B, samples);
+  auto one = [&](int c) {
+    const int32_t *l = lists + (size_t)c * TTS_PF_WORDS;
+    const int n = l[0];
+    out[c] = (n < 1 || n > TTS_PF_MAX) ? -1
+                                       : sample_one_list(n, l + 4, (const float *)(l + 4 + TTS_PF_MAX), ids + (size_t)c * ids_per_cand, ids_per_cand, samples[c]);
+  };
+  if (B < 8 || ctx->sampler_threads == 0) { for (int c = 0; c < B; c++) one(c); } // ~2 us per list: the pool's wake-up costs more below 8
+  else run_on_pool(ctx, B, one);
+  int fb = 0;
+  for (int c = 0; c < B; c++) {
+    if (out[c] >= 0) continue;
+    const float *row = full_row(c);
+    if (!row) return -1;
+    out[c] = sample_one(row, ids + (size_t)c * ids_per_cand, ids_per_cand, samples[c]);
+    fb++;
+  }
+  if (n_fallbacks) *n_fallbacks += fb;
+  return 0;
+}
+
+// Host restatement of the device prefilter for tests (tts_host_sample_prefiltered): the `keep` largest logits and every tie of the
+// smallest of them, in index order; n = -1 when that exceeds the list capacity.
+int host_prefilter_row(const float *row, int keep, int32_t *list) {
+  const int V = TTS_VOCAB_MEL;
+  std::vector<float> tmp(row, row + V);
+  std::nth_element(tmp.begin(), tmp.begin() + (keep - 1), tmp.end(), std::greater<float>());
+  const float thr = tmp[keep - 1];
+  int n = 0;
+  for (int i = 0; i < V; i++) n += row[i] >= thr;
+  std::fill(list, list + TTS_PF_WORDS, 0);
+  if (n > TTS_PF_MAX) { list[0] = -1; return -1; }
+  list[0] = n;
+  float *lv = (float *)(list + 4 + TTS_PF_MAX);
+  int k = 0;
+  for (int i = 0; i < V; i++)
+    if (row[i] >= thr) { list[4 + k] = i; lv[k] = row[i]; k++; }
+  return n;
+}
+
+int sample_one_row(const float *row, const int32_t *ids, int ids_per_cand, float uniform) { return sample_one(row, ids, ids_per_cand, uniform); }
+int sample_one_from_list(const int32_t *list, const int32_t *ids, int ids_per_cand, float uniform) {
+  const int n = list[0];
+  if (n < 1 || n > TTS_PF_MAX) return -1;
+  return sample_one_list(n, list + 4, (const float *)(list + 4 + TTS_PF_MAX), ids, ids_per_cand, uniform);
 }
 
 // apply_padding, main.cpp:4510-4532 (the 8139 is the reference's literal, not 8193)
