@@ -379,3 +379,24 @@ def test_full_size_ar_192_steps_teacher_forced(full_engine, oracle, full_models,
     e_lat = max(rel_err(lats[c], lat_o[k, :200]) for k, c in enumerate((0, 15)))
     print("full-size AR, 16 candidates x 192 steps teacher-forced: worst logits rel err %.1e; latents (200 rows) rel err %.1e" % (worst, e_lat))
     assert worst < 1e-4 and e_lat < 1e-3
+
+
+def test_full_size_ar_device_topk_on_off(full_engine, voice):
+    """The benchmark's AR workload (16 candidates x 192 masked steps, full-depth weights) with the sampler's top-k selected on the device (default)
+    and with the reference's full-logits hand-over: same codes, same latents, same RNG position, and hardly a list that needed its full row."""
+    eng = full_engine
+    toks = np.array([255] + [int(x) for x in (np.arange(62) * 7 + 3) % 250] + [0], np.int32)
+    out = []
+    try:
+        for on in (1, 0):
+            eng.set_option("device_topk", on)
+            eng.seed(1234)
+            codes, rows, lats, steps = eng.autoregressive(toks, voice, 16, 192, mask_stop=True)
+            out.append((codes, rows, lats, steps, eng.rng_uniform(), eng.topk_fallbacks()))
+    finally:
+        eng.set_option("device_topk", 1)
+    a, b = out
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and a[3] == b[3] == 192 and a[4] == b[4]
+    assert all(np.array_equal(x, y) for x, y in zip(a[2], b[2]))
+    print("full-size AR, 16 x 192 steps: device top-k == full logits; %d of %d candidate-steps fetched their full row" % (a[5], 16 * 191))
+    assert a[5] <= 16 * 191 // 100

@@ -308,12 +308,17 @@ struct StepState { int n_past; int pos_id; };
 // index of (candidate r, channel k) in the decode step's interleaved residual-stream layout h4 (described in front of the decode kernels)
 __host__ __device__ __forceinline__ size_t h4_index(int r, int k) { return ((((size_t)(r >> 4) * 256 + (k >> 2)) * 16 + (r & 15)) << 2) + (k & 3); }
 
+// First kernel of the decode step. `host_step` is the PINNED HOST block [tokens[B] | n_past, pos_id] the host fills before it launches the graph: the kernel
+// reads it over PCIe (one ~2 us round trip inside a kernel that has nothing else to wait for) and block 0 leaves the step state in device memory for
+// the 150 launches behind it — instead of a host-to-device copy node in front of the graph (a 5 us blit kernel + a launch boundary per step).
 __global__ __launch_bounds__(256) void embed_step_kernel(const float *__restrict__ mel_emb, const float *__restrict__ mel_pos,
-                                                         const int *__restrict__ toks, const StepState *__restrict__ ss,
+                                                         const int *__restrict__ host_step, int B, StepState *__restrict__ ss_out,
                                                          float *__restrict__ h4) {
   const int r = blockIdx.x;
-  const float4 a = ((const float4 *)(mel_emb + (size_t)toks[r] * D))[threadIdx.x];
-  const float4 b = ((const float4 *)(mel_pos + (size_t)ss->pos_id * D))[threadIdx.x];
+  const int tok = host_step[r], n_past = host_step[B], pos_id = host_step[B + 1];
+  if (r == 0 && threadIdx.x == 0) { ss_out->n_past = n_past; ss_out->pos_id = pos_id; }
+  const float4 a = ((const float4 *)(mel_emb + (size_t)tok * D))[threadIdx.x];
+  const float4 b = ((const float4 *)(mel_pos + (size_t)pos_id * D))[threadIdx.x];
   *(float4 *)(h4 + h4_index(r, 4 * threadIdx.x)) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); // h4 layout, see below
 }
 
@@ -1063,8 +1068,7 @@ struct ArState {
   DevBuf d_toks;
   int32_t *h_toks = nullptr;   // pinned
   float *h_logits = nullptr;   // pinned [B][8194]
-  int32_t *h_pf = nullptr;     // pinned [B][TTS_PF_WORDS]: the device prefilter's lists (step_mode != 0)
-  DevBuf pf;
+  int32_t *h_pf = nullptr;     // pinned [B][TTS_PF_WORDS]: the device prefilter's lists (step_mode != 0), written by the kernel itself
   int step_mode = 0;           // what the step hands to the host: 0 = the logits, 1 = the prefilter's lists, 2 = lists with the stop token masked
   int h_cap_B = 0;             // candidates the pinned buffers were sized for
   hipGraph_t graph = nullptr;
@@ -1072,16 +1076,16 @@ struct ArState {
   // everything the captured step bakes into its nodes: the graph of the previous utterance is replayed when nothing moved
   struct GraphSig {
     int B = 0, max_pos = 0, lut = 0, wmode = 0, mode = 0;
-    const void *p[12] = {};
+    const void *p[11] = {};
     bool operator==(const GraphSig &o) const {
-      return B == o.B && max_pos == o.max_pos && lut == o.lut && wmode == o.wmode && mode == o.mode && std::equal(p, p + 12, o.p);
+      return B == o.B && max_pos == o.max_pos && lut == o.lut && wmode == o.wmode && mode == o.mode && std::equal(p, p + 11, o.p);
     }
   } graph_sig;
   GraphSig current_sig(int lut, int wmode) const {
     GraphSig g;
     g.B = B; g.max_pos = max_pos; g.lut = lut; g.wmode = wmode; g.mode = step_mode;
-    const void *q[12] = {h.p, qkv.p, att.p, ff.p, kcache.p, vcache.p, d_toks.p, logits.p, h_toks, h_logits, pf.p, h_pf};
-    std::copy(q, q + 12, g.p);
+    const void *q[11] = {h.p, qkv.p, att.p, ff.p, kcache.p, vcache.p, d_toks.p, logits.p, h_toks, h_logits, h_pf};
+    std::copy(q, q + 11, g.p);
     return g;
   }
   void drop_graph() {
@@ -1567,7 +1571,6 @@ int ar_begin(tts_ctx *ctx, const int32_t *text_ids, int n_text, const float *voi
   TTS_HIP(ctx, st->vcache.reserve(cache));
   TTS_HIP(ctx, st->d_toks.reserve((size_t)(B + 2) * 4)); // [tokens | n_past, pos_id]
   TTS_HIP(ctx, st->logits.reserve((size_t)B * V * 4));
-  TTS_HIP(ctx, st->pf.reserve((size_t)B * TTS_PF_WORDS * 4));
   if (B > st->h_cap_B) { // pinned allocations are slow (milliseconds): keep them across utterances
     if (st->h_toks) (void)hipHostFree(st->h_toks);
     if (st->h_logits) (void)hipHostFree(st->h_logits);
@@ -1644,8 +1647,7 @@ static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
   const size_t layer_stride = (size_t)B * st->max_pos * D;
   const int wm = ctx->ar_weights; // 1 / 2: fp16 / fp8 weights, a half / a quarter of the bytes per step (throughput modes, not f32-exact); checked by ar_step
   const double wb = wm == 2 ? 1.0 : wm == 1 ? 2.0 : 4.0;
-  TTS_HIP(ctx, hipMemcpyAsync(st->d_toks.p, st->h_toks, (size_t)(B + 2) * 4, hipMemcpyHostToDevice, ctx->stream));
-  embed_step_kernel<<<B, 256, 0, ctx->stream>>>(st->mel_emb, st->mel_pos, st->d_toks.as<int>(), ss, h);
+  embed_step_kernel<<<B, 256, 0, ctx->stream>>>(st->mel_emb, st->mel_pos, st->h_toks, B, (StepState *)(st->d_toks.as<int>() + B), h);
   for (int l = 0; l < st->n_layers; l++) {
     const ArLayerDev &w = st->L[l];
     __half *kc = st->kcache.as<__half>() + l * layer_stride, *vc = st->vcache.as<__half>() + l * layer_stride;
@@ -1683,8 +1685,8 @@ static int enqueue_decode_step(tts_ctx *ctx, ArState *st) {
     TTS_HIP(ctx, hipMemcpyAsync(st->h_logits, st->logits.p, (size_t)B * V * 4, hipMemcpyDeviceToHost, ctx->stream));
   } else { // the sampler's top-k prefilter on the device: 16 KB instead of 524 KB back to the host per step of 16 candidates
     ProfScope ps(ctx, "ar_prefilter", (double)B * V * 4.0);
-    sample_prefilter_kernel<<<B, 256, 0, ctx->stream>>>(st->logits.as<float>(), st->step_mode == 2, st->pf.as<int32_t>());
-    TTS_HIP(ctx, hipMemcpyAsync(st->h_pf, st->pf.p, (size_t)B * TTS_PF_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // the lists are written straight into pinned host memory (1 KB per candidate over PCIe from the kernel's stores): no copy node behind the graph
+    sample_prefilter_kernel<<<B, 256, 0, ctx->stream>>>(st->logits.as<float>(), st->step_mode == 2, st->h_pf);
   }
   TTS_HIP(ctx, hipGetLastError());
   return TTS_OK;
