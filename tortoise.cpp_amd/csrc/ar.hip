@@ -248,6 +248,132 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const float *__restrict__
   }
 }
 
+// Causal attention of the multi-row passes (latent pass: 16 candidates x ~200 rows x 16 heads), default (non-LUT) numerics. One workgroup per
+// (candidate, head, block of 64 rows): lane = row, and the four waves split the KEYS (wave w takes the groups of 8 keys w, w + 4, ..) so that every SIMD
+// holds several waves to hide the LDS latency (one thread per row alone is < 1 wave per SIMD at 3 216 rows). The keys are staged through LDS in chunks of
+// 128 (K and V rows of the head, 128 B each: 32 KB per chunk) and walked with wave-uniform LDS addresses (broadcast reads, no bank conflicts): q.k on
+// v_dot2_f32_f16 (q is the fp16-rounded query, so the products are exact and the sum is f32), online softmax per group of 8 keys (one rescale of the 64
+// accumulators per group), p.V on v_fma_mix_f32 (f32 weight x fp16 V, f32 accumulate). The four partial states (m, l, acc[64]) are merged through LDS.
+// Same arithmetic class as attention_kernel below (f32 weights, f32 accumulation; only the summation order and exp2 vs expf differ), which needed one wave
+// per (row, head) and re-read every K/V row from L2 per row: 225 us per layer at 3 216 rows.
+typedef _Float16 ar_half2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void attention_rows_kernel(const float *__restrict__ qkv, const __half *__restrict__ kc,
+                                                             const __half *__restrict__ vc, float *__restrict__ out, int S, int n_past,
+                                                             int max_pos) {
+  constexpr int CH = 128; // keys per LDS chunk: 32 KB of LDS, three workgroups per CU (the registers allow three waves per SIMD)
+  constexpr float L2E = 1.4426950408889634f;
+  __shared__ __attribute__((aligned(16))) __half kvs[2 * CH * HD]; // K chunk | V chunk; reused for the merge: acc[wave][32 dims][lane], two passes
+  __shared__ float wm[4][64], wl[4][64];
+  __half *ks = kvs, *vs = kvs + CH * HD;
+  const int c = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s0 = blockIdx.z * 64, s = s0 + lane;
+  const bool live = s < S;
+  const int nk = live ? n_past + s + 1 : 0;         // keys this row sees (ggml_diag_mask_inf(n_past))
+  const int nk_block = n_past + min(S, s0 + 64);     // keys the block's last row sees
+  ar_half2 q2[HD / 2];
+  {
+    const float *qp = qkv + (size_t)(c * S + (live ? s : S - 1)) * 3 * D + h * HD;
+#pragma unroll
+    for (int i = 0; i < HD / 4; i++) {
+      const float4 f = ((const float4 *)qp)[i];
+      q2[2 * i] = (ar_half2){(_Float16)f.x, (_Float16)f.y};
+      q2[2 * i + 1] = (ar_half2){(_Float16)f.z, (_Float16)f.w};
+    }
+  }
+  const __half *kb = kc + (size_t)c * max_pos * D + h * HD;
+  const __half *vb = vc + (size_t)c * max_pos * D + h * HD;
+  float m = -INFINITY, l = 0.f, acc[HD];
+#pragma unroll
+  for (int d = 0; d < HD; d++) acc[d] = 0.f;
+  for (int j0 = 0; j0 < nk_block; j0 += CH) {
+    const int nch = min(CH, nk_block - j0), nch8 = (nch + 7) & ~7;
+    __syncthreads(); // the previous chunk has been consumed
+    // stage K and V rows j0 .. j0 + nch: 8 threads per row, 16 bytes each (a row of the head = 128 contiguous bytes); the rows that fill the last
+    // group of 8 are zeroed (their weights are exp2(-inf) = 0, and 0 x stale LDS bits could be 0 x inf)
+    for (int r = tid >> 3; r < nch8; r += 32) {
+      const size_t g = (size_t)(j0 + r) * D + (tid & 7) * 8;
+      uint4 ku = make_uint4(0u, 0u, 0u, 0u), vu = ku;
+      if (r < nch) { ku = *(const uint4 *)(kb + g); vu = *(const uint4 *)(vb + g); }
+      *(uint4 *)(ks + r * HD + (tid & 7) * 8) = ku;
+      *(uint4 *)(vs + r * HD + (tid & 7) * 8) = vu;
+    }
+    __syncthreads();
+    for (int jg = wave * 8; jg < nch; jg += 32) {
+      float sc[8];
+      float gmax = m;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const ar_half2 *kr = (const ar_half2 *)(ks + (jg + e) * HD);
+        float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < HD / 2; i += 2) {
+          d0 = __builtin_amdgcn_fdot2(q2[i], kr[i], d0, false);
+          d1 = __builtin_amdgcn_fdot2(q2[i + 1], kr[i + 1], d1, false);
+        }
+        const float v = (j0 + jg + e < nk) ? (d0 + d1) * 0.125f : -INFINITY; // 1/sqrt(64)
+        sc[e] = v;
+        gmax = fmaxf(gmax, v);
+      }
+      if (gmax == -INFINITY) continue; // nothing visible to this row yet (or a row past S)
+      const float resc = __builtin_amdgcn_exp2f((m - gmax) * L2E); // m = -inf -> 0
+      l *= resc;
+#pragma unroll
+      for (int d = 0; d < HD; d++) acc[d] *= resc;
+      m = gmax;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float pw = __builtin_amdgcn_exp2f((sc[e] - gmax) * L2E); // masked key: exp2(-inf) = 0
+        l += pw;
+        // acc[d] += pw * V[d] with V read as fp16 by the FMA itself (v_fma_mix_f32: no conversion instructions; hipcc emits cvt + packed FMA otherwise)
+        const uint4 *vr = (const uint4 *)(vs + (jg + e) * HD);
+#pragma unroll
+        for (int i = 0; i < HD / 8; i++) {
+          const uint4 u = vr[i];
+          const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "+v"(acc[8 * i + 2 * k]) : "v"(pw), "v"(w[k]));
+            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(acc[8 * i + 2 * k + 1]) : "v"(pw), "v"(w[k]));
+          }
+        }
+      }
+    }
+  }
+  // merge the four waves' partial states of every row (fixed order: wave 0 .. 3)
+  __syncthreads(); // the last chunk has been consumed: its LDS becomes the exchange buffer
+  float *xa = (float *)kvs; // [wave][32 dims][lane]: 32 KB, dims 0-31 then dims 32-63
+  wm[wave][lane] = m; wl[wave][lane] = l;
+  float o[16]; // this wave finishes dims 16 wave .. 16 wave + 15 of all 64 rows
+#pragma unroll
+  for (int half = 0; half < 2; half++) {
+    if (half) __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 32; d++) xa[(wave * 32 + d) * 64 + lane] = acc[half * 32 + d];
+    __syncthreads();
+    if ((wave >> 1) == half) { // waves 0, 1 own dims 0-31, waves 2, 3 dims 32-63
+      const float M = fmaxf(fmaxf(wm[0][lane], wm[1][lane]), fmaxf(wm[2][lane], wm[3][lane])); // wave 0 holds key 0 of every live row: finite
+      float f[4], tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        f[w] = __builtin_amdgcn_exp2f((wm[w][lane] - M) * L2E); // a wave that saw no key: exp2(-inf) = 0
+        tot = fmaf(f[w], wl[w][lane], tot);
+      }
+      const float inv = 1.0f / tot;
+#pragma unroll
+      for (int d = 0; d < 16; d++) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; w++) t = fmaf(f[w], xa[(w * 32 + (wave & 1) * 16 + d) * 64 + lane], t);
+        o[d] = t * inv;
+      }
+    }
+  }
+  if (!live) return;
+  float *op = out + (size_t)(c * S + s) * D + h * HD + wave * 16;
+#pragma unroll
+  for (int i = 0; i < 4; i++) ((float4 *)op)[i] = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+}
+
 // Causal attention for one (row, head): q from the f16-rounded qkv buffer, K/V from an fp16 cache
 // [cand][max_pos][1024]. Row r = cand*S + s sees keys 0 .. n_past+s (ggml_diag_mask_inf(n_past)).
 // One wave per (row, head). Scores in LDS (<= 1024 keys).
@@ -1515,7 +1641,8 @@ static int run_layers(tts_ctx *ctx, ArState *st, int rows, int S, int n_past, __
     KvDst kv{kc + l * layer_stride, vc + l * layer_stride, S, n_past, kv_max_pos, replicate};
     CHECK(launch_epilogue<EPI_QKV>(ctx, st, ks, rows, 3 * D, 3 * D, w.b_attn, qkv, 3 * D, kv, ps));
     { ProfScope ps(ctx, "ar_attention");
-      attention_kernel<<<dim3(rows, NH), 64, 0, ctx->stream>>>(qkv, kv.k, kv.v, att, S, n_past, kv_max_pos, ctx->ggml_lut); }
+      if (ctx->ggml_lut) attention_kernel<<<dim3(rows, NH), 64, 0, ctx->stream>>>(qkv, kv.k, kv.v, att, S, n_past, kv_max_pos, 1);
+      else attention_rows_kernel<<<dim3(rows / S, NH, (S + 63) / 64), 256, 0, ctx->stream>>>(qkv, kv.k, kv.v, att, S, n_past, kv_max_pos); }
     if (mfma) CHECK(launch_mfma_matmul(ctx, st, att, rows, w.s_proj, D, D));
     else CHECK(launch_gemv(ctx, st, att, D, rows, w.w_proj, D, D, &ks));
     CHECK(launch_epilogue<EPI_RESID>(ctx, st, ks, rows, D, D, w.b_proj, h, D, nokv, ps));
