@@ -203,6 +203,10 @@ int tts_diffusion_forward(tts_ctx *ctx, const float *latents, int latent_rows, c
 enum { TTS_NOISE_REFERENCE = 0, TTS_NOISE_DEVICE = 1 };
 int tts_diffusion(tts_ctx *ctx, const float *latents, const int32_t *rows, int n_candidates,
                   int n_steps, const float *noise, int noise_mode, float *mel_out);
+/* The timestep MLP (main.cpp:3331-3343, 3410-3428: five tiny launches at the start of every tts_diffusion / tts_diffusion_forward call) is evaluated twice
+ * and compared bit for bit, and repeated when the two evaluations disagree — observed only while a second process uses the same GPU.
+ * Number of disagreeing evaluations since the context was created (0 in every single-process run). */
+int tts_diffusion_time_mlp_retries(const tts_ctx *ctx);
 
 /* ---- vocoder stage -------------------------------------------------------------------------- */
 int tts_vocoder_samples(int mel_frames); /* (T+10)*256-6, main.cpp:6051, 4459-4478 */

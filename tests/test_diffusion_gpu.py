@@ -140,3 +140,9 @@ def test_device_noise_is_deterministic_and_normal(engine, small_models, pkg):
     assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
     assert not (a[0] == a[1]).all()  # independent per-candidate streams
     assert np.isfinite(a[0]).all()
+
+
+def test_time_mlp_guard_is_silent_in_a_single_process(engine):
+    """The timestep MLP is evaluated twice per call and repeated on disagreement (diffusion.hip: precompute_time; DESIGN.md section 6: two evaluations
+    were seen to disagree only while a second engine process shared the GPU). Every call of this module ran alone: not one repetition."""
+    assert engine.time_mlp_retries() == 0

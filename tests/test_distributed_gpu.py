@@ -135,17 +135,20 @@ def test_cli_devices_shards_reproduce_the_single_process_batch(small_models, tmp
     shutil.copy(os.path.join(ROOT, "models", "tokenizer.json"), d / "tokenizer.json")
     base = [exe, "--models", str(d), "--message", "this is a test message.", "--voice", os.path.join(ROOT, "models", "mol.bin"), "--seed", "3",
             "--codes", "16", "--steps", "4", "--candidates", "4"]
-    outs = {}
+    outs, errs = {}, {}
     for tag, extra in (("one", []), ("two", ["--devices", "2", "--device-map", "0,0"])):
         out = tmp_path / (tag + ".wav")
         r = subprocess.run(base + ["--output", str(out)] + extra, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
+        errs[tag] = r.stderr
         files = [out] + [tmp_path / ("%s.wav.%d.wav" % (tag, c)) for c in range(1, 4)]
         assert all(f.exists() for f in files), [f.name for f in files if not f.exists()]
         outs[tag] = [np.frombuffer(f.read_bytes()[44:], np.float32) for f in files]
+    # (two engine processes on ONE GPU is this test's vehicle, not a deployment: while they overlap, the diffusion stage's timestep MLP may be re-evaluated —
+    #  the CLI says so on stderr — see DESIGN.md section 6 and profiles/r4_two_process_determinism.txt)
     for c in range(4):
         a, b = outs["one"][c], outs["two"][c]
-        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-4 * max(1e-6, np.abs(a).max()), c
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-4 * max(1e-6, np.abs(a).max()), (c, errs["two"][-600:])
 
 
 def test_cli_clvp_reranking_single_process_and_shards(small_models, tmp_path):

@@ -1,0 +1,22 @@
+#!/bin/bash
+# developer probe: the standalone matrix-vector probe (cold weights) beside an engine process that keeps the GPU busy
+cd "$(dirname "$0")/.." || exit 1
+python - <<'PY' &
+import sys, os
+sys.path.insert(0, os.getcwd())
+import tortoise_cpp_amd_loader as l, numpy as np
+pkg = l.load()
+from tortoise_cpp_amd import synth_weights as sw
+src = "/tmp/tts_synth/small"
+if not os.path.exists(src + "/.done"):
+    sw.write_all(src, ar_layers=2, diff_main=1, diff_tail=1, diff_integ=1, diff_lc=1, seed=4321); open(src + "/.done", "w").write("ok")
+e = pkg.Engine(0); e.load(src); rs = np.random.RandomState(0)
+print("engine load running", flush=True)
+while True:
+    e.diffusion([rs.randn(30, 1024).astype(np.float32) for _ in range(4)], n_steps=6, noise_mode=pkg.NOISE_DEVICE)
+PY
+LOADPID=$!
+sleep 14
+tools/bin/mp_corruption_probe 12 cold48 48
+tools/bin/mp_corruption_probe 6 hot1 1
+kill $LOADPID

@@ -59,7 +59,7 @@ def lib():
         "tts_ar_begin": (ci, [vp, _i32p, ci, _f32p, ci, ci]), "tts_ar_prefill": (ci, [vp, _f32p]),
         "tts_ar_step": (ci, [vp, _i32p, ci, _f32p]), "tts_ar_latents": (ci, [vp, _i32p, ci, ci, _f32p]),
         "tts_sample": (ci, [vp, _f32p, _i32p, ci, ci, _i32p]),
-        "tts_ar_step_sample": (ci, [vp, _i32p, ci, C.c_uint, _i32p]), "tts_ar_topk_fallbacks": (ci, [vp]),
+        "tts_ar_step_sample": (ci, [vp, _i32p, ci, C.c_uint, _i32p]), "tts_ar_topk_fallbacks": (ci, [vp]), "tts_diffusion_time_mlp_retries": (ci, [vp]),
         "tts_host_sample_row": (ci, [_f32p, _i32p, ci, cf]), "tts_host_sample_prefiltered": (ci, [_f32p, _i32p, ci, cf, ci]),
         "tts_autoregressive": (ci, [vp, _i32p, ci, _f32p, ci, ci, C.c_uint, _i32p, _i32p, vp, _i32p]),
         "tts_ar_stop_status": (ci, [vp, _i32p, ci]),
@@ -186,6 +186,9 @@ class Engine:
 
     def topk_fallbacks(self):
         return self.L.tts_ar_topk_fallbacks(self.h)
+
+    def time_mlp_retries(self):
+        return self.L.tts_diffusion_time_mlp_retries(self.h)
 
     def ar_latents(self, codes502, n_mel=502):
         codes502 = np.ascontiguousarray(codes502, np.int32).reshape(-1, 502)

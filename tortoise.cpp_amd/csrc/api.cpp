@@ -263,6 +263,7 @@ int tts_ar_step_sample(tts_ctx *c, const int32_t *prev, int i, unsigned flags, i
   });
 }
 int tts_ar_topk_fallbacks(const tts_ctx *c) { return c ? c->topk_fallbacks : -1; }
+int tts_diffusion_time_mlp_retries(const tts_ctx *c) { return c ? c->time_mlp_retries : -1; }
 int tts_host_sample_row(const float *row, const int32_t *ids, int ids_per_cand, float uniform) {
   if (!row || !ids || ids_per_cand < 1) return -1;
   return sample_one_row(row, ids, ids_per_cand, uniform);

@@ -54,6 +54,7 @@ int main(int argc, char **argv) {
   int seed = 0, candidates = 1, steps = 80, device = 0, fixed_codes = 0, devices = 1, shard = -1, nshards = 1;
   std::string device_map, clvpPath, exchange = "files", rccl_id, diffLatentPath;
   bool dry = false;
+  std::vector<std::pair<std::string, double>> engine_options; // --option key=value (repeatable): tts_set_option before the models are loaded
   for (int i = 1; i < argc - 1; ++i) {
     std::string a(argv[i]);
     if (a == "--voice") voicePath = argv[i + 1];
@@ -70,6 +71,12 @@ int main(int argc, char **argv) {
     else if (a == "--clvp") clvpPath = argv[i + 1];
     else if (a == "--exchange") exchange = argv[i + 1];
     else if (a == "--dry-run") dry = argv[i + 1][0] != '0'; // plumbing check without a device, see below
+    else if (a == "--option") { // engine option, e.g. --option attn_f32=1 (include/tortoise_mi355x.h: tts_set_option)
+      const std::string kv = argv[i + 1];
+      const size_t eq = kv.find('=');
+      if (eq == std::string::npos) { fprintf(stderr, "--option %s: expected key=value\n", kv.c_str()); return 1; }
+      engine_options.emplace_back(kv.substr(0, eq), std::atof(kv.c_str() + eq + 1));
+    }
     else if (a == "--diffusion-latent") diffLatentPath = argv[i + 1];
     else if (a == "--rccl-id") rccl_id = argv[i + 1]; // worker mode (set by the parent)
     else if (a == "--shard") { // worker mode (set by the parent): "r/N"
@@ -162,6 +169,8 @@ int main(int argc, char **argv) {
     return 1;
   }
   if (have_seed) tts_seed(ctx, (uint32_t)seed);
+  for (const auto &kv : engine_options)
+    if (tts_set_option(ctx, kv.first.c_str(), kv.second)) return die(ctx, "--option");
   if (shard >= 0) {
     tts_set_option(ctx, "rng_shard_offset", (double)(shard * candidates));
     tts_set_option(ctx, "rng_shard_total", (double)total_candidates);
@@ -290,6 +299,8 @@ int main(int argc, char **argv) {
   // B == 1: the reference's exact RNG order (AR uniforms, x_T, per-step noise, vocoder noise)
   const int noise_mode = (total_candidates == 1) ? TTS_NOISE_REFERENCE : TTS_NOISE_DEVICE;
   if (tts_diffusion(ctx, lat_in, rows.data(), B, steps, nullptr, noise_mode, mel.data())) return die(ctx, "diffusion");
+  if (tts_diffusion_time_mlp_retries(ctx) > 0) // only ever seen while another process shares the GPU (include/tortoise_mi355x.h)
+    fprintf(stderr, "[tortoise] the timestep MLP was re-evaluated %d times before two evaluations agreed\n", tts_diffusion_time_mlp_retries(ctx));
   if (tts_load_vocoder(ctx, (modelsDir + "/ggml-vocoder-model.bin").c_str())) return die(ctx, "vocoder_model_load");
   if (tts_vocoder(ctx, mel.data(), frames.data(), B, nullptr, noise_mode, audio.data())) return die(ctx, "vocoder");
   for (int c = 0; c < B; c++) nsamp.push_back((size_t)tts_vocoder_samples(frames[c]));

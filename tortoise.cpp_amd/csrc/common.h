@@ -85,6 +85,7 @@ struct tts_ctx {
   tts::Tokenizer *tok = nullptr;
   tts::SamplerPool *sampler_pool = nullptr; // worker threads for the per-candidate sampler scans (host_logic.cpp)
   int device_topk = 1;                      // option "device_topk": tts_autoregressive's loop samples from the device prefilter's lists
+  int time_mlp_retries = 0;                 // evaluations of the diffusion time MLP that disagreed with their repetition (diffusion.hip: precompute_time)
   int topk_fallbacks = 0;                   // candidates x steps of the last tts_autoregressive call that needed their full row
   int sampler_threads = -1;                 // -1: min(7, hardware threads - 1); option "sampler_threads"
   bool share_uncond = true;                 // option "share_uncond": see DiffState::share_integ (diffusion.hip)

@@ -860,7 +860,7 @@ struct DiffState {
     if (step_graph) (void)hipGraphDestroy(step_graph);
     step_exec = nullptr; step_graph = nullptr;
   }
-  DevBuf code_emb, ce, ce16, xt16, inp16, net, temb, e1, emb, ss_all, xbuf, xoff, noise, seq_src, lat_in16, out_ct;
+  DevBuf code_emb, ce, ce16, xt16, inp16, net, temb, e1, emb, ss_all, ss_chk, xbuf, xoff, noise, seq_src, lat_in16, out_ct;
   ~DiffState() { drop_step_graph(); for (void *p : owned) (void)hipFree(p); }
   int n_res() const { return n_integ + n_main + n_tail; }
 };
@@ -1027,6 +1027,31 @@ int diff_load(tts_ctx *ctx, const char *path) {
 #define CHECK(x) do { int _r = (x); if (_r) return _r; } while (0)
 
 // algorithmic FLOPs of one launch: valid rows (no guard/pad rows) x valid columns x valid K
+#ifdef TTS_DEBUG_CHECKSUM // developer build: hash of a buffer after the launch that produced it, one line per call on stderr (tools/determinism_probe*.py)
+static void dbg_sum(tts_ctx *ctx, const char *tag, const void *p, size_t bytes) {
+  std::vector<uint8_t> h(bytes);
+  (void)hipMemcpyAsync(h.data(), p, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream);
+  uint64_t x = 1469598103934665603ull;
+  for (size_t i = 0; i < bytes; i++) x = (x ^ h[i]) * 1099511628211ull;
+  fprintf(stderr, "[cks] %s %016llx\n", tag, (unsigned long long)x);
+  if (!strncmp(tag, "time", 4)) { // the small f32 vectors of the time MLP: keep them to show WHERE two runs differ
+    static std::map<std::string, std::vector<float>> first;
+    const float *f = (const float *)h.data();
+    const size_t n = bytes / 4;
+    auto it = first.find(tag);
+    if (it == first.end()) first[tag].assign(f, f + n);
+    else {
+      size_t nd = 0, i0 = 0; float worst = 0.f;
+      for (size_t i = 0; i < n; i++) if (memcmp(&f[i], &it->second[i], 4)) { if (!nd) i0 = i; nd++; worst = std::max(worst, fabsf(f[i] - it->second[i])); }
+      if (nd) fprintf(stderr, "[dif] %s: %zu of %zu floats differ from the first call, first at %zu (%.9g vs %.9g), largest difference %.3g\n", tag, nd, n, i0, f[i0], it->second[i0], worst);
+    }
+  }
+}
+#define DBG_SUM(tag, p, bytes) dbg_sum(ctx, tag, p, bytes)
+#else
+#define DBG_SUM(tag, p, bytes)
+#endif
 static int gemm(tts_ctx *ctx, const char *fam, GemmArgs &g, const Layout &lay, int n_valid = 0, int k_valid = 0) {
   double mv = 0;
   for (int l : lay.len) mv += l;
@@ -1195,9 +1220,12 @@ static int gn_fused(tts_ctx *ctx, const Layout &lay, const float *x, const float
 // in_layers of a ResBlock (GroupNorm, SiLU, conv k=1): H = conv(silu(gn(x))). No timestep dependence.
 static int res_in_layers(tts_ctx *ctx, const Layout &lay, Work &wk, const float *x, const ResDev &w, float *H) {
   CHECK(gn_fused(ctx, lay, x, w.in_g, w.in_b, nullptr, 1, wk.A16(), w.in_w, (size_t)C * C * 2));
+  DBG_SUM("res.in gn", wk.A16(), (size_t)lay.rows * C * 2);
   GemmArgs g = gemm_base(lay, wk.A16(), C, 1, C, w.in_w, C, w.in_bias);
   g.mode = GEMM_OUT_F32; g.outF = H; g.ldo = C; g.resid = nullptr;
-  return gemm(ctx, "diff_gemm", g, lay);
+  CHECK(gemm(ctx, "diff_gemm", g, lay));
+  DBG_SUM("res.in conv", H, (size_t)lay.rows * C * 4);
+  return TTS_OK;
 }
 
 // AttentionBlock on X (in place). Two arithmetic modes (option attn_f32):
@@ -1208,11 +1236,14 @@ static int res_in_layers(tts_ctx *ctx, const Layout &lay, Work &wk, const float 
 static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, float *X, const AttnDev &w) {
   const bool f32 = ctx->attn_f32 != 0;
   CHECK(gn_fused(ctx, lay, X, w.norm_g, w.norm_b, nullptr, 0, wk.A16(), w.qkv_w, (size_t)3 * C * C * 2, w.proj_w, (size_t)C * C * 2));
+  DBG_SUM("attn gn", wk.A16(), (size_t)lay.rows * C * 2);
   GemmArgs g = gemm_base(lay, wk.A16(), C, 1, C, w.qkv_w, 3 * C, w.qkv_b);
   g.mode = f32 ? GEMM_OUT_QKV_SPLIT : GEMM_OUT_QKV;
   g.outH = wk.qk16.as<__half>(); g.ldh = 2048; g.outVt = wk.vt16.as<__half>(); g.ldvt = wk.rows + 128;
   g.outH2 = wk.qk16_lo.as<__half>(); g.outVt2 = wk.vt16_lo.as<__half>();
   CHECK(gemm(ctx, "diff_gemm", g, lay));
+  DBG_SUM("attn qk", wk.qk16.p, (size_t)lay.rows * 2048 * 2);
+  DBG_SUM("attn vt", wk.vt16.p, (size_t)C * (wk.rows + 128) * 2);
   {
     double aw = 0;
     for (int l : lay.len) aw += 4.0 * l * (double)l * 64 * NHEAD; // QK^T + PV
@@ -1229,6 +1260,7 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
     }
     TTS_HIP(ctx, hipGetLastError());
   }
+  DBG_SUM("attn out", wk.ATT16(), (size_t)lay.rows * C * 2);
   if (f32) { // att . W^T = att_hi . W_hi + att_lo . W_hi + att_hi . W_lo  (W scaled by 64 at load)
     GemmArgs p = gemm_base(lay, wk.ATT16(), C, 3, C, w.proj_w_split, C, w.proj_b);
     p.A[0] = wk.ATT16(); p.A[1] = wk.att16_lo.as<__half>() + C; p.A[2] = wk.ATT16();
@@ -1239,7 +1271,9 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
   }
   GemmArgs p = gemm_base(lay, wk.ATT16(), C, 1, C, w.proj_w, C, w.proj_b);
   p.mode = GEMM_OUT_F32; p.outF = X; p.ldo = C; p.resid = X;
-  return gemm(ctx, "diff_gemm", p, lay);
+  CHECK(gemm(ctx, "diff_gemm", p, lay));
+  DBG_SUM("attn proj", X, (size_t)lay.rows * C * 4);
+  return TTS_OK;
 }
 
 // ResBlock: X = Xin + out_layers(in_layers(Xin) with the step's scale/shift); Xin == nullptr: in place on X.
@@ -1252,52 +1286,83 @@ static int res_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, f
     CHECK(res_in_layers(ctx, lay, wk, xin, w, wk.H()));
     Hpre = wk.H();
   }
+  DBG_SUM("res.out ss", ss, (size_t)2 * C * 4);
+  DBG_SUM("res.out hpre", Hpre, (size_t)lay.rows * C * 4);
   CHECK(gn_fused(ctx, lay, Hpre, w.out_g, w.out_b, ss, 1, wk.A16(), w.out_w, (size_t)3 * C * C * 2));
+  DBG_SUM("res.out gn", wk.A16(), (size_t)lay.rows * C * 2);
   GemmArgs c3 = gemm_base(lay, wk.A16(), C, 3, C, w.out_w, C, w.out_bias);
   c3.mode = GEMM_OUT_F32; c3.outF = X; c3.ldo = C; c3.resid = xin;
-  return gemm(ctx, "diff_gemm", c3, lay);
+  CHECK(gemm(ctx, "diff_gemm", c3, lay));
+  DBG_SUM("res.out conv", X, (size_t)lay.rows * C * 4);
+  return TTS_OK;
 }
 
-// x = silu(x) in place (exact expf and division; lut: through fp16 on both sides like ggml's table). Applied once to the
-// time-MLP activations so that linear_nk_kernel does not redo it for every output column.
-static __global__ __launch_bounds__(256) void silu_inplace_kernel(float *__restrict__ x, int n, int lut) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float v = x[i];
-  if (lut) v = __half2float(__float2half_rn(v));
-  v = v / (1.f + expf(-v));
-  if (lut) v = __half2float(__float2half_rn(v));
-  x[i] = v;
+// Sum over the 64 lanes of a wave, every lane gets the total. The same butterfly as `for (o = 32; o; o >>= 1) v += __shfl_xor(v, o)` — the same pairs in the
+// same order, so the same bits — but on the gfx950 half/row swap instructions and DPP row rotations instead of ds_bpermute_b32 (the LDS crossbar): after
+// the xor-8 step a row's values have period 8, so "lane + 4" holds what "lane ^ 4" holds, and so on down.
+template <int CTRL> __device__ __forceinline__ float lnk_dpp(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+  x += lnk_dpp<0x128>(x); // row_ror:8
+  x += lnk_dpp<0x124>(x); // row_ror:4
+  x += lnk_dpp<0x122>(x); // row_ror:2
+  x += lnk_dpp<0x121>(x); // row_ror:1
+  return x;
 }
 
 // out[r][n] = sum_k x[r][k] * W[n][k] + b[n] for small row counts (time MLP, emb_layers):
 // one wave per output column, 16-byte loads along K, shuffle reduction. F32 exact (reference: F32 mul_mat).
-static __global__ __launch_bounds__(256) void linear_nk_kernel(const float *__restrict__ x, int ldx, int rows, const float *__restrict__ W,
-                                                        int K, int N, const float *__restrict__ b, float *__restrict__ out, int ldo) {
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (n >= N) return;
-  const float *wr = W + (size_t)n * K;
-  for (int r0 = 0; r0 < rows; r0 += 8) {
-    float acc[8];
+// A workgroup (16 waves x 2 columns) owns 32 CONSECUTIVE columns = one whole 128-byte line of every output row (round 4; before, eight workgroups — one per
+// XCD — wrote 16 bytes each into every line). `act`: the time MLP's SiLU applied by the producer.
+static constexpr int LNK_COLS = 32;
+static __global__ __launch_bounds__(1024) void linear_nk_kernel(const float *__restrict__ x, int ldx, int rows, const float *__restrict__ W,
+                                                         int K, int N, const float *__restrict__ b, float *__restrict__ out, int ldo,
+                                                         int act /*0 none, 1 SiLU (exact expf and division), 2 SiLU through fp16 on both sides (ggml's table)*/
+) {
+  const int lane = threadIdx.x & 63;
+  for (int half = 0; half < 2; half++) {
+    const int n = blockIdx.x * LNK_COLS + half * 16 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float *wr = W + (size_t)n * K;
+    for (int r0 = 0; r0 < rows; r0 += 8) {
+      float acc[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) acc[i] = 0.f;
-    for (int k = lane * 4; k < K; k += 256) {
-      const float4 w = *(const float4 *)(wr + k);
+      for (int i = 0; i < 8; i++) acc[i] = 0.f;
+      for (int k = lane * 4; k < K; k += 256) {
+        const float4 w = *(const float4 *)(wr + k);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const float4 xv = *(const float4 *)(x + (size_t)min(r0 + i, rows - 1) * ldx + k);
+          acc[i] = fmaf(xv.x, w.x, acc[i]); acc[i] = fmaf(xv.y, w.y, acc[i]);
+          acc[i] = fmaf(xv.z, w.z, acc[i]); acc[i] = fmaf(xv.w, w.w, acc[i]);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 8; i++) {
-        const float4 xv = *(const float4 *)(x + (size_t)min(r0 + i, rows - 1) * ldx + k);
-        acc[i] = fmaf(xv.x, w.x, acc[i]); acc[i] = fmaf(xv.y, w.y, acc[i]);
-        acc[i] = fmaf(xv.z, w.z, acc[i]); acc[i] = fmaf(xv.w, w.w, acc[i]);
+        float v = wave_sum_dpp(acc[i]);
+        if (lane == 0 && r0 + i < rows) {
+          v += b ? b[n] : 0.f;
+          if (act) { // the time MLP's SiLU, applied by the producer: no address of these vectors ever holds a second version of itself
+            if (act == 2) v = __half2float(__float2half_rn(v));
+            v = v / (1.f + expf(-v));
+            if (act == 2) v = __half2float(__float2half_rn(v));
+          }
+          out[(size_t)(r0 + i) * ldo + n] = v;
+        }
       }
     }
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      float v = acc[i];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-      if (lane == 0 && r0 + i < rows) out[(size_t)(r0 + i) * ldo + n] = v + (b ? b[n] : 0.f);
-    }
   }
+}
+
+// Bitwise comparison of two f32 vectors: *flag = 1 if any word differs (see precompute_time).
+static __global__ __launch_bounds__(256) void differ_kernel(const unsigned *__restrict__ a, const unsigned *__restrict__ b, size_t n, int *__restrict__ flag) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    if (a[i] != b[i]) *flag = 1;
 }
 
 // Timestep MLP + every emb_layers linear for `n` timesteps at once:
@@ -1310,18 +1375,47 @@ static int precompute_time(tts_ctx *ctx, DiffState *st, const std::vector<int> &
   TTS_HIP(ctx, st->ss_all.reserve((size_t)n * nres * 2 * C * 4));
   TTS_HIP(ctx, hipMemcpyAsync(st->temb.p, te.data(), te.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  linear_nk_kernel<<<C / 4, 256, 0, ctx->stream>>>(st->temb.as<float>(), C, n, st->te0_w, C, C, st->te0_b, st->e1.as<float>(), C);
-  silu_inplace_kernel<<<(n * C + 255) / 256, 256, 0, ctx->stream>>>(st->e1.as<float>(), n * C, ctx->ggml_lut);
-  linear_nk_kernel<<<C / 4, 256, 0, ctx->stream>>>(st->e1.as<float>(), C, n, st->te2_w, C, C, st->te2_b, st->emb.as<float>(), C);
-  silu_inplace_kernel<<<(n * C + 255) / 256, 256, 0, ctx->stream>>>(st->emb.as<float>(), n * C, ctx->ggml_lut); // emb is only used activated
-  for (int j = 0; j < nres; j++) {
-    const ResDev &w = j < st->n_integ ? st->integ_res[j] : j < st->n_integ + st->n_main ? st->main_res[j - st->n_integ]
-                                                                                        : st->tail_res[j - st->n_integ - st->n_main];
-    // out row i -> ss_all[(i*nres + j)*2048]
-    linear_nk_kernel<<<2 * C / 4, 256, 0, ctx->stream>>>(st->emb.as<float>(), C, n, w.emb_w, C, 2 * C, w.emb_b,
-                                                         st->ss_all.as<float>() + (size_t)j * 2 * C, nres * 2 * C);
+  // SiLU of both hidden vectors is applied by the kernel that produces them (emb is only used activated): three launches fewer than a separate in-place
+  // activation kernel, and no address of these vectors ever holds two versions of itself within a call.
+  const int act = ctx->ggml_lut ? 2 : 1;
+  auto mlp = [&](float *ss_out) {
+    linear_nk_kernel<<<C / LNK_COLS, 1024, 0, ctx->stream>>>(st->temb.as<float>(), C, n, st->te0_w, C, C, st->te0_b, st->e1.as<float>(), C, act);
+    linear_nk_kernel<<<C / LNK_COLS, 1024, 0, ctx->stream>>>(st->e1.as<float>(), C, n, st->te2_w, C, C, st->te2_b, st->emb.as<float>(), C, act);
+    for (int j = 0; j < nres; j++) {
+      const ResDev &w = j < st->n_integ ? st->integ_res[j] : j < st->n_integ + st->n_main ? st->main_res[j - st->n_integ]
+                                                                                          : st->tail_res[j - st->n_integ - st->n_main];
+      // out row i -> ss[(i*nres + j)*2048]
+      linear_nk_kernel<<<2 * C / LNK_COLS, 1024, 0, ctx->stream>>>(st->emb.as<float>(), C, n, w.emb_w, C, 2 * C, w.emb_b, ss_out + (size_t)j * 2 * C,
+                                                                 nres * 2 * C, 0);
+    }
+  };
+  // Evaluated TWICE and compared bit for bit; repeated until two evaluations agree. Round 4 found that this chain of tiny launches — the first kernels
+  // behind the host transfers of a call — returns 5 .. 40 consecutive wrong outputs in 10-30 % of the calls WHILE A SECOND ENGINE PROCESS USES THE SAME GPU
+  // (never otherwise; every other launch of the stage hashed identical in the same runs; a stand-alone probe with this kernel shape does not reproduce
+  // it). Kernel overlap, stale kernel arguments, cross-XCD line sharing, the LDS crossbar and in-place updates were each excluded by an experiment; the
+  // cause is not understood (profiles/r4_two_process_determinism.txt). The chain runs once per utterance: the guard costs ~50 us and turns a silent
+  // 1e-3-level perturbation of the whole sampling loop into either the right values or an error.
+  const size_t nss = (size_t)n * nres * 2 * C;
+  TTS_HIP(ctx, st->ss_chk.reserve(nss * 4 + 4));
+  int *flag = (int *)(st->ss_chk.as<float>() + nss);
+  bool agreed = false;
+  for (int attempt = 0; attempt < 64 && !agreed; attempt++) {
+    mlp(st->ss_all.as<float>());
+    mlp(st->ss_chk.as<float>());
+    TTS_HIP(ctx, hipMemsetAsync(flag, 0, 4, ctx->stream));
+    differ_kernel<<<64, 256, 0, ctx->stream>>>(st->ss_all.as<unsigned>(), st->ss_chk.as<unsigned>(), nss, flag);
+    int h = 1;
+    TTS_HIP(ctx, hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    agreed = h == 0;
+    if (!agreed) ctx->time_mlp_retries++;
   }
+  if (!agreed) return fail(ctx, TTS_ERR_HIP, "the timestep MLP did not evaluate to the same values twice in 64 attempts");
   TTS_HIP(ctx, hipGetLastError());
+  DBG_SUM("time temb", st->temb.p, (size_t)n * C * 4);
+  DBG_SUM("time e1", st->e1.p, (size_t)n * C * 4);
+  DBG_SUM("time emb", st->emb.p, (size_t)n * C * 4);
+  DBG_SUM("time ss_all", st->ss_all.p, (size_t)n * nres * 2 * C * 4);
   return TTS_OK;
 }
 
@@ -1374,12 +1468,15 @@ static int network_forward(tts_ctx *ctx, DiffState *st, const float *ss) {
   // inp_block: conv k3 100(->128) -> 1024 on x_t, output rounded to fp16 (operand of the next conv)
   GemmArgs gi = gemm_base(lay, st->xt16.as<__half>() + XTC, XTC, 3, XTC, st->inp_w, C, st->inp_bias);
   gi.mode = GEMM_OUT_F16; gi.outH = inp16; gi.ldh = C;
+  DBG_SUM("ce16", ce16, (size_t)lay.rows * C * 2);
   CHECK(gemm(ctx, "diff_gemm", gi, lay, 0, 300));
+  DBG_SUM("inp16", inp16, (size_t)lay.rows * C * 2);
   // integrating conv k1 over concat[inp | code_emb]
   GemmArgs gc = gemm_base(lay, inp16, C, 2, C, st->integ_w, C, st->integ_bias);
   gc.A[1] = ce16;
   gc.mode = GEMM_OUT_F32; gc.outF = wk.X(); gc.ldo = C; gc.resid = nullptr;
   CHECK(gemm(ctx, "diff_gemm", gc, lay));
+  DBG_SUM("integ conv", wk.X(), (size_t)lay.rows * C * 4);
   for (int i = 0; i < st->n_main; i++, j++) {
     CHECK(res_block(ctx, st, lay, wk, wk.X(), st->main_res[i], ss + (size_t)j * 2 * C));
     CHECK(attention_block(ctx, st, lay, wk, wk.X(), st->main_attn[i]));
@@ -1388,7 +1485,10 @@ static int network_forward(tts_ctx *ctx, DiffState *st, const float *ss) {
   CHECK(gn_fused(ctx, lay, wk.X(), st->outn_g, st->outn_b, nullptr, 1, wk.A16()));
   GemmArgs go = gemm_base(lay, wk.A16(), C, 3, C, st->out_w, 256, st->out_bias);
   go.mode = GEMM_OUT_F32; go.outF = st->net.as<float>(); go.ldo = 256; go.resid = nullptr;
-  return gemm(ctx, "diff_gemm", go, lay, 200, 0);
+  DBG_SUM("out gn", wk.A16(), (size_t)lay.rows * C * 2);
+  CHECK(gemm(ctx, "diff_gemm", go, lay, 200, 0));
+  DBG_SUM("net", st->net.p, (size_t)lay.rows * 256 * 4);
+  return TTS_OK;
 }
 
 // Sets up layouts/buffers for B candidates (cond + optionally uncond copies) and the code embedding.
