@@ -1,4 +1,4 @@
-"""Developer probe: per-launch buffer hashes (debug library, -DTTS_DEBUG_CHECKSUM) of ONE diffusion forward, repeated while another process keeps the GPU
+"""Developer probe (build the debug library first: tools/build_debug_lib.sh): per-launch buffer hashes (-DTTS_DEBUG_CHECKSUM) of ONE diffusion forward, repeated while another process keeps the GPU
 busy; prints the first launch whose output differs from the first repetition's."""
 import os, subprocess, sys, time, tempfile
 import numpy as np
