@@ -17,6 +17,15 @@ if os.environ.get("NOLOAD") is None:
     load = subprocess.Popen([sys.executable, "-c", "import sys, os, ctypes; sys.path.insert(0, %r)\nif os.environ.get('LOADPAD'):\n    hip = ctypes.CDLL('libamdhip64.so'); pp = ctypes.c_void_p(); print('pad', hip.hipMalloc(ctypes.byref(pp), ctypes.c_size_t(int(os.environ['LOADPAD']) << 20)), hex(pp.value or 0), flush=True)\nimport tortoise_cpp_amd_loader as l, numpy as np; pkg = l.load(); e = pkg.Engine(0); e.load(%r); rs = np.random.RandomState(0)\nwhile True:\n    e.diffusion([rs.randn(30, 1024).astype(np.float32) for _ in range(4)], n_steps=6, noise_mode=pkg.NOISE_DEVICE)" % (ROOT, src)],
                             stderr=subprocess.DEVNULL)  # LOADPAD=<MB>: the other process first allocates a dummy buffer, so that its buffers get other virtual addresses
     time.sleep(12)
+if os.environ.get("VICTIMPAD"):  # this process first takes VICTIMPAD small device allocations, so that its small buffers get other virtual addresses than the load's
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    keep = []
+    for i in range(int(os.environ["VICTIMPAD"])):
+        pp = ctypes.c_void_p()
+        hip.hipMalloc(ctypes.byref(pp), ctypes.c_size_t(4096 * (1 + i % 7)))
+        keep.append(pp)
+    print("victim pad:", len(keep), "allocations, first", hex(keep[0].value or 0), "last", hex(keep[-1].value or 0))
 rs = np.random.RandomState(1)
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 43
 reps = 30
