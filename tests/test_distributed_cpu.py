@@ -213,3 +213,19 @@ def test_cli_devices_worker_bookkeeping_without_a_gpu(tmp_path):
     # candidates must divide over the devices
     r = subprocess.run(base + ["--devices", "3", "--output", str(tmp_path / "y.wav")], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "does not divide" in r.stderr
+
+
+def test_cli_option_flag(tmp_path):
+    """`--option key=value` forwards engine options (tts_set_option) before the models load; workers inherit it; a malformed or unknown option fails loudly."""
+    exe = os.path.join(ROOT, "tortoise.cpp_amd", "tortoise")
+    if not os.path.exists(exe):
+        pytest.skip("CLI binary not built")
+    models = os.path.join(ROOT, "models")
+    base = [exe, "--dry-run", "1", "--models", models, "--voice", os.path.join(models, "mol.bin"), "--seed", "11", "--codes", "5", "--candidates", "2",
+            "--output", str(tmp_path / "o.wav")]
+    r = subprocess.run(base + ["--option", "device_topk=0", "--option", "attn_f32=1", "--devices", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run(base + ["--option", "attn_f32"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "key=value" in r.stderr
+    r = subprocess.run(base + ["--option", "no_such_option=1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0, r.stdout + r.stderr
