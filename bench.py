@@ -521,6 +521,9 @@ def main():
         "other_share_uncond_setting": other,
         "ar_f32_default_rerun": f32_rerun,
         "ar_device_topk_option": topk,
+        # evaluations of the diffusion timestep MLP that disagreed with their repetition (the evaluate-twice guard): 0 unless another
+        # process shares this GPU
+        "diffusion_time_mlp_retries": (None if a.dry_engine else int(eng.time_mlp_retries())),
         "ar_weights_f16_option": f16,
         "ar_weights_fp8_option": fp8,
         "reference_precision_option": ref_prec,
