@@ -309,7 +309,8 @@ def main():
                 audio = [np.full(100 + int(i) % 7, float(i), np.float32) for i in ids]
                 rows, Ts = np.full(B, 200), [870] * B
                 shape.update(L=200, T=870, ids=[int(i) for i in ids])
-                print("DRY_IDS rank %d prompt %d pass %d: %s" % (rank, p, it, " ".join(str(int(i)) for i in ids)), file=sys.stderr)
+                # one os.write per line: the ranks share stderr, and print() may split a line into several writes that interleave with the other rank's
+                os.write(2, ("DRY_IDS rank %d prompt %d pass %d: %s\n" % (rank, p, it, " ".join(str(int(i)) for i in ids))).encode())
             else:
                 t_a = time.time()
                 codes, rows, lats, steps = eng.autoregressive(prompts[p], voice, B, S, mask_stop=True)
