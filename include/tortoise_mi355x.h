@@ -204,8 +204,9 @@ enum { TTS_NOISE_REFERENCE = 0, TTS_NOISE_DEVICE = 1 };
 int tts_diffusion(tts_ctx *ctx, const float *latents, const int32_t *rows, int n_candidates,
                   int n_steps, const float *noise, int noise_mode, float *mel_out);
 /* The timestep MLP (main.cpp:3331-3343, 3410-3428: five tiny launches at the start of every tts_diffusion / tts_diffusion_forward call) is evaluated twice
- * and compared bit for bit, and repeated when the two evaluations disagree — observed only while a second process uses the same GPU.
- * Number of disagreeing evaluations since the context was created (0 in every single-process run). */
+ * and compared bit for bit, and repeated when the two evaluations disagree: a tripwire kept from round 4, when an earlier form of that kernel (packed f32 FMAs)
+ * returned wrong sums while a second engine process used the same GPU. Number of disagreeing evaluations since the context was created:
+ * 0 in every single-process run, and 0 beside a second process since the kernel was rebuilt. */
 int tts_diffusion_time_mlp_retries(const tts_ctx *ctx);
 
 /* ---- vocoder stage -------------------------------------------------------------------------- */

@@ -143,6 +143,6 @@ def test_device_noise_is_deterministic_and_normal(engine, small_models, pkg):
 
 
 def test_time_mlp_guard_is_silent_in_a_single_process(engine):
-    """The timestep MLP is evaluated twice per call and repeated on disagreement (diffusion.hip: precompute_time; DESIGN.md section 6: two evaluations
-    were seen to disagree only while a second engine process shared the GPU). Every call of this module ran alone: not one repetition."""
+    """The timestep MLP is evaluated twice per call and repeated on disagreement (diffusion.hip: precompute_time; DESIGN.md section 6: a tripwire kept from the
+    round-4 hunt for the packed-FMA fault that a second engine process on the same GPU exposed). Every call of this module ran alone: not one repetition."""
     assert engine.time_mlp_retries() == 0

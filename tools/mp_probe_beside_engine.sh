@@ -17,6 +17,6 @@ while True:
 PY
 LOADPID=$!
 sleep 14
-tools/bin/mp_corruption_probe 12 cold48 48
-tools/bin/mp_corruption_probe 6 hot1 1
+for v in 16 32 2; do tools/bin/mp_corruption_probe 11 "engine-kernel-variant-$v" 24 $v | tail -3; done
+
 kill $LOADPID

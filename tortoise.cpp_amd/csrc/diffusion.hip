@@ -1315,45 +1315,45 @@ __device__ __forceinline__ float wave_sum_dpp(float x) {
   return x;
 }
 
-// out[r][n] = sum_k x[r][k] * W[n][k] + b[n] for small row counts (time MLP, emb_layers):
-// one wave per output column, 16-byte loads along K, shuffle reduction. F32 exact (reference: F32 mul_mat).
-// A workgroup (16 waves x 2 columns) owns 32 CONSECUTIVE columns = one whole 128-byte line of every output row (round 4; before, eight workgroups — one per
-// XCD — wrote 16 bytes each into every line). `act`: the time MLP's SiLU applied by the producer.
+// out[r][n] = sum_k x[r][k] * W[n][k] + b[n] for small row counts (time MLP, emb_layers), K = 1024:
+// one wave per output column — a lane keeps its 16 weights of the column in registers and the rows are walked one at a time (16-byte loads along K, wave
+// reduction on permlane swaps + DPP rotations, same pairs in the same order as the shuffle butterfly). F32 exact (reference: F32 mul_mat).
+// A workgroup (16 waves x 2 columns) owns 32 CONSECUTIVE columns = one whole 128-byte line of every output row. `act`: the time MLP's SiLU applied by the producer.
+// Round 4: the previous form of this kernel (8 clamped rows per pass) compiled to v_pk_fma_f32 (packed f32 FMA with op_sel broadcasts), and THAT instruction
+// returned wrong sums — in a wave or two per few hundred launches — whenever a second engine process (MFMA kernels) ran on the same GPU; the same kernel on
+// v_fmac_f32 never did (profiles/r4_two_process_determinism.txt: 217 wrong launches of 38 518 against 0 of 37 952, same loads, same clamps, same reduction).
+// The sums are the same f32 chains as before, bit for bit; this form has no packed f32 arithmetic (checked in the ISA).
 static constexpr int LNK_COLS = 32;
 static __global__ __launch_bounds__(1024) void linear_nk_kernel(const float *__restrict__ x, int ldx, int rows, const float *__restrict__ W,
-                                                         int K, int N, const float *__restrict__ b, float *__restrict__ out, int ldo,
-                                                         int act /*0 none, 1 SiLU (exact expf and division), 2 SiLU through fp16 on both sides (ggml's table)*/
-) {
+                                                         int N, const float *__restrict__ b, float *__restrict__ out, int ldo,
+                                                         int act /*0 none, 1 SiLU (exact expf and division), 2 SiLU through fp16 on both sides (ggml's table)*/) {
   const int lane = threadIdx.x & 63;
   for (int half = 0; half < 2; half++) {
     const int n = blockIdx.x * LNK_COLS + half * 16 + (threadIdx.x >> 6);
     if (n >= N) return;
-    const float *wr = W + (size_t)n * K;
-    for (int r0 = 0; r0 < rows; r0 += 8) {
-      float acc[8];
+    const float *wr = W + (size_t)n * C + lane * 4;
+    float4 w[4]; // k = 256 j + 4 lane + (0..3)
 #pragma unroll
-      for (int i = 0; i < 8; i++) acc[i] = 0.f;
-      for (int k = lane * 4; k < K; k += 256) {
-        const float4 w = *(const float4 *)(wr + k);
+    for (int j = 0; j < 4; j++) w[j] = *(const float4 *)(wr + j * 256);
+    const float bn = b ? b[n] : 0.f;
+    for (int r = 0; r < rows; r++) {
+      const float *xr = x + (size_t)r * ldx + lane * 4;
+      float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-          const float4 xv = *(const float4 *)(x + (size_t)min(r0 + i, rows - 1) * ldx + k);
-          acc[i] = fmaf(xv.x, w.x, acc[i]); acc[i] = fmaf(xv.y, w.y, acc[i]);
-          acc[i] = fmaf(xv.z, w.z, acc[i]); acc[i] = fmaf(xv.w, w.w, acc[i]);
-        }
+      for (int j = 0; j < 4; j++) {
+        const float4 xv = *(const float4 *)(xr + j * 256);
+        acc = fmaf(xv.x, w[j].x, acc); acc = fmaf(xv.y, w[j].y, acc);
+        acc = fmaf(xv.z, w[j].z, acc); acc = fmaf(xv.w, w[j].w, acc);
       }
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        float v = wave_sum_dpp(acc[i]);
-        if (lane == 0 && r0 + i < rows) {
-          v += b ? b[n] : 0.f;
-          if (act) { // the time MLP's SiLU, applied by the producer: no address of these vectors ever holds a second version of itself
-            if (act == 2) v = __half2float(__float2half_rn(v));
-            v = v / (1.f + expf(-v));
-            if (act == 2) v = __half2float(__float2half_rn(v));
-          }
-          out[(size_t)(r0 + i) * ldo + n] = v;
+      float v = wave_sum_dpp(acc);
+      if (lane == 0) {
+        v += bn;
+        if (act) { // the time MLP's SiLU, applied by the producer: no address of these vectors ever holds a second version of itself
+          if (act == 2) v = __half2float(__float2half_rn(v));
+          v = v / (1.f + expf(-v));
+          if (act == 2) v = __half2float(__float2half_rn(v));
         }
+        out[(size_t)r * ldo + n] = v;
       }
     }
   }
@@ -1379,23 +1379,22 @@ static int precompute_time(tts_ctx *ctx, DiffState *st, const std::vector<int> &
   // activation kernel, and no address of these vectors ever holds two versions of itself within a call.
   const int act = ctx->ggml_lut ? 2 : 1;
   auto mlp = [&](float *ss_out) {
-    linear_nk_kernel<<<C / LNK_COLS, 1024, 0, ctx->stream>>>(st->temb.as<float>(), C, n, st->te0_w, C, C, st->te0_b, st->e1.as<float>(), C, act);
-    linear_nk_kernel<<<C / LNK_COLS, 1024, 0, ctx->stream>>>(st->e1.as<float>(), C, n, st->te2_w, C, C, st->te2_b, st->emb.as<float>(), C, act);
+    linear_nk_kernel<<<C / LNK_COLS, 1024, 0, ctx->stream>>>(st->temb.as<float>(), C, n, st->te0_w, C, st->te0_b, st->e1.as<float>(), C, act);
+    linear_nk_kernel<<<C / LNK_COLS, 1024, 0, ctx->stream>>>(st->e1.as<float>(), C, n, st->te2_w, C, st->te2_b, st->emb.as<float>(), C, act);
     for (int j = 0; j < nres; j++) {
       const ResDev &w = j < st->n_integ ? st->integ_res[j] : j < st->n_integ + st->n_main ? st->main_res[j - st->n_integ]
                                                                                           : st->tail_res[j - st->n_integ - st->n_main];
       // out row i -> ss[(i*nres + j)*2048]
-      linear_nk_kernel<<<2 * C / LNK_COLS, 1024, 0, ctx->stream>>>(st->emb.as<float>(), C, n, w.emb_w, C, 2 * C, w.emb_b, ss_out + (size_t)j * 2 * C,
+      linear_nk_kernel<<<2 * C / LNK_COLS, 1024, 0, ctx->stream>>>(st->emb.as<float>(), C, n, w.emb_w, 2 * C, w.emb_b, ss_out + (size_t)j * 2 * C,
                                                                  nres * 2 * C, 0);
     }
   };
-  // Evaluated TWICE and compared bit for bit; repeated until two evaluations agree. Round 4 found that this chain of tiny launches — the first kernels
-  // behind the host transfers of a call — returns 5 .. 40 consecutive wrong outputs in 10-30 % of the calls WHILE A SECOND ENGINE PROCESS USES THE SAME GPU
-  // (never otherwise; every other launch of the stage hashed identical in the same runs; a stand-alone probe with this kernel shape does not reproduce
-  // it). Kernel overlap, stale kernel arguments, cross-XCD line sharing, the LDS crossbar and in-place updates were each excluded by an experiment; the
-  // cause is not understood (profiles/r4_two_process_determinism.txt). The chain runs once per utterance: the guard costs ~50 us and turns a silent
-  // 1e-3-level perturbation of the whole sampling loop into either the right values or an error.
-#ifdef TTS_DEBUG_NO_TIME_GUARD // developer build (tools/build_debug_lib.sh noguard): one evaluation, so that the probes see the fault itself
+  // Evaluated TWICE and compared bit for bit; repeated until two evaluations agree. Round 4: while a second engine process used the same GPU, the previous form
+  // of linear_nk_kernel returned a few wrong outputs in 10-30 % of the calls (traced to its packed f32 FMAs, see the kernel and
+  // profiles/r4_two_process_determinism.txt; the present form has none and ran clean without this guard). The guard stays as a tripwire: the chain runs once per
+  // utterance (~50 us), a silent 1e-3-level perturbation of the whole sampling loop becomes either the right values or an error, and
+  // tts_diffusion_time_mlp_retries() says if it ever fired.
+#ifdef TTS_DEBUG_NO_TIME_GUARD // developer build (tools/build_debug_lib.sh noguard): one evaluation, so that the probes see a fault itself
   mlp(st->ss_all.as<float>());
   if (false) {
 #else
