@@ -1,6 +1,6 @@
 // Developer microbench for the diffusion attention kernel: bench-shaped batch (32 sequences x 870 rows, 16 heads),
 // steady-state time per launch and per-tile phase timestamps (shader cycles) of wave 0 of one workgroup.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -DTTS_ATT_TRACE=100 -I include -I tortoise.cpp_amd/csrc \
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -DTTS_ATT_TRACE=100 -I include -I tortoise.cpp_amd/csrc -I tools/attic \
 //         tools/attn_bench.hip tortoise.cpp_amd/csrc/host_logic.cpp -o tools/attn_bench_bin   (TTS_ATT_TRACE = traced workgroup id)
 #include "../tortoise.cpp_amd/csrc/diffusion.hip"
 #include "attn_r3_kernel.h"

@@ -3,7 +3,7 @@
 // operands, printed beside the guide's reference table (cdna_hip_programming.md "Reference targets": 128^2 + XCD swizzle 912 / 948 TF on
 // zero-filled operands, the 256^2 8-phase template ~1330 / ~1470 TF on random operands), and on the benchmark's own shapes, so that
 // "my shapes are hard" (K = 1024, N = 1024, f32 epilogue) and "my 8-phase kernel is slow" can be told apart.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I tortoise.cpp_amd/csrc -I tools tools/gemm_cube_bench.hip -o tools/bin/gemm_cube_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I tortoise.cpp_amd/csrc -I tools -I tools/attic tools/gemm_cube_bench.hip -o tools/bin/gemm_cube_bench
 //   tools/bin/gemm_cube_bench [zero]        ("zero": zero-filled operands as well, the guide's headline fill)
 #include "gemm_f16.h"
 #include "gemm_f16_big.h"

@@ -4,7 +4,7 @@
 // -DBIG_STAGGER=0/1 -DBIG_PREFETCH=0/1 for its variants). Every output is compared bit for bit with the round-2 kernel's; timings are interleaved rounds in one
 // process (median and min). (The per-tile phase stamps and the K-loop ablation builds of round 3 — profiles/r3_gemm_epilogue.txt, r3_gemm_kloop_ablation.txt — needed instrumentation
 // inside csrc/gemm_f16.h; it was removed from the product header in round 4, the results stay in profiles/.)
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I tortoise.cpp_amd/csrc -I tools tools/gemm_tab_bench.hip -o tools/bin/gemm_tab_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I tortoise.cpp_amd/csrc -I tools -I tools/attic tools/gemm_tab_bench.hip -o tools/bin/gemm_tab_bench
 //   tools/bin/gemm_tab_bench [shape-filter] [policy ...]      e.g.  tools/bin/gemm_tab_bench conv3 arith=0 u7=7 mix=8,6/8/0 big=0
 //   results: profiles/r3_gemm_tile_tables.txt, r3_gemm_epilogue.txt, r3_gemm_256col_kernel.txt
 #define tts tts_r2 // the round-2 one-tile-per-workgroup kernels, for reference output and timing

@@ -109,9 +109,58 @@ def run_problem(path, latents, noise, steps):
     return {"T": int(T), "L": int(L), "steps": int(steps), "oracle_vs_t32": float(d.max()), "oracle_vs_t32_mean": float(d.mean())}
 
 
+ABLATION_SETS = ("", "qk", "v", "p", "o", "w",                                   # the reference's F32 block; each rounding alone
+                 "qk,v", "qk,v,p", "qk,v,p,o",                                    # cumulative ladder towards the throughput mode
+                 "v,p,o,w", "v,p,w", "v,p", "p,w", "v,w", "o,w",                   # candidates for a cheaper floor-level mode (qk kept in f32 first)
+                 "qk,v,p,o,w")                                                    # = the engine's throughput mode (f16_attention=True)
+
+
+def ablate(kind, L, seed, steps=80, sets=None):
+    """the 80-step distance from the ORACLE of a torch-f32 evaluation in which a chosen subset of the engine's five fp16 roundings
+    (tests/torch_ref.py: qk, v, p, o, w) is applied inside the AttentionBlock. Same latents / noise for every subset; recorded under rec[kind]["ablation"]."""
+    sets = sets or [x.replace("+", ",") for x in os.environ.get("TTS_ABLATION_SETS", "").split(":") if x] or ABLATION_SETS
+    sets = ["" if x == "none" else x for x in sets]
+    path = ensure_models(kind)
+    od = O.Diffusion(O.Model(path))
+    T = od.T_of(L)
+    rs = np.random.RandomState(seed)
+    lat = rs.randn(L, 1024).astype(np.float32)
+    noise = rs.randn(steps + 1, 100 * T).astype(np.float32)
+    tm = O.default_timestep_map(steps)
+    ce = od.code_embedding(lat, T)
+    want = od.sample(lat, steps, noise=noise.reshape(-1))
+    rec = json.load(open(FLOOR_JSON))
+    ab = rec[kind].setdefault("ablation", {})
+    key = "L=%d,seed=%d,steps=%d" % (L, seed, steps)
+    row = ab.setdefault(key, {"T": int(T)})
+    for st in sets:
+        name = st or "none"
+        if name in row:
+            continue
+        net = TR.TorchDiffusion(path, O.buckets, f16_attention=st)  # "" = the reference's F32 block
+        x = noise[0].copy()
+        for idx in range(steps):
+            t = steps - 1 - idx
+            te = O.timestep_embedding(int(tm[t]))
+            xc = x.reshape(100, T)
+            x = O.diffusion_update(tm, t, net.forward(ce, xc, te), net.forward(None, xc, te), x, noise[idx + 1], T)
+        d = np.abs(x.reshape(100, T) - want)
+        row[name] = {"max": float(d.max()), "mean": float(d.mean())}
+        print(kind, key, "%-12s max %.3e mean %.3e" % (name, d.max(), d.mean()), flush=True)
+        rec = json.load(open(FLOOR_JSON))
+        rec[kind].setdefault("ablation", {})[key] = row
+        json.dump(rec, open(FLOOR_JSON, "w"), indent=1)
+
+
 def main():
     torch.set_num_threads(int(os.environ.get("TTS_FLOOR_THREADS", "4")))
     O.build()
+    if "--ablate" in sys.argv:  # python tools/regen_parity_floor.py --ablate full:L=20,seed=9 mid:L=12,seed=5
+        for spec in sys.argv[sys.argv.index("--ablate") + 1:]:
+            kind, kv = spec.split(":")
+            kw = {k: int(v) for k, v in (p.split("=") for p in kv.split(","))}
+            ablate(kind, kw["L"], kw.get("seed", 5), kw.get("steps", 80))
+        return
     rec = json.load(open(FLOOR_JSON))
     args = sys.argv[1:]
     extra = {}

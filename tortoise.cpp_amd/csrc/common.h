@@ -101,6 +101,7 @@ struct tts_ctx {
   int ar_weights = 0;      // option "ar_weights": 0 = f32 weights in the decode step (reference numerics), 1 = fp16 weights, 2 = OCP fp8 (e4m3) weights with a power-of-two scale per output column (set before tts_load_ar)
   int dec_f32_mfma = 0;    // option "dec_f32_mfma": the decode step's LayerNorm-GEMVs use exact-f32 MFMA products instead of split fp16 (set before tts_load_ar; +1 us per launch)
   int attn_f32 = 0;        // option "attn_f32": the diffusion AttentionBlock in reference precision (F32 QK^T / softmax / PV / proj_out, main.cpp:3848-3875) via split-fp16 MFMA operands; 0 = fp16 operands (throughput mode)
+  int attn_proj_f16 = 0;   // option "attn_proj_f16": 1 = proj_out's weight as ONE fp16 operand (the all-fp16 AttentionBlock of rounds 1-4, A/B only); 0 default = split pair W_hi + W_lo (F32-accurate weight, round 5)
   bool capturing = false;  // a hipGraph is being captured on the stream: ProfScope records nothing (event records would become graph nodes)
   int diff_graph = 1;      // option "diff_graph": the diffusion step is captured once per call and replayed (0: every step launched eagerly)
   int prof_eager_every = 8; // while a diff_* family is profiled, every Nth diffusion step runs eagerly with its event pairs; the others replay the graph

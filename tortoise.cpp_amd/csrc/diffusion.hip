@@ -1063,7 +1063,8 @@ static int gemm(tts_ctx *ctx, const char *fam, GemmArgs &g, const Layout &lay, i
   if (!strcmp(fam, "diff_gemm")) {
     if (g.mode == GEMM_OUT_QKV) fam = "diff_gemm_qkv";                                              // N = 3072, K = 1024, fp16 out
     else if (gemm_is_conv3(g) && g.N == C && g.kseg == C) fam = g.resid ? "diff_gemm_k3r" : "diff_gemm_k3"; // out_layers / latent conditioner conv
-    else if (g.nseg == 1 && g.N == C && g.kseg == C && g.mode == GEMM_OUT_F32) fam = g.resid ? "diff_gemm_k1r" : "diff_gemm_k1"; // proj_out / in_layers
+    else if (g.nseg == 1 && g.N == C && g.kseg == C && g.mode == GEMM_OUT_F32) fam = g.resid ? "diff_gemm_k1r" : "diff_gemm_k1"; // proj_out (option attn_proj_f16) / in_layers
+    else if (g.custom_w && g.N == C && g.kseg == C && g.mode == GEMM_OUT_F32_SCALED && g.resid) fam = "diff_gemm_k1r";                   // proj_out on a split-precision weight (k_valid = C: the product's own FLOPs)
     else fam = "diff_gemm_misc";                                                                    // inp_block, integrating conv, out head
   }
   ProfScope ps(ctx, fam, 2.0 * mv * (n_valid ? n_valid : g.N) * (k_valid ? k_valid : g.nseg * g.kseg));
@@ -1228,14 +1229,21 @@ static int res_in_layers(tts_ctx *ctx, const Layout &lay, Work &wk, const float 
   return TTS_OK;
 }
 
-// AttentionBlock on X (in place). Two arithmetic modes (option attn_f32):
-//   0  throughput mode (north star: "MFMA ... for the dense fp16 GEMMs in attention"): q, k, v, P, the attention output and the
-//      proj_out weight are fp16 MFMA operands, f32 accumulation;
+// AttentionBlock on X (in place). Arithmetic modes (options attn_f32, attn_proj_f16):
+//   0  default (north star: "MFMA ... for the dense fp16 GEMMs in attention"): q, k, v, P and the attention output are fp16 MFMA operands,
+//      f32 accumulation; proj_out's F32 weight is multiplied as the split pair W_hi + W_lo (two MFMAs per product). Round 5: the five fp16
+//      roundings of the rounds 1-4 throughput mode were ablated one at a time in the CPU emulator (tests/golden/parity_floor.json
+//      "ablation", tools/regen_parity_floor.py --ablate): the fp16 rounding of the proj_out WEIGHT alone carries the whole distance to the
+//      oracle above the f32-vs-f32 floor (full depth, 80 steps: mean 1.16e-4 with it alone, 6.5e-5 with the other four together, 5.6e-5 with
+//      none) — it is the one rounding that is the SAME perturbation at every step and in every row; the activation roundings average out.
+//      attn_proj_f16 = 1 restores the all-fp16 block of rounds 1-4 (A/B only);
 //   1  reference precision (main.cpp:3848-3875: F32 QK^T, softmax, PV and proj_out): the same products on split-precision fp16 pairs
 //      (hi + lo, three MFMAs per product, 2^-22 relative) — the parity mode, as ar_weights = 0 is for the AR stage.
 static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, float *X, const AttnDev &w) {
   const bool f32 = ctx->attn_f32 != 0;
-  CHECK(gn_fused(ctx, lay, X, w.norm_g, w.norm_b, nullptr, 0, wk.A16(), w.qkv_w, (size_t)3 * C * C * 2, w.proj_w, (size_t)C * C * 2));
+  const bool pw16 = !f32 && ctx->attn_proj_f16; // weight touch for the two GEMMs that follow: the proj_out matrix this mode will stream
+  CHECK(gn_fused(ctx, lay, X, w.norm_g, w.norm_b, nullptr, 0, wk.A16(), w.qkv_w, (size_t)3 * C * C * 2, pw16 ? w.proj_w : w.proj_w_split,
+                 (size_t)C * C * (pw16 ? 2 : 4)));
   DBG_SUM("attn gn", wk.A16(), (size_t)lay.rows * C * 2);
   GemmArgs g = gemm_base(lay, wk.A16(), C, 1, C, w.qkv_w, 3 * C, w.qkv_b);
   g.mode = f32 ? GEMM_OUT_QKV_SPLIT : GEMM_OUT_QKV;
@@ -1268,6 +1276,14 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
     p.custom_w = 1; p.ldw_ = 2 * C; p.w_off_[0] = 0; p.w_off_[1] = 0; p.w_off_[2] = C;
     p.mode = GEMM_OUT_F32_SCALED; p.alpha = 1.0f / 64.0f; p.outF = X; p.ldo = C; p.resid = X;
     return gemm(ctx, "diff_gemm", p, lay, 0, C);
+  }
+  if (!ctx->attn_proj_f16) { // default: att16 . (W_hi + W_lo)^T — proj_out's F32 weight to 2^-22, the attention output stays one fp16 operand
+    GemmArgs p = gemm_base(lay, wk.ATT16(), C, 2, C, w.proj_w_split, C, w.proj_b);
+    p.custom_w = 1; p.ldw_ = 2 * C; p.w_off_[0] = 0; p.w_off_[1] = C;
+    p.mode = GEMM_OUT_F32_SCALED; p.alpha = 1.0f / 64.0f; p.outF = X; p.ldo = C; p.resid = X;
+    CHECK(gemm(ctx, "diff_gemm", p, lay, 0, C));
+    DBG_SUM("attn proj", X, (size_t)lay.rows * C * 4);
+    return TTS_OK;
   }
   GemmArgs p = gemm_base(lay, wk.ATT16(), C, 1, C, w.proj_w, C, w.proj_b);
   p.mode = GEMM_OUT_F32; p.outF = X; p.ldo = C; p.resid = X;

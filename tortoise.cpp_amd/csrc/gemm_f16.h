@@ -273,16 +273,19 @@ __device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, 
   // Accumulators START from the residual (F32 outputs, swapped operand order: acc[i][j] = 4 consecutive columns of one row): the
   // residual read is issued with the first operand tile and hides behind it, instead of being a dependent HBM round trip in front
   // of the stores when the K loop is over. The sum is the same set of f32 adds in a different order.
-  const bool resid_first = MODE == GEMM_OUT_F32 && g.resid != nullptr;
+  // GEMM_OUT_F32_SCALED (out = alpha acc + bias + resid, alpha a power of two): the accumulators start from resid / alpha — exact, and scaled back
+  // exactly by the epilogue.
+  const bool resid_first = gemm_mode_f32(MODE) && g.resid != nullptr;
   floatx4 acc[MA][4];
   if (resid_first) {
+    const float rs = MODE == GEMM_OUT_F32_SCALED ? 1.0f / g.alpha : 1.0f;
 #pragma unroll
     for (int i = 0; i < MI; i++) {
       const int row = m0 + vh_blk(wm, i) * 16 + fr;
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const float4 rr = *(const float4 *)(g.resid + (size_t)row * g.ldo + n0 + wn * 64 + j * 16 + fq * 4);
-        acc[i][j] = (floatx4){rr.x, rr.y, rr.z, rr.w};
+        acc[i][j] = (floatx4){rr.x * rs, rr.y * rs, rr.z * rs, rr.w * rs};
       }
     }
   } else {
@@ -334,7 +337,6 @@ __device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, 
   if (gemm_mode_qkv(MODE) && natural) kloop(std::true_type{});
   else kloop(std::false_type{});
   if (resid_first) gemm_epilogue_vh<MODE, MI, EPI_RESID_IN_ACC>(g, acc, m0, n0, wm, wn, fr, fq);
-  else if (MODE == GEMM_OUT_F32_SCALED && g.resid) gemm_epilogue_vh<MODE, MI, EPI_RESID_LOAD>(g, acc, m0, n0, wm, wn, fr, fq);
   else gemm_epilogue_vh<MODE, MI, EPI_NO_RESID>(g, acc, m0, n0, wm, wn, fr, fq);
 }
 
