@@ -206,6 +206,7 @@ def main():
     ap.add_argument("--models", default=None)
     ap.add_argument("--device-map", default=None, help="comma list: HIP device of each local rank (default: LOCAL_RANK). `--backend gloo --device-map 0,0` "
                                                        "runs two real engines on one GPU (test of the N > 1 path on a one-GPU box; RCCL needs one GPU per rank)")
+    ap.add_argument("--allow-shared-device", action="store_true", help="let two ranks create their engine on ONE GPU (unsupported form; one-GPU test boxes only)")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -222,6 +223,8 @@ def main():
             sys.exit("bench.py: --device-map has %d entries, local rank %d" % (len(dm), local_rank))
         if a.backend == "nccl" and len(set(dm)) != len(dm):
             sys.exit("bench.py: RCCL needs a distinct GPU per rank (--device-map %s); use --backend gloo to share a device" % a.device_map)
+        if len(set(dm)) != len(dm) and not (a.allow_shared_device or a.dry_engine):
+            sys.exit("bench.py: --device-map %s puts two engine processes on one GPU: unsupported (DESIGN.md section 6); --allow-shared-device to run anyway" % a.device_map)
         device = dm[local_rank]
     pkg = tortoise_cpp_amd_loader.load()
     model_dir = a.models or ("/tmp/tts_bench_models_quick" if a.quick else "/tmp/tts_bench_models")
@@ -397,6 +400,7 @@ def main():
         o_audio, o_dt, o_stages = timed(1, not share)
         other = {"uncond_integrator_shared": not share, "value": round(o_audio / o_dt, 3), "ms_per_step": round(1000.0 * o_dt, 2),
                  "stage_ms_per_step": o_stages}
+        eng.set_option("share_uncond", 1 if share else 0)  # (rounds 1-4 left the other setting on for the option passes below)
     if not a.dry_engine:
         eng.prof_reset(False)
     # the reference-precision mode of the diffusion stage (option attn_f32 = 1: F32 AttentionBlock as main.cpp:3848-3875 on split-fp16 MFMA
@@ -473,6 +477,77 @@ def main():
                                      "fp8": "fp8 e4m3 decode weights change the logits by ~5e-2"}[tag] +
                                     ": sampled ids follow the f32 run until the first draw that lands on the other side of a CDF edge"}
         f16, fp8 = reports["f16"], reports["fp8"]
+    # ---- what a real batch looks like, outside the headline's timed region like the other A/B passes -------------------------
+    ragged = single_ms = first_audio = clvp = None
+    if world == 1 and not a.no_ab and not a.dry_engine and a.config == 3:
+        eng.set_option("share_uncond", 1)
+        # (a) RAGGED batch: trained weights stop every candidate at its own step (main.cpp:5188-5249); random-init ones never stop, so a stop SCHEDULE
+        # (tts_ar_set_stop_schedule) ends candidate b after 0.61 S .. S codes. Decode steps then carry retired candidates (TTS_AR_RETIRE), the latent pass,
+        # the diffusion row space (no two unconditioned sequences of one length to share) and the vocoder batch have B different lengths.
+        stop_at = [int(round(S * (0.61 + 0.39 * b / max(1, B - 1)))) for b in range(B)]
+        eng.set_stop_schedule(stop_at)
+        try:
+            for rep in range(2):  # the first pass sizes the buffers and captures the graphs of these shapes
+                eng.seed(777)
+                t_a = time.time()
+                codes_r, rows_r, lats_r, steps_r = eng.autoregressive(prompts[0], voice, B, S, mask_stop=True, retire=True)
+                t_b = time.time()
+                mels_r = eng.diffusion(lats_r, n_steps=n_diff, noise_mode=pkg.NOISE_DEVICE)
+                t_c = time.time()
+                eng.vocoder(mels_r, noise_mode=pkg.NOISE_DEVICE)
+                t_d = time.time()
+        finally:
+            eng.set_stop_schedule(None)
+        Ts_r = [int(m.shape[1]) for m in mels_r]
+        aud_r = sum(t * 256 for t in Ts_r) / 24000.0
+        ragged = {"value": round(aud_r / (t_d - t_a), 3), "unit": "audio-seconds/sec", "ms_per_step": round(1e3 * (t_d - t_a), 2),
+                  "stage_ms": {"ar": round(1e3 * (t_b - t_a), 1), "diffusion": round(1e3 * (t_c - t_b), 1), "vocoder": round(1e3 * (t_d - t_c), 1)},
+                  "codes_per_candidate": stop_at, "latent_rows": [int(r) for r in rows_r], "mel_frames": Ts_r, "decode_iterations": int(steps_r),
+                  "audio_seconds": round(aud_r, 3),
+                  "note": "16 candidates stopped by schedule after 0.61 S .. S codes (TTS_AR_MASK_STOP | TTS_AR_RETIRE): ragged decode, latent pass, diffusion and "
+                          "vocoder shapes; second of two passes. tests/test_ragged_gpu.py: every candidate of this batch equals the candidate run alone"}
+        # (b) ONE utterance (what ./tortoise runs, main.cpp:6570), (c) time to the first audio: AR + the whole diffusion loop (GroupNorm and attention are global
+        # over the utterance: no chunked diffusion) + ONE vocoder window of 32 frames (tts_vocoder_chunk, 0.34 s of audio) instead of the full vocoder pass
+        tl = []
+        for rep in range(3):
+            eng.seed(31)
+            t_a = time.time()
+            _, _, lats_1, _ = eng.autoregressive(prompts[0], voice, 1, S, mask_stop=True)
+            t_b = time.time()
+            mels_1 = eng.diffusion(lats_1, n_steps=n_diff, noise_mode=pkg.NOISE_DEVICE)
+            t_c = time.time()
+            eng.vocoder(mels_1, noise_mode=pkg.NOISE_DEVICE)
+            t_d = time.time()
+            nz1 = np.random.RandomState(3).randn(64, mels_1[0].shape[1] + 10).astype(np.float32)
+            t_e = time.time()
+            first = eng.vocoder_chunk(mels_1[0], nz1, 0, 32)
+            t_f = time.time()
+            tl.append((t_d - t_a, t_b - t_a, t_c - t_b, t_d - t_c, t_f - t_e))
+        best = min(tl[1:])
+        single_ms = round(1e3 * best[0], 1)
+        first_audio = {"one_utterance_ms": round(1e3 * (best[1] + best[2] + best[4]), 1),
+                       "batch_of_%d_ms" % B: round(stages["ar"] + stages["diffusion"] + 1e3 * best[4], 1),
+                       "stage_ms_one_utterance": {"ar": round(1e3 * best[1], 1), "diffusion": round(1e3 * best[2], 1), "vocoder_full": round(1e3 * best[3], 1),
+                                                  "vocoder_first_window": round(1e3 * best[4], 2)},
+                       "first_window": "%d samples = %.3f s of audio (32 frames + halo)" % (len(first), len(first) / 24000.0),
+                       "note": "AR stage + all %d diffusion steps + the first tts_vocoder_chunk window; the diffusion loop is not chunked (DESIGN.md section 7)" % n_diff}
+        # (d) CLVP re-ranking of the batch (16 candidates only mean something with it; not in the reference): full-size synthetic CLVP weights
+        clvp_path = os.path.join(model_dir, "ggml-clvp-model.bin")
+        if not os.path.exists(clvp_path + ".done"):
+            from tortoise_cpp_amd import synth_weights as sw
+            sw.write_clvp(clvp_path, depth=2 if a.quick else 20, seed=1237)
+            open(clvp_path + ".done", "w").write("ok")
+        eng.load_clvp(clvp_path)
+        eng.seed(1000 * (a.steps - 1))
+        codes_c, _, _, _ = eng.autoregressive(prompts[0], voice, B, S, mask_stop=True, want_latents=False)
+        cl = [codes_c[b, 1:1 + S] for b in range(B)]
+        text_c = prompts[0][prompts[0] < 256]
+        eng.clvp_score(text_c, cl)
+        t0 = time.time()
+        for rep in range(3):
+            sc = eng.clvp_score(text_c, cl)
+        clvp = {"ms": round(1e3 * (time.time() - t0) / 3, 2), "candidates": B, "codes_per_candidate": S, "kept": int(np.argmax(sc)),
+                "note": "tts_clvp_score over the batch's codes (two 20-layer encoders, synthetic weights); not part of the metric"}
     if rank != 0:
         if dist:
             dist.destroy_process_group()
@@ -528,6 +603,7 @@ def main():
         "ar_weights_f16_option": f16,
         "ar_weights_fp8_option": fp8,
         "reference_precision_option": ref_prec,
+        "ragged_batch": ragged, "single_utterance_ms": single_ms, "first_audio_ms": first_audio, "clvp_ms": clvp,
         # the collective backend has seen this many ranks (all_reduce of ones) and rank 0 has gathered this many audio samples in the last pass
         "collective_ranks": collective_ranks, "collective_backend": (a.backend if dist else None), "gathered_samples": shape.get("gathered_samples"),
         "roofline": {"kernel": "gemm_f16_vh_kernel + gemm_f16_conv3_vh_kernel (diffusion convs/projections)", "bound": "mfma",

@@ -41,6 +41,14 @@ typedef enum {
 enum { TTS_VOCAB_MEL = 8194, TTS_DMODEL = 1024, TTS_MEL_CH = 100, TTS_CODES = 502 };
 
 /* ---- lifecycle --------------------------------------------------------------------------- */
+/* Interface version: bumped whenever a prototype in this file changes incompatibly (a caller built against another value must not call in).
+ *   4 = round 4: tts_host_mel_diffusion100 gained `normalize` (voice files written by the earlier tools/make_voice.py hold a NORMALISED mel of
+ *       full-length clips and must be regenerated: INTEGRATION.md "voice files"),
+ *   5 = round 5: tts_ar_set_stop_schedule, tts_version; option "attn_proj_f16"; the default AttentionBlock multiplies proj_out on an F32-accurate
+ *       (split fp16 pair) weight. */
+#define TTS_API_VERSION 5
+int tts_version(void);
+
 /* replaces ggml_backend_cuda_init(0) (main.cpp:651, 1213, 1777). device = HIP ordinal; returns NULL
  * when there is no such device. device = -1 gives a host-only context (tokenizer, RNG, sampler):
  * every stage call on it fails with TTS_ERR_HIP — there is no CPU compute path. */
@@ -76,6 +84,10 @@ const char *tts_last_error(const tts_ctx *ctx);
  * those products runs on split-precision fp16 pairs (x = hi + lo, three MFMAs per product, 2^-22 relative) and SiLU is the reference's f32 formula: the
  * 80-step sampling loop then stays as close to the CPU restatement as a second f32 evaluation of the reference's graph does (tests/golden/parity_floor.json).
  * Costs about 1.5x the diffusion stage's time; may be switched between calls.
+ * "attn_proj_f16" (0 default): the default (throughput) AttentionBlock keeps q, k, v, the softmax numerators and the attention output as fp16 MFMA
+ * operands but multiplies proj_out — an F32 linear in the reference — on its weight held as the split pair W_hi + W_lo (two MFMAs per product). Of the five
+ * fp16 roundings of the rounds 1-4 block only the WEIGHT's survives 80 steps (the same perturbation at every step; tests/golden/parity_floor.json
+ * "ablation"): without it the default mode sits on the f32-vs-f32 floor of the sampling loop. 1 = the all-fp16 block of rounds 1-4 (A/B only).
  * "device_topk" (1 default): tts_autoregressive's decode loop samples from the device prefilter's lists (tts_ar_step_sample); 0 = every step copies
  * the [B][8194] logits to the host as the reference does (main.cpp:4766-4768). Sampled ids are identical either way.
  * "dec_f32_mfma" (0 default; set BEFORE tts_load_ar): the decode step's LayerNorm-GEMV kernels multiply on v_mfma_f32_16x16x4_f32 (exact f32 products)
@@ -170,6 +182,12 @@ enum { TTS_AR_MASK_STOP = 1, TTS_AR_RETIRE = 2 };
 int tts_autoregressive(tts_ctx *ctx, const int32_t *text_ids, int n_text, const float *voice1024,
                        int n_candidates, int max_steps, unsigned flags, int32_t *codes_out,
                        int32_t *rows_out, float *latents_out, int32_t *steps_out);
+/* Stop schedule (benchmark / test device; random-init weights never sample a stop token, trained ones stop at different steps per candidate —
+ * main.cpp:5188-5249): candidate b of the following tts_autoregressive calls samples the stop token 8193 at iteration stop_at[b] (= after stop_at[b]
+ * codes) whatever its logits say; the uniforms are consumed as always. Meant to be combined with TTS_AR_MASK_STOP | TTS_AR_RETIRE: the batch then
+ * becomes RAGGED in a reproducible way (decode steps with retired candidates, a latent pass / diffusion row space / vocoder batch of unequal
+ * lengths). stop_at == NULL or n_candidates == 0 clears it; a call whose candidate count differs from the schedule's fails with TTS_ERR_ARG. */
+int tts_ar_set_stop_schedule(tts_ctx *ctx, const int32_t *stop_at, int n_candidates);
 /* Per candidate of the last tts_autoregressive call: 1 = the sequence ends in a sampled stop token (what main.cpp:5214-5222
  * waits for), 0 = it was cut at max_steps (TTS_AR_RETIRE / TTS_AR_MASK_STOP) and padded like a finished one. */
 int tts_ar_stop_status(tts_ctx *ctx, int32_t *stopped_out, int n_candidates);

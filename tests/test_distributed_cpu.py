@@ -229,3 +229,56 @@ def test_cli_option_flag(tmp_path):
     assert r.returncode != 0 and "key=value" in r.stderr
     r = subprocess.run(base + ["--option", "no_such_option=1"], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0, r.stdout + r.stderr
+
+
+@pytest.fixture(scope="module")
+def fake_rccl(tmp_path_factory):
+    """tests/fake_rccl.cpp -> a shared library with librccl's ten entry points that moves host buffers over Unix sockets (TTS_RCCL_LIB)."""
+    src = os.path.join(ROOT, "tests", "fake_rccl.cpp")
+    so = str(tmp_path_factory.mktemp("fake_rccl") / "libfake_rccl.so")
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I/opt/rocm/include", src, "-o", so], capture_output=True, text=True, timeout=300)
+    if r.returncode != 0:
+        pytest.skip("fake rccl does not build here: " + r.stderr[-500:])
+    return so
+
+
+def test_cli_rccl_exchange_four_ranks_on_the_cpu(tmp_path, fake_rccl):
+    """`tortoise --devices 4 --exchange rccl` with FOUR ranks on a machine without a GPU: --dry-run keeps the staging buffers of
+    csrc/cli_rccl.h on the host and TTS_RCCL_LIB points its dlopen at tests/fake_rccl.cpp, so the N > 1 code of the RCCL exchange executes for the first
+    time anywhere — unique id created by the parent and handed to the workers, conditioning broadcast from rank 0, all-gather of the per-candidate
+    sample counts, one send / receive pair per rank to rank 0, which writes every file. The files equal the `--exchange files` run's and the
+    single process's; with --clvp the winner is the single process's and no per-candidate file is left."""
+    exe = os.path.join(ROOT, "tortoise.cpp_amd", "tortoise")
+    if not os.path.exists(exe):
+        pytest.skip("CLI binary not built")
+    models = os.path.join(ROOT, "models")
+    env = dict(os.environ, TTS_RCCL_LIB=fake_rccl, TMPDIR=str(tmp_path))
+    base = [exe, "--dry-run", "1", "--models", models, "--voice", os.path.join(models, "mol.bin"), "--seed", "23", "--codes", "7", "--candidates", "8"]
+
+    def wav(p):
+        return np.frombuffer(open(p, "rb").read()[44:], np.float32)
+
+    runs = {}
+    for tag, extra in (("one", []), ("files4", ["--devices", "4"]), ("rccl4", ["--devices", "4", "--exchange", "rccl"]), ("rccl2", ["--devices", "2", "--exchange", "rccl"])):
+        out = str(tmp_path / (tag + ".wav"))
+        r = subprocess.run(base + ["--output", out] + extra, capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0, (tag, r.stdout + r.stderr)
+        files = [out] + ["%s.%d.wav" % (out, c) for c in range(1, 8)]
+        assert all(os.path.exists(f) for f in files), (tag, sorted(os.listdir(tmp_path)))
+        runs[tag] = [wav(f) for f in files]
+    for tag in ("files4", "rccl4", "rccl2"):
+        for c in range(8):
+            assert len(runs[tag][c]) == 7 and (runs[tag][c] == runs["one"][c]).all(), (tag, c)
+    picks = {}
+    for tag, extra in (("one", []), ("rccl4", ["--devices", "4", "--exchange", "rccl"])):
+        out = str(tmp_path / ("rr_" + tag + ".wav"))
+        r = subprocess.run(base + ["--output", out, "--clvp", "unused-in-dry-run"] + extra, capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0 and "clvp: candidate" in r.stdout, (tag, r.stdout + r.stderr)
+        picks[tag] = (r.stdout.split("clvp: candidate")[1].split()[0], tuple(wav(out)))
+        assert not [f for f in os.listdir(tmp_path) if f.startswith("rr_" + tag + ".wav.")], os.listdir(tmp_path)
+    assert picks["one"] == picks["rccl4"]
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".sock")]  # rank 0 removed its socket
+    # a library that is not there fails loudly, in the parent, before any worker starts
+    r = subprocess.run(base + ["--output", str(tmp_path / "z.wav"), "--devices", "2", "--exchange", "rccl"], capture_output=True, text=True, timeout=120,
+                       env=dict(env, TTS_RCCL_LIB=str(tmp_path / "no_such_lib.so")))
+    assert r.returncode != 0 and "TTS_RCCL_LIB" in r.stderr

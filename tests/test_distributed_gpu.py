@@ -110,7 +110,7 @@ def test_bench_two_ranks_share_one_gpu():
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device-map", "0,0", "--quick", "--config", "4",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--device-map", "0,0", "--allow-shared-device", "--quick", "--config", "4",
            "--candidates", "4", "--steps", "1", "--warmup", "0", "--decode-steps", "8", "--diff-steps", "4", "--no-cpu-baseline", "--no-ab"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -136,7 +136,7 @@ def test_cli_devices_shards_reproduce_the_single_process_batch(small_models, tmp
     base = [exe, "--models", str(d), "--message", "this is a test message.", "--voice", os.path.join(ROOT, "models", "mol.bin"), "--seed", "3",
             "--codes", "16", "--steps", "4", "--candidates", "4"]
     outs, errs = {}, {}
-    for tag, extra in (("one", []), ("two", ["--devices", "2", "--device-map", "0,0"])):
+    for tag, extra in (("one", []), ("two", ["--devices", "2", "--device-map", "0,0", "--allow-shared-device", "1"])):
         out = tmp_path / (tag + ".wav")
         r = subprocess.run(base + ["--output", str(out)] + extra, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
@@ -174,7 +174,7 @@ def test_cli_clvp_reranking_single_process_and_shards(small_models, tmp_path):
     r = subprocess.run(base + ["--output", str(plain)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     kept, audio = {}, {}
-    for tag, extra in (("one", []), ("two", ["--devices", "2", "--device-map", "0,0"])):
+    for tag, extra in (("one", []), ("two", ["--devices", "2", "--device-map", "0,0", "--allow-shared-device", "1"])):
         out = tmp_path / (tag + ".wav")
         r = subprocess.run(base + ["--clvp", clvp, "--output", str(out)] + extra, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
@@ -247,6 +247,9 @@ def test_cli_rccl_exchange_one_worker(small_models, tmp_path):
     # an unknown exchange is an error; two workers on ONE device cannot form an RCCL communicator and say so instead of hanging
     r = subprocess.run(base + ["--output", str(tmp_path / "x.wav"), "--exchange", "mpi"], capture_output=True, text=True, timeout=60, env=env)
     assert r.returncode != 0 and "files or rccl" in r.stderr
-    r = subprocess.run(base + ["--output", str(tmp_path / "y.wav"), "--devices", "2", "--device-map", "0,0", "--exchange", "rccl"],
+    r = subprocess.run(base + ["--output", str(tmp_path / "y.wav"), "--devices", "2", "--device-map", "0,0", "--allow-shared-device", "1", "--exchange", "rccl"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0
+    # two workers on one GPU are refused outright unless asked for (unsupported form: DESIGN.md section 6)
+    r = subprocess.run(base + ["--output", str(tmp_path / "w.wav"), "--devices", "2", "--device-map", "0,0"], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode != 0 and "share a GPU" in r.stderr

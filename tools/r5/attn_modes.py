@@ -19,8 +19,11 @@ pkg = tortoise_cpp_amd_loader.load()
 import oracle as O  # noqa: E402
 import conftest as CT  # noqa: E402
 
-MODES = (("default (split proj_out weight)", {"attn_f32": 0, "attn_proj_f16": 0}), ("all-fp16 (rounds 1-4)", {"attn_f32": 0, "attn_proj_f16": 1}),
-         ("attn_f32", {"attn_f32": 1, "attn_proj_f16": 0}))
+MODES = (("default (split W, P x 2^14)", {"attn_f32": 0, "attn_proj_f16": 0, "attn_pshift": 14}),
+         ("split W, P unscaled", {"attn_f32": 0, "attn_proj_f16": 0, "attn_pshift": 0}),
+         ("all-fp16, P x 2^14", {"attn_f32": 0, "attn_proj_f16": 1, "attn_pshift": 14}),
+         ("all-fp16 (rounds 1-4)", {"attn_f32": 0, "attn_proj_f16": 1, "attn_pshift": 0}),
+         ("attn_f32", {"attn_f32": 1, "attn_proj_f16": 0, "attn_pshift": 14}))
 
 
 def models(kind):
@@ -84,8 +87,8 @@ def main():
                     t0 = time.time()
                     eng.diffusion(lats, n_steps=80, noise_mode=pkg.NOISE_DEVICE)
                     print("cost B=%d %-34s diffusion stage %.1f ms" % (B, name, 1e3 * (time.time() - t0)), flush=True)
-    for k in ("attn_f32", "attn_proj_f16"):
-        eng.set_option(k, 0)
+    for k, v in (("attn_f32", 0), ("attn_proj_f16", 0), ("attn_pshift", 14)):
+        eng.set_option(k, v)
     eng.close()
 
 

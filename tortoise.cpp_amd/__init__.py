@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libtortoise_mi355x.so")
+LIB_PATH = os.environ.get("TTS_LIB_PATH") or os.path.join(HERE, "libtortoise_mi355x.so")  # TTS_LIB_PATH: developer A/B of another build of the same sources
 HEADER = os.path.join(os.path.dirname(HERE), "include", "tortoise_mi355x.h")
 VOCAB_MEL = 8194
 DMODEL = 1024
@@ -45,7 +45,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     sig = {
-        "tts_create": (vp, [ci]), "tts_destroy": (None, [vp]), "tts_last_error": (C.c_char_p, [vp]),
+        "tts_version": (ci, []), "tts_create": (vp, [ci]), "tts_destroy": (None, [vp]), "tts_last_error": (C.c_char_p, [vp]),
         "tts_set_option": (ci, [vp, C.c_char_p, C.c_double]),
         "tts_load_ar": (ci, [vp, C.c_char_p]), "tts_load_diffusion": (ci, [vp, C.c_char_p]),
         "tts_load_vocoder": (ci, [vp, C.c_char_p]), "tts_load_clvp": (ci, [vp, C.c_char_p]),
@@ -62,7 +62,7 @@ def lib():
         "tts_ar_step_sample": (ci, [vp, _i32p, ci, C.c_uint, _i32p]), "tts_ar_topk_fallbacks": (ci, [vp]), "tts_diffusion_time_mlp_retries": (ci, [vp]),
         "tts_host_sample_row": (ci, [_f32p, _i32p, ci, cf]), "tts_host_sample_prefiltered": (ci, [_f32p, _i32p, ci, cf, ci]),
         "tts_autoregressive": (ci, [vp, _i32p, ci, _f32p, ci, ci, C.c_uint, _i32p, _i32p, vp, _i32p]),
-        "tts_ar_stop_status": (ci, [vp, _i32p, ci]),
+        "tts_ar_stop_status": (ci, [vp, _i32p, ci]), "tts_ar_set_stop_schedule": (ci, [vp, C.c_void_p, ci]),
         "tts_diffusion_frames": (ci, [ci]),
         "tts_diffusion_forward": (ci, [vp, _f32p, ci, _f32p, ci, ci, _f32p]),
         "tts_diffusion": (ci, [vp, _f32p, _i32p, ci, ci, vp, ci, _f32p]),
@@ -203,6 +203,14 @@ class Engine:
         out = np.empty(logits.shape[0], np.int32)
         self._ck(self.L.tts_sample(self.h, logits.reshape(-1), ids.reshape(-1), ids.shape[1], logits.shape[0], out))
         return out
+
+    def set_stop_schedule(self, stop_at=None):
+        """candidate b of the following autoregressive() calls samples the stop token after stop_at[b] codes (None clears): a reproducible ragged batch"""
+        if stop_at is None:
+            self._ck(self.L.tts_ar_set_stop_schedule(self.h, None, 0))
+        else:
+            a = np.ascontiguousarray(stop_at, np.int32)
+            self._ck(self.L.tts_ar_set_stop_schedule(self.h, a.ctypes.data_as(C.c_void_p), len(a)))
 
     def autoregressive(self, tokens, voice, B, max_steps, mask_stop=False, want_latents=True, retire=False):
         """Returns (codes [B,502], rows [B], list of trimmed latents [rows_c,1024], steps)."""

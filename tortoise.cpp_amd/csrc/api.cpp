@@ -94,6 +94,8 @@ void tts_destroy(tts_ctx *c) {
   delete c;
 }
 
+int tts_version(void) { return TTS_API_VERSION; }
+
 const char *tts_last_error(const tts_ctx *c) { return c ? c->err.c_str() : "no context (no HIP device?)"; }
 
 int tts_set_option(tts_ctx *c, const char *key, double value) {
@@ -258,6 +260,7 @@ int tts_ar_step_sample(tts_ctx *c, const int32_t *prev, int i, unsigned flags, i
   NEED_CTX(c);
   if (!prev || !samples_out) return TTS_ERR_ARG;
   return guarded(c, [&] {
+    if (ar_batch(c) < 1) return fail(c, TTS_ERR_STATE, "tts_ar_begin not called"); // before the shard check: with no AR state the batch is 0
     if (int rc = shard_check(c, ar_batch(c))) return rc;
     c->topk_fallbacks = 0;
     return step_sample(c, prev, i, (flags & TTS_AR_MASK_STOP) != 0, samples_out, &c->topk_fallbacks);
@@ -318,6 +321,8 @@ static int autoregressive_impl(tts_ctx *c, const int32_t *text_ids, int n_text, 
   // The uniforms are consumed exactly as in strict mode (two per candidate and step, candidate order), so every
   // sequence is the one strict mode would have produced.
   const bool retire = (flags & TTS_AR_RETIRE) != 0;
+  const bool sched = !c->stop_schedule.empty();
+  if (sched && (int)c->stop_schedule.size() != B) return fail(c, TTS_ERR_ARG, "tts_autoregressive: the stop schedule holds %d candidates, the call %d", (int)c->stop_schedule.size(), B);
   if ((rc = shard_check(c, B))) return rc;
   std::vector<char> done(B, 0);
   std::vector<int32_t> next; // the samples of the coming iteration when the device-top-k step already produced them
@@ -335,6 +340,7 @@ static int autoregressive_impl(tts_ctx *c, const int32_t *text_ids, int n_text, 
     }
     int stops = 0;
     for (int b = 0; b < B; b++) {
+      if (sched && i == c->stop_schedule[b]) samples[b] = 8193; // tts_ar_set_stop_schedule
       if (retire && done[b]) { samples[b] = 8193; stops++; continue; }
       if (!(seq[b].size() > 0 && seq[b].back() == 8193)) seq[b].push_back(samples[b]);
       if (samples[b] == 8193) { stops++; done[b] = 1; }
@@ -402,6 +408,15 @@ int tts_autoregressive(tts_ctx *c, const int32_t *text_ids, int n_text, const fl
   return guarded(c, [&] {
     return autoregressive_impl(c, text_ids, n_text, voice, B, max_steps, flags, codes_out, rows_out, latents_out, steps_out);
   });
+}
+
+int tts_ar_set_stop_schedule(tts_ctx *c, const int32_t *stop_at, int n_candidates) {
+  if (!c || n_candidates < 0) return TTS_ERR_ARG;
+  if (!stop_at || n_candidates == 0) { c->stop_schedule.clear(); return TTS_OK; }
+  for (int b = 0; b < n_candidates; b++)
+    if (stop_at[b] < 1) return fail(c, TTS_ERR_ARG, "tts_ar_set_stop_schedule: candidate %d would stop before its first code", b);
+  c->stop_schedule.assign(stop_at, stop_at + n_candidates);
+  return TTS_OK;
 }
 
 int tts_ar_stop_status(tts_ctx *c, int32_t *stopped_out, int n_candidates) {

@@ -1197,8 +1197,10 @@ struct ArState {
   int32_t *h_pf = nullptr;     // pinned [B][TTS_PF_WORDS]: the device prefilter's lists (step_mode != 0), written by the kernel itself
   int step_mode = 0;           // what the step hands to the host: 0 = the logits, 1 = the prefilter's lists, 2 = lists with the stop token masked
   int h_cap_B = 0;             // candidates the pinned buffers were sized for
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
+  // one captured step per mode (a caller alternating tts_ar_step / tts_ar_step_sample, or bench's device_topk on/off loop, re-instantiated
+  // the ~150-node graph on every switch)
+  hipGraph_t graphs[3] = {};
+  hipGraphExec_t graph_execs[3] = {};
   // everything the captured step bakes into its nodes: the graph of the previous utterance is replayed when nothing moved
   struct GraphSig {
     int B = 0, max_pos = 0, lut = 0, wmode = 0, mode = 0;
@@ -1206,7 +1208,7 @@ struct ArState {
     bool operator==(const GraphSig &o) const {
       return B == o.B && max_pos == o.max_pos && lut == o.lut && wmode == o.wmode && mode == o.mode && std::equal(p, p + 11, o.p);
     }
-  } graph_sig;
+  } graph_sigs[3];
   GraphSig current_sig(int lut, int wmode) const {
     GraphSig g;
     g.B = B; g.max_pos = max_pos; g.lut = lut; g.wmode = wmode; g.mode = step_mode;
@@ -1214,13 +1216,13 @@ struct ArState {
     std::copy(q, q + 11, g.p);
     return g;
   }
-  void drop_graph() {
-    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-    if (graph) (void)hipGraphDestroy(graph);
-    graph_exec = nullptr; graph = nullptr;
+  void drop_graph(int m) {
+    if (graph_execs[m]) (void)hipGraphExecDestroy(graph_execs[m]);
+    if (graphs[m]) (void)hipGraphDestroy(graphs[m]);
+    graph_execs[m] = nullptr; graphs[m] = nullptr;
   }
   ~ArState() {
-    drop_graph();
+    for (int m = 0; m < 3; m++) drop_graph(m);
     if (h_toks) (void)hipHostFree(h_toks);
     if (h_logits) (void)hipHostFree(h_logits);
     if (h_pf) (void)hipHostFree(h_pf);
@@ -1846,21 +1848,21 @@ int ar_step(tts_ctx *ctx, const int32_t *prev_ids, int step_i, float *logits_out
     CHECK(enqueue_decode_step(ctx, st));
   } else {
     const ArState::GraphSig sig = st->current_sig(ctx->ggml_lut, ctx->ar_weights);
-    if (st->graph_exec && !(sig == st->graph_sig)) st->drop_graph();
-    if (!st->graph_exec) {
-      st->graph_sig = sig;
+    if (st->graph_execs[mode] && !(sig == st->graph_sigs[mode])) st->drop_graph(mode);
+    if (!st->graph_execs[mode]) {
+      st->graph_sigs[mode] = sig;
       TTS_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
       int rc = enqueue_decode_step(ctx, st);
-      hipError_t e = hipStreamEndCapture(ctx->stream, &st->graph);
-      if (rc || e != hipSuccess) { st->drop_graph(); if (rc) return rc; TTS_HIP(ctx, e); } // never keep a half-captured graph
-      e = hipGraphInstantiate(&st->graph_exec, st->graph, nullptr, nullptr, 0);
-      if (e != hipSuccess) { st->drop_graph(); TTS_HIP(ctx, e); }
+      hipError_t e = hipStreamEndCapture(ctx->stream, &st->graphs[mode]);
+      if (rc || e != hipSuccess) { st->drop_graph(mode); if (rc) return rc; TTS_HIP(ctx, e); } // never keep a half-captured graph
+      e = hipGraphInstantiate(&st->graph_execs[mode], st->graphs[mode], nullptr, nullptr, 0);
+      if (e != hipSuccess) { st->drop_graph(mode); TTS_HIP(ctx, e); }
     }
     // HBM-bound step: every weight once (f32: 12 d^2 per layer + the padded head) + the fp16 K/V rows read + logits
     const double step_bytes = (ctx->ar_weights == 2 ? 1.0 : ctx->ar_weights == 1 ? 2.0 : 4.0) * ((double)st->n_layers * 12.0 * D * D + (double)D * V) +
                               (double)st->B * st->n_layers * 2.0 * (st->P + step_i + 1) * D * 2.0 + (double)st->B * V * 4.0;
     ProfScope ps(ctx, "ar_decode_step", step_bytes);
-    TTS_HIP(ctx, hipGraphLaunch(st->graph_exec, ctx->stream));
+    TTS_HIP(ctx, hipGraphLaunch(st->graph_execs[mode], ctx->stream));
   }
   TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (logits_out) memcpy(logits_out, st->h_logits, (size_t)st->B * V * 4);

@@ -53,7 +53,7 @@ int main(int argc, char **argv) {
   bool have_seed = false;
   int seed = 0, candidates = 1, steps = 80, device = 0, fixed_codes = 0, devices = 1, shard = -1, nshards = 1;
   std::string device_map, clvpPath, exchange = "files", rccl_id, diffLatentPath;
-  bool dry = false;
+  bool dry = false, allow_shared = false;
   std::vector<std::pair<std::string, double>> engine_options; // --option key=value (repeatable): tts_set_option before the models are loaded
   for (int i = 1; i < argc - 1; ++i) {
     std::string a(argv[i]);
@@ -68,6 +68,7 @@ int main(int argc, char **argv) {
     else if (a == "--codes") fixed_codes = std::stoi(argv[i + 1]); // exactly N sampled codes, stop token masked (synthetic weights never stop)
     else if (a == "--devices") devices = std::stoi(argv[i + 1]);
     else if (a == "--device-map") device_map = argv[i + 1];
+    else if (a == "--allow-shared-device") allow_shared = argv[i + 1][0] != '0';
     else if (a == "--clvp") clvpPath = argv[i + 1];
     else if (a == "--exchange") exchange = argv[i + 1];
     else if (a == "--dry-run") dry = argv[i + 1][0] != '0'; // plumbing check without a device, see below
@@ -95,6 +96,16 @@ int main(int argc, char **argv) {
       if (q == std::string::npos) break;
       p = q + 1;
     }
+    // One engine process per GPU. Two on ONE device is not a deployment form: round 4 saw a kernel's packed f32 FMAs return wrong sums while another
+    // process's MFMA waves shared the GPU (profiles/r4_two_process_determinism.txt). The library is built without packed f32 arithmetic since round 5
+    // (tortoise.cpp_amd/Makefile), but the form stays unsupported: refused unless --allow-shared-device 1 (tests on a one-GPU box).
+    if (!dry && !allow_shared)
+      for (int r = 0; r < devices; r++)
+        for (int q = 0; q < r; q++)
+          if ((r < (int)map.size() ? map[r] : r) == (q < (int)map.size() ? map[q] : q)) {
+            fprintf(stderr, "--device-map %s: workers %d and %d would share a GPU (unsupported; --allow-shared-device 1 to run anyway)\n", device_map.c_str(), q, r);
+            return 1;
+          }
     if (!have_seed) // every worker must draw from the same stream
       seed = (int)(std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count() & 0x7fffffff);
     std::string id_hex;
@@ -190,7 +201,7 @@ int main(int argc, char **argv) {
   RcclWorld world;
   const bool use_rccl = shard >= 0 && !rccl_id.empty();
   if (use_rccl) {
-    if (!world.init(rccl_id, shard, nshards)) { fprintf(stderr, "rccl: %s\n", world.err.c_str()); return 1; }
+    if (!world.init(rccl_id, shard, nshards, dry)) { fprintf(stderr, "rccl: %s\n", world.err.c_str()); return 1; }
     // conditioning from rank 0: number of text ids, the ids, the voice latent (what SURVEY 8e's ncclBroadcast carries)
     struct { int32_t n; int32_t ids[4096]; float voice[1024]; } cond;
     memset(&cond, 0, sizeof cond);
@@ -329,19 +340,20 @@ int main(int argc, char **argv) {
         write_one(got.data(), (int64_t)got.size(), (int)all[3 * win + 1], true);
       }
     } else { // all candidates of all ranks: rank 0 writes <output> (candidate 0) and <output>.<c>.wav
-      std::vector<int32_t> fr(frames.begin(), frames.end());
-      if (!world.all_gather(fr.data(), (size_t)B * 4, g)) return bail();
-      const int32_t *allf = (const int32_t *)g.data();
+      // sizes first: every rank's per-candidate sample counts (the stages' own numbers, so a --dry-run stand-in pairs exactly like a real run)
+      std::vector<int64_t> mine_ns(nsamp.begin(), nsamp.end());
+      if (!world.all_gather(mine_ns.data(), (size_t)B * 8, g)) return bail();
+      const int64_t *alln = (const int64_t *)g.data();
       std::vector<int64_t> counts(nshards, 0);
       for (int r = 0; r < nshards; r++)
-        for (int c = 0; c < B; c++) counts[r] += tts_vocoder_samples(allf[r * B + c]);
+        for (int c = 0; c < B; c++) counts[r] += alln[r * B + c];
       for (int r = 0; r < nshards; r++) {
         std::vector<float> got;
         if (!world.send_floats(audio.data(), counts, r, 0, got)) return bail();
         if (shard == 0) {
           size_t off = 0;
           for (int c = 0; c < B; c++) {
-            const int64_t ns = tts_vocoder_samples(allf[r * B + c]);
+            const int64_t ns = alln[r * B + c];
             write_one(got.data() + off, ns, r * B + c, r * B + c == 0);
             off += (size_t)ns;
           }

@@ -27,8 +27,14 @@ struct RcclApi {
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   bool open() {
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-      if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+    // TTS_RCCL_LIB=<path>: another library with the same ten entry points (tests/fake_rccl.cpp: host buffers over a Unix socket, so that the
+    // N > 1 pairing / size logic below executes on a box without GPUs)
+    if (const char *over = getenv("TTS_RCCL_LIB")) {
+      if (!(h = dlopen(over, RTLD_NOW | RTLD_LOCAL))) { fprintf(stderr, "rccl: cannot open TTS_RCCL_LIB=%s: %s\n", over, dlerror()); return false; }
+    } else {
+      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if ((h = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+    }
     if (!h) { fprintf(stderr, "rccl: cannot open librccl.so: %s\n", dlerror()); return false; }
 #define RCCL_SYM(f) if (!(f = (decltype(f))dlsym(h, "nccl" #f))) { fprintf(stderr, "rccl: symbol nccl" #f " missing\n"); return false; }
     RCCL_SYM(GetUniqueId) RCCL_SYM(CommInitRank) RCCL_SYM(CommDestroy) RCCL_SYM(Broadcast) RCCL_SYM(AllGather) RCCL_SYM(Send) RCCL_SYM(Recv)
@@ -64,12 +70,26 @@ struct RcclWorld {
   std::string err;
   bool fail(const char *what, ncclResult_t r) { err = std::string(what) + ": " + (api.GetErrorString ? api.GetErrorString(r) : "?"); return false; }
   bool failh(const char *what, hipError_t e) { err = std::string(what) + ": " + hipGetErrorString(e); return false; }
-  bool init(const std::string &hex_id, int rank_, int n_) { // the calling process has already selected its device (tts_create)
-    rank = rank_; n = n_;
+  // host_only (tortoise --dry-run: no device in the process): the staging buffers are host memory and no stream exists — only meaningful with a
+  // TTS_RCCL_LIB stand-in that moves host buffers; the real librccl would reject them
+  bool host_only = false;
+  hipError_t dmalloc(void **p, size_t bytes) {
+    if (!host_only) return hipMalloc(p, bytes);
+    *p = malloc(bytes ? bytes : 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+  }
+  hipError_t copy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    if (!host_only) return hipMemcpyAsync(dst, src, bytes, kind, stream);
+    memcpy(dst, src, bytes);
+    return hipSuccess;
+  }
+  hipError_t sync() { return host_only ? hipSuccess : hipStreamSynchronize(stream); }
+  bool init(const std::string &hex_id, int rank_, int n_, bool host_only_ = false) { // the calling process has already selected its device (tts_create)
+    rank = rank_; n = n_; host_only = host_only_;
     ncclUniqueId id;
     if (!rccl_id_from_hex(hex_id, id)) { err = "bad --rccl-id"; return false; }
     if (!api.open()) { err = "librccl.so not available"; return false; }
-    hipError_t e = hipStreamCreate(&stream);
+    hipError_t e = host_only ? hipSuccess : hipStreamCreate(&stream);
     if (e != hipSuccess) return failh("hipStreamCreate", e);
     ncclResult_t r = api.CommInitRank(&comm, n, id, rank);
     if (r != ncclSuccess) return fail("ncclCommInitRank (distinct GPUs per rank required)", r);
@@ -79,52 +99,54 @@ struct RcclWorld {
     if (comm) api.CommDestroy(comm);
     if (stream) (void)hipStreamDestroy(stream);
   }
-  struct Dev { // device staging buffer
+  struct Dev { // staging buffer (device; host under host_only)
     void *p = nullptr;
-    ~Dev() { if (p) (void)hipFree(p); }
+    bool host;
+    explicit Dev(const RcclWorld &w) : host(w.host_only) {}
+    ~Dev() { if (p) { if (host) free(p); else (void)hipFree(p); } }
   };
   bool broadcast(void *host, size_t bytes, int root) {
-    Dev d;
-    hipError_t e = hipMalloc(&d.p, bytes);
+    Dev d(*this);
+    hipError_t e = dmalloc(&d.p, bytes);
     if (e != hipSuccess) return failh("hipMalloc", e);
-    if (rank == root && (e = hipMemcpyAsync(d.p, host, bytes, hipMemcpyHostToDevice, stream)) != hipSuccess) return failh("hipMemcpyAsync", e);
+    if (rank == root && (e = copy(d.p, host, bytes, hipMemcpyHostToDevice)) != hipSuccess) return failh("hipMemcpyAsync", e);
     ncclResult_t r = api.Broadcast(d.p, d.p, bytes, ncclChar, root, comm, stream);
     if (r != ncclSuccess) return fail("ncclBroadcast", r);
-    if ((e = hipMemcpyAsync(host, d.p, bytes, hipMemcpyDeviceToHost, stream)) != hipSuccess) return failh("hipMemcpyAsync", e);
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return failh("hipStreamSynchronize", e);
+    if ((e = copy(host, d.p, bytes, hipMemcpyDeviceToHost)) != hipSuccess) return failh("hipMemcpyAsync", e);
+    if ((e = sync()) != hipSuccess) return failh("hipStreamSynchronize", e);
     return true;
   }
   // every rank contributes `bytes`; out = n x bytes in rank order
   bool all_gather(const void *mine, size_t bytes, std::vector<char> &out) {
-    Dev s, d;
+    Dev s(*this), d(*this);
     hipError_t e;
-    if ((e = hipMalloc(&s.p, bytes)) != hipSuccess || (e = hipMalloc(&d.p, bytes * n)) != hipSuccess) return failh("hipMalloc", e);
-    if ((e = hipMemcpyAsync(s.p, mine, bytes, hipMemcpyHostToDevice, stream)) != hipSuccess) return failh("hipMemcpyAsync", e);
+    if ((e = dmalloc(&s.p, bytes)) != hipSuccess || (e = dmalloc(&d.p, bytes * n)) != hipSuccess) return failh("hipMalloc", e);
+    if ((e = copy(s.p, mine, bytes, hipMemcpyHostToDevice)) != hipSuccess) return failh("hipMemcpyAsync", e);
     ncclResult_t r = api.AllGather(s.p, d.p, bytes, ncclChar, comm, stream);
     if (r != ncclSuccess) return fail("ncclAllGather", r);
     out.resize(bytes * n);
-    if ((e = hipMemcpyAsync(out.data(), d.p, bytes * n, hipMemcpyDeviceToHost, stream)) != hipSuccess) return failh("hipMemcpyAsync", e);
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return failh("hipStreamSynchronize", e);
+    if ((e = copy(out.data(), d.p, bytes * n, hipMemcpyDeviceToHost)) != hipSuccess) return failh("hipMemcpyAsync", e);
+    if ((e = sync()) != hipSuccess) return failh("hipStreamSynchronize", e);
     return true;
   }
   // rank `from` sends counts[from] floats to rank `to` (every rank calls it with the same arguments; the others do nothing)
   bool send_floats(const float *mine, const std::vector<int64_t> &counts, int from, int to, std::vector<float> &out_at_to) {
     if (from == to) { if (rank == to) out_at_to.assign(mine, mine + counts[from]); return true; }
     if (rank != from && rank != to) return true;
-    Dev d;
+    Dev d(*this);
     const size_t bytes = (size_t)counts[from] * 4;
-    hipError_t e = hipMalloc(&d.p, bytes ? bytes : 4);
+    hipError_t e = dmalloc(&d.p, bytes ? bytes : 4);
     if (e != hipSuccess) return failh("hipMalloc", e);
     ncclResult_t r;
     if (rank == from) {
-      if ((e = hipMemcpyAsync(d.p, mine, bytes, hipMemcpyHostToDevice, stream)) != hipSuccess) return failh("hipMemcpyAsync", e);
+      if ((e = copy(d.p, mine, bytes, hipMemcpyHostToDevice)) != hipSuccess) return failh("hipMemcpyAsync", e);
       if ((r = api.Send(d.p, (size_t)counts[from], ncclFloat, to, comm, stream)) != ncclSuccess) return fail("ncclSend", r);
     } else {
       if ((r = api.Recv(d.p, (size_t)counts[from], ncclFloat, from, comm, stream)) != ncclSuccess) return fail("ncclRecv", r);
       out_at_to.resize((size_t)counts[from]);
-      if ((e = hipMemcpyAsync(out_at_to.data(), d.p, bytes, hipMemcpyDeviceToHost, stream)) != hipSuccess) return failh("hipMemcpyAsync", e);
+      if ((e = copy(out_at_to.data(), d.p, bytes, hipMemcpyDeviceToHost)) != hipSuccess) return failh("hipMemcpyAsync", e);
     }
-    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return failh("hipStreamSynchronize", e);
+    if ((e = sync()) != hipSuccess) return failh("hipStreamSynchronize", e);
     return true;
   }
 };

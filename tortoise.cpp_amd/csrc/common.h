@@ -92,6 +92,7 @@ struct tts_ctx {
   // candidate-parallel sharding: this context runs candidates [rng_shard_offset, +B) of a batch of rng_shard_total
   // (0 = unsharded). The sampler skips the other ranks' uniforms; device noise streams are keyed by the global candidate id.
   int rng_shard_offset = 0, rng_shard_total = 0;
+  std::vector<int32_t> stop_schedule; // tts_ar_set_stop_schedule: forced stop iteration per candidate (empty = none)
   std::vector<int32_t> ar_stopped; // last tts_autoregressive call, per candidate: 1 = it sampled the stop token, 0 = cut at max_steps (tts_ar_stop_status)
   // profiling: per kernel family, HIP event pairs recorded on the ctx stream around every launch and
   // resolved lazily (no host sync inside the timed region)
