@@ -410,14 +410,17 @@ def main():
         eng.seed(99)
         _, _, lats_rp, _ = eng.autoregressive(prompts[0], voice, B, S, mask_stop=True)
         times = {}
-        for mode in (0, 1):
-            eng.set_option("attn_f32", mode)
+        for mode, opts in ((0, {"attn_f32": 0}), (1, {"attn_f32": 1}), (2, {"attn_f32": 0, "attn_proj_f16": 1, "lc_attn_f32": 0})):
+            for k_, v_ in opts.items():
+                eng.set_option(k_, v_)
             eng.diffusion(lats_rp, n_steps=4, noise_mode=pkg.NOISE_DEVICE)  # warm-up of this mode's buffers
             t0 = time.time()
             eng.diffusion(lats_rp, n_steps=n_diff, noise_mode=pkg.NOISE_DEVICE)
             times[mode] = 1e3 * (time.time() - t0)
-        eng.set_option("attn_f32", 0)
+        for k_, v_ in (("attn_f32", 0), ("attn_proj_f16", 0), ("lc_attn_f32", 1)):
+            eng.set_option(k_, v_)
         ref_prec = {"diffusion_ms_attn_f32": round(times[1], 1), "diffusion_ms_default": round(times[0], 1), "ratio": round(times[1] / times[0], 3),
+                    "diffusion_ms_all_fp16_block_of_rounds_1_to_4": round(times[2], 1), "default_over_all_fp16": round(times[0] / times[2], 3),
                     "note": "option attn_f32 = 1: QK^T, softmax, PV and proj_out evaluated to f32 accuracy (three fp16 MFMAs per product on hi + lo operand "
                             "pairs) and SiLU with libm expf + IEEE division; the 80-step loop then sits at the distance two f32 evaluations of the reference's graph keep "
                             "from each other (tests/golden/parity_floor.json: gate_f32)"}
@@ -590,6 +593,9 @@ def main():
                    "parallelism": "candidate-parallel x%d (one process per GPU, replicated weights, RCCL broadcast of prompt/voice + gather of audio)" % world,
                    # the unconditioned branch's integrator layers (input independent of the candidate) are evaluated once per distinct
                    # sequence length; with the stop token masked all candidates have one length (option share_uncond)
+                   # arithmetic of the timed diffusion stage: the mode the parity tests gate at the f32-vs-f32 floor
+                   "diffusion_arithmetic": "default: fp16 q/k/v/P/attention-output MFMA operands, proj_out on a split-precision (F32-accurate) weight, latent conditioner "
+                                           "in reference precision; f32 accumulate everywhere (options attn_f32 = 0, attn_proj_f16 = 0, lc_attn_f32 = 1)",
                    "uncond_integrator_shared": share,
                    "audio_seconds": "T*256/24000 per candidate = %.3f s (SURVEY 8d; the vocoder also emits 10 silent pad frames: %.3f s of samples)"
                                     % (T * 256 / 24000.0, ((T + 10) * 256 - 6) / 24000.0)},

@@ -78,42 +78,41 @@ def engine(pkg):
 
 
 def loop_gate(kind, attn_f32=False):
-    """Gate (max abs on the +-1 mel range) of an 80-/200-step sampling-loop comparison between the engine and the oracle on the
-    `kind` = small | mid | full weights (record: tests/golden/parity_floor.json, measured on the CPU with torch by
-    tools/regen_parity_floor.py / tests/test_parity_floor.py).
+    """Gate (max abs on the +-1 mel range) of an 80-/200-step sampling-loop comparison between the engine and the oracle on the `kind` = small | mid | full
+    weights (record: tests/golden/parity_floor.json, measured on the CPU with torch by tools/regen_parity_floor.py / tests/test_parity_floor.py).
 
-    attn_f32 = True  — the engine's reference-precision mode (option attn_f32 = 1: F32 AttentionBlock as main.cpp:3848-3875 + exact SiLU): gated against
-                       the distance between the oracle and a torch-f32 evaluation of the reference's graph (`oracle_vs_t32`: two correct f32 evaluations,
-                       measured on the class's samples AND on the very problems the GPU tests run): max(1e-3 [north star], 1.5 x the largest recorded
-                       maximum) — the maximum over 100 x T chaotic values moves by +-30 % under an arithmetic-neutral change, see loop_gate_mean for the
-                       stable statistic. The trajectory is chaotic at the 1e-3 level (fp16 rounding of every convolution operand), so the distance between
-                       two correct f32 evaluations IS the tolerance an f32 engine can be held to.
-    attn_f32 = False — throughput mode (fp16 MFMA operands in the AttentionBlock, a north-star design decision): max(1e-3, 2 x the
-                       distance an f32 emulation of that arithmetic keeps from the oracle). The reference's own gate is 0.01 (main.cpp:6223)."""
+    ONE gate for both arithmetic modes of the diffusion stage since round 5: the distance between the oracle and a torch-f32 evaluation of the
+    reference's graph (`oracle_vs_t32`: two correct f32 evaluations, measured on the class's samples AND on the very problems the GPU tests run):
+    max(1e-3 [north star], 1.5 x the largest recorded maximum) — the maximum over 100 x T chaotic values moves by +-30 % under an arithmetic-neutral change, see
+    loop_gate_mean for the stable statistic. The trajectory is chaotic at the 1e-3 level (fp16 rounding of every convolution operand), so the distance between two
+    correct f32 evaluations IS the tolerance an engine can be held to. The reference's own gate is 0.01 (main.cpp:6223).
+      mode 0  the default: q, k, v, softmax numerators and attention output are fp16 MFMA operands; proj_out multiplies on its F32 weight as a split pair and the
+              latent conditioner (once per utterance) runs in reference precision — the two roundings that are the SAME perturbation at every step; what is left
+              averages out over the loop (tests/golden/parity_floor.json "ablation", profiles/r5_attention_ablation.txt);
+      mode 1  option attn_f32: every product of the AttentionBlock on split-fp16 pairs + exact SiLU (main.cpp:3848-3875's F32 arithmetic).
+    (Rounds 1-4 gated mode 0 at max(1e-3, 2 x an f32 emulation of the engine's own all-fp16 block): 2.8e-3 .. 5.0e-3. That block is still there as option
+    attn_proj_f16 = 1 / lc_attn_f32 = 0 for A/B and is not gated.)"""
     import json
     rec = json.load(open(os.path.join(GOLDEN, "parity_floor.json")))[kind]
-    return float(rec["gate_f32"] if attn_f32 else rec["gate"])
+    return float(rec["gate_f32"])
 
 
 def loop_gate_mean(kind):
-    """Reference-precision mode only: gate on the MEAN abs distance from the oracle = 1.25 x the largest mean the torch-f32 evaluation kept from the oracle
-    on the class's test problems (the engine's mean has been 1.04 .. 1.17 x the same problem's, a stable statistic unlike the maximum)."""
+    """Gate on the MEAN abs distance from the oracle = 1.25 x the largest mean the torch-f32 evaluation kept from the oracle on the class's test problems (the
+    engine's reference-precision mode has been 1.04 .. 1.17 x the same problem's, the default mode 1.09 .. 1.21 x: a stable statistic unlike the maximum)."""
     import json
     return float(json.load(open(os.path.join(GOLDEN, "parity_floor.json")))[kind]["gate_f32_mean"])
 
 
 def check_loop(err, kind, mode, what=""):
-    """assert the loop gates of one comparison (err = |engine - oracle|); returns the text for the log"""
-    g = loop_gate(kind, mode)
+    """assert the loop gates of one comparison (err = |engine - oracle|), the same for both modes; returns the text for the log"""
+    g, gm = loop_gate(kind, mode), loop_gate_mean(kind)
     assert err.max() <= g, (what, mode, float(err.max()), float(err.mean()), g)
-    if mode:
-        gm = loop_gate_mean(kind)
-        assert err.mean() <= gm, (what, mode, float(err.mean()), gm)
-        return "max %.2e (gate %.2e) mean %.2e (gate %.2e)" % (err.max(), g, err.mean(), gm)
-    return "max %.2e (gate %.2e) mean %.2e" % (err.max(), g, err.mean())
+    assert err.mean() <= gm, (what, mode, float(err.mean()), gm)
+    return "max %.2e (gate %.2e) mean %.2e (gate %.2e)" % (err.max(), g, err.mean(), gm)
 
 
-ATTN_MODES = ((0, "throughput mode: fp16 attention operands"), (1, "reference precision: attn_f32"))
+ATTN_MODES = ((0, "default: fp16 attention operands, F32-accurate proj_out weight, f32 conditioner"), (1, "reference precision: attn_f32"))
 
 
 DEFAULT_TOKENS = np.array([255, 147, 2, 54, 2, 14, 2, 136, 63, 2, 80, 32, 150, 112, 9, 0], np.int32)

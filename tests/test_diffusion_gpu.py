@@ -37,7 +37,7 @@ def test_forward_matches_oracle(engine, oracle, small_models, mid_models, models
             engine.set_option("attn_f32", mode)
             got = engine.diffusion_forward(lat, x_t, timestep, cond_free)
             assert got.shape == want.shape == (200, T)
-            # north star: 1e-3 relative with fp16 MFMA inputs for attention / proj_out (f32 accumulate); the reference-precision mode sits on the
+            # north star: 1e-3 relative with fp16 MFMA operands in the attention core (f32 accumulate); the reference-precision mode sits on the
             # single-forward chaos floor of the fp16-rounded convolutions (two f32 evaluations: 2-5e-4, tests/test_oracle_vs_torch.py)
             e = rel_err(got, want)
             print("forward rel err %s L=%d t=%d cond_free=%s [%s]: %.2e" % (models, L, timestep, cond_free, what, e))
@@ -74,8 +74,8 @@ def test_numerics_switches(engine, oracle, small_models, gn_eps, lut):
 
 def test_sampling_loop_matches_oracle(engine, oracle, small_models):
     """diffusion(): the full 80-step schedule, 2 candidates of different length in one batch (ragged layout), explicit noise —
-    gate: conftest.loop_gate (2 x the measured distance between two correct evaluations; the reference's own gate is max abs 0.01,
-    main.cpp:6223). (Coarse schedules are a worse test, not a faster one: with 4-6
+    gates: conftest.loop_gate / loop_gate_mean (the distance two correct f32 evaluations keep, both arithmetic modes; the reference's own gate is max abs
+    0.01, main.cpp:6223). (Coarse schedules are a worse test, not a faster one: with 4-6
     respaced steps the first update multiplies the eps error by up to 153 before the +-1 clamp and single bins land 5e-2 apart on two
     correct implementations; over 80 steps the same two implementations agree to ~2e-3.)"""
     engine.load(diffusion=small_models + "/ggml-diffusion-model.bin")

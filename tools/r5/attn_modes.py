@@ -19,11 +19,11 @@ pkg = tortoise_cpp_amd_loader.load()
 import oracle as O  # noqa: E402
 import conftest as CT  # noqa: E402
 
-MODES = (("default (split W, P x 2^14)", {"attn_f32": 0, "attn_proj_f16": 0, "attn_pshift": 14}),
-         ("split W, P unscaled", {"attn_f32": 0, "attn_proj_f16": 0, "attn_pshift": 0}),
-         ("all-fp16, P x 2^14", {"attn_f32": 0, "attn_proj_f16": 1, "attn_pshift": 14}),
-         ("all-fp16 (rounds 1-4)", {"attn_f32": 0, "attn_proj_f16": 1, "attn_pshift": 0}),
-         ("attn_f32", {"attn_f32": 1, "attn_proj_f16": 0, "attn_pshift": 14}))
+MODES = (("default (split W, f32 conditioner)", {"attn_f32": 0, "attn_proj_f16": 0, "lc_attn_f32": 1}),
+         ("split W, fp16 conditioner", {"attn_f32": 0, "attn_proj_f16": 0, "lc_attn_f32": 0}),
+         ("all-fp16 blocks, f32 conditioner", {"attn_f32": 0, "attn_proj_f16": 1, "lc_attn_f32": 1}),
+         ("all-fp16 (rounds 1-4)", {"attn_f32": 0, "attn_proj_f16": 1, "lc_attn_f32": 0}),
+         ("attn_f32", {"attn_f32": 1, "attn_proj_f16": 0, "lc_attn_f32": 1}))
 
 
 def models(kind):
@@ -76,6 +76,13 @@ def main():
         d = models("full")
         eng.load(diffusion=d + "/ggml-diffusion-model.bin")
         rs = np.random.RandomState(1)
+        lat, xt = rs.randn(200, 1024).astype(np.float32), rs.randn(100, 870).astype(np.float32)
+        ys = []
+        eng.set_option("attn_f32", 0)
+        for db in (1, 0):
+            eng.set_option("proj_dual_b", db)
+            ys.append(eng.diffusion_forward(lat, xt, 557, False))
+        print("dual-B proj_out kernel vs two K segments, one full-depth forward at T=870: max rel diff %.2e" % (np.abs(ys[0] - ys[1]).max() / np.abs(ys[1]).max()), flush=True)
         for B in (16, 1):
             lats = [rs.randn(200, 1024).astype(np.float32) for _ in range(B)]
             for rep in range(2):
@@ -87,7 +94,7 @@ def main():
                     t0 = time.time()
                     eng.diffusion(lats, n_steps=80, noise_mode=pkg.NOISE_DEVICE)
                     print("cost B=%d %-34s diffusion stage %.1f ms" % (B, name, 1e3 * (time.time() - t0)), flush=True)
-    for k, v in (("attn_f32", 0), ("attn_proj_f16", 0), ("attn_pshift", 14)):
+    for k, v in (("attn_f32", 0), ("attn_proj_f16", 0), ("lc_attn_f32", 1)):
         eng.set_option(k, v)
     eng.close()
 

@@ -118,7 +118,7 @@ ABLATION_SETS = ("", "qk", "v", "p", "o", "w",                                  
 def ablate(kind, L, seed, steps=80, sets=None):
     """the 80-step distance from the ORACLE of a torch-f32 evaluation in which a chosen subset of the engine's five fp16 roundings
     (tests/torch_ref.py: qk, v, p, o, w) is applied inside the AttentionBlock. Same latents / noise for every subset; recorded under rec[kind]["ablation"]."""
-    sets = sets or [x.replace("+", ",") for x in os.environ.get("TTS_ABLATION_SETS", "").split(":") if x] or ABLATION_SETS
+    sets = sets or [x.replace("+lc", "@").replace("+", ",").replace("@", "+lc") for x in os.environ.get("TTS_ABLATION_SETS", "").split(":") if x] or ABLATION_SETS
     sets = ["" if x == "none" else x for x in sets]
     path = ensure_models(kind)
     od = O.Diffusion(O.Model(path))
@@ -134,10 +134,15 @@ def ablate(kind, L, seed, steps=80, sets=None):
     key = "L=%d,seed=%d,steps=%d" % (L, seed, steps)
     row = ab.setdefault(key, {"T": int(T)})
     for st in sets:
-        name = st or "none"
+        # a trailing "+lc": the latent conditioner (evaluated ONCE, its output enters every step) is emulated with the same roundings; without it the code
+        # embedding is the oracle's — the engine's default since round 5 (option lc_attn_f32)
+        with_lc = st.endswith("+lc")
+        st = st[:-3] if with_lc else st
+        name = (st or "none") + ("+lc" if with_lc else "")
         if name in row:
             continue
         net = TR.TorchDiffusion(path, O.buckets, f16_attention=st)  # "" = the reference's F32 block
+        ce = net.code_embedding(lat, T) if with_lc else od.code_embedding(lat, T)
         x = noise[0].copy()
         for idx in range(steps):
             t = steps - 1 - idx

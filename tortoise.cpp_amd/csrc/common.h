@@ -102,6 +102,9 @@ struct tts_ctx {
   int ar_weights = 0;      // option "ar_weights": 0 = f32 weights in the decode step (reference numerics), 1 = fp16 weights, 2 = OCP fp8 (e4m3) weights with a power-of-two scale per output column (set before tts_load_ar)
   int dec_f32_mfma = 0;    // option "dec_f32_mfma": the decode step's LayerNorm-GEMVs use exact-f32 MFMA products instead of split fp16 (set before tts_load_ar; +1 us per launch)
   int attn_f32 = 0;        // option "attn_f32": the diffusion AttentionBlock in reference precision (F32 QK^T / softmax / PV / proj_out, main.cpp:3848-3875) via split-fp16 MFMA operands; 0 = fp16 operands (throughput mode)
+  int proj_dual_b = 1;     // option "proj_dual_b" (developer A/B): the split-weight proj_out GEMM stages both weight halves per activation tile (1) or runs two K segments (0)
+  int attn_f32_drop = 0;   // option "attn_f32_drop" (developer ablation inside attn_f32 = 1): bit 0 q/k, bit 1 v, bit 2 attention output lose their low halves (= the fp16 rounding of the default mode, one operand at a time)
+  int lc_attn_f32 = 1;     // option "lc_attn_f32": the latent conditioner's AttentionBlocks (once per utterance; their output enters every step) in reference precision whatever attn_f32 says; 0 = follow attn_f32 (rounds 1-4)
   int attn_proj_f16 = 0;   // option "attn_proj_f16": 1 = proj_out's weight as ONE fp16 operand (the all-fp16 AttentionBlock of rounds 1-4, A/B only); 0 default = split pair W_hi + W_lo (F32-accurate weight, round 5)
   bool capturing = false;  // a hipGraph is being captured on the stream: ProfScope records nothing (event records would become graph nodes)
   int diff_graph = 1;      // option "diff_graph": the diffusion step is captured once per call and replayed (0: every step launched eagerly)

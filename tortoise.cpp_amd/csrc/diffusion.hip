@@ -811,7 +811,7 @@ struct Work {
   float *H() { return hbuf.as<float>(); }
   __half *A16() { return a16.as<__half>() + C; }
   __half *ATT16() { return att16.as<__half>() + C; }
-  int reserve(tts_ctx *ctx, int r, int ns) {
+  int reserve(tts_ctx *ctx, int r, int ns, bool split = false) { // split: the low-half buffers of the reference-precision AttentionBlock are needed whatever attn_f32 says
     auto rz = [&](DevBuf &b, size_t bytes) -> hipError_t {
       size_t old = b.cap;
       hipError_t e = b.reserve(bytes);
@@ -826,7 +826,7 @@ struct Work {
     TTS_HIP(ctx, rz(qk16, (size_t)(r + 128) * 2048 * 2));
     TTS_HIP(ctx, rz(vt16, (size_t)C * (r + 128) * 2));
     TTS_HIP(ctx, rz(stats, (size_t)ns * 32 * sizeof(float2)));
-    if (ctx->attn_f32) {
+    if (ctx->attn_f32 || split) {
       TTS_HIP(ctx, rz(att16_lo, (size_t)(r + 2) * C * 2));
       TTS_HIP(ctx, rz(qk16_lo, (size_t)(r + 128) * 2048 * 2));
       TTS_HIP(ctx, rz(vt16_lo, (size_t)C * (r + 128) * 2));
@@ -1241,8 +1241,8 @@ static int res_in_layers(tts_ctx *ctx, const Layout &lay, Work &wk, const float 
 //      attn_proj_f16 = 1 restores the all-fp16 block of rounds 1-4 (A/B only);
 //   1  reference precision (main.cpp:3848-3875: F32 QK^T, softmax, PV and proj_out): the same products on split-precision fp16 pairs
 //      (hi + lo, three MFMAs per product, 2^-22 relative) — the parity mode, as ar_weights = 0 is for the AR stage.
-static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, float *X, const AttnDev &w) {
-  const bool f32 = ctx->attn_f32 != 0;
+static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, float *X, const AttnDev &w, bool force_ref = false) {
+  const bool f32 = ctx->attn_f32 != 0 || force_ref;
   const bool pw16 = !f32 && ctx->attn_proj_f16; // weight touch for the two GEMMs that follow: the proj_out matrix this mode will stream
   CHECK(gn_fused(ctx, lay, X, w.norm_g, w.norm_b, nullptr, 0, wk.A16(), w.qkv_w, (size_t)3 * C * C * 2, pw16 ? w.proj_w : w.proj_w_split,
                  (size_t)C * C * (pw16 ? 2 : 4)));
@@ -1252,6 +1252,8 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
   g.outH = wk.qk16.as<__half>(); g.ldh = 2048; g.outVt = wk.vt16.as<__half>(); g.ldvt = wk.rows + 128;
   g.outH2 = wk.qk16_lo.as<__half>(); g.outVt2 = wk.vt16_lo.as<__half>();
   CHECK(gemm(ctx, "diff_gemm", g, lay));
+  if (f32 && (ctx->attn_f32_drop & 1)) TTS_HIP(ctx, hipMemsetAsync(wk.qk16_lo.p, 0, (size_t)(wk.rows + 128) * 2048 * 2, ctx->stream)); // developer ablation: q, k as ONE fp16 value
+  if (f32 && (ctx->attn_f32_drop & 2)) TTS_HIP(ctx, hipMemsetAsync(wk.vt16_lo.p, 0, (size_t)C * (wk.rows + 128) * 2, ctx->stream));    // v as one fp16 value
   DBG_SUM("attn qk", wk.qk16.p, (size_t)lay.rows * 2048 * 2);
   DBG_SUM("attn vt", wk.vt16.p, (size_t)C * (wk.rows + 128) * 2);
   {
@@ -1270,6 +1272,7 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
     }
     TTS_HIP(ctx, hipGetLastError());
   }
+  if (f32 && (ctx->attn_f32_drop & 4)) TTS_HIP(ctx, hipMemsetAsync(wk.att16_lo.p, 0, (size_t)(wk.rows + 2) * C * 2, ctx->stream));     // attention output as one fp16 value
   DBG_SUM("attn out", wk.ATT16(), (size_t)lay.rows * C * 2);
   if (f32) { // att . W^T = att_hi . W_hi + att_lo . W_hi + att_hi . W_lo  (W scaled by 64 at load)
     GemmArgs p = gemm_base(lay, wk.ATT16(), C, 3, C, w.proj_w_split, C, w.proj_b);
@@ -1283,6 +1286,7 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
     GemmArgs p = gemm_base(lay, wk.ATT16(), C, 2, C, w.proj_w_split, C, w.proj_b);
     p.custom_w = 1; p.ldw_ = 2 * C; p.w_off_[0] = 0; p.w_off_[1] = C;
     p.mode = GEMM_OUT_F32_SCALED; p.alpha = 1.0f / 64.0f; p.outF = X; p.ldo = C; p.resid = X;
+    p.dual_b = ctx->proj_dual_b; // both weight halves per staged activation tile (gemm_f16_vh_dualb_kernel); 0 = two K segments (A/B)
     CHECK(gemm(ctx, "diff_gemm", p, lay, 0, C));
     DBG_SUM("attn proj", X, (size_t)lay.rows * C * 4);
     return TTS_OK;
@@ -1449,7 +1453,13 @@ static int latent_conditioner(tts_ctx *ctx, DiffState *st, const float *latents_
   Layout &ll = st->lat_lay;
   CHECK(ll.build(ctx, lat_lens));
   Work &wk = st->lat_wk;
-  CHECK(wk.reserve(ctx, ll.rows, ll.ns));
+  // Round 5: the conditioner's four AttentionBlocks ALWAYS run in reference precision (option lc_attn_f32, default 1). Their output — the code embedding — is
+  // evaluated once per utterance and enters all 80 / 200 steps: an fp16 rounding inside it is the same perturbation at every step, exactly like the rounding
+  // of the proj_out weight, and does not average out the way the per-step activation roundings of the integrator / main blocks do. Engine-side ablation
+  // (profiles/r5_attention_ablation.txt): with an fp16 conditioner every single operand rounding of the per-step blocks looked 3-4x as expensive as the CPU
+  // emulation (which takes the code embedding from the oracle) said. Cost: four blocks over L = 200 rows once per utterance.
+  const bool lc_ref = ctx->lc_attn_f32 != 0;
+  CHECK(wk.reserve(ctx, ll.rows, ll.ns, lc_ref));
   // latents -> f32 rows of X, then fp16 operand
   TTS_HIP(ctx, hipMemsetAsync(wk.X(), 0, (size_t)ll.rows * C * 4, ctx->stream));
   size_t off = 0;
@@ -1462,7 +1472,7 @@ static int latent_conditioner(tts_ctx *ctx, DiffState *st, const float *latents_
   GemmArgs c3 = gemm_base(ll, wk.A16(), C, 3, C, st->lc_w, C, st->lc_bias);
   c3.mode = GEMM_OUT_F32; c3.outF = wk.X(); c3.ldo = C; c3.resid = nullptr;
   CHECK(gemm(ctx, "diff_gemm", c3, ll));
-  for (int i = 0; i < st->n_lc; i++) CHECK(attention_block(ctx, st, ll, wk, wk.X(), st->lc_attn[i]));
+  for (int i = 0; i < st->n_lc; i++) CHECK(attention_block(ctx, st, ll, wk, wk.X(), st->lc_attn[i], lc_ref));
   CHECK(gn_stats(ctx, ll, wk, wk.X()));
   gn_apply_f32_kernel<<<ll.rows, 256, 0, ctx->stream>>>(wk.X(), ll.d_row_seq.as<int>(), wk.stats.as<float2>(), st->code_g, st->code_b,
                                                         st->cond_latent, wk.H());
@@ -1572,7 +1582,7 @@ static int setup_batch(tts_ctx *ctx, DiffState *st, const float *latents, const 
   if (cond) CHECK(latent_conditioner(ctx, st, latents, L));
   else { // layout still needed by build_code_emb (never dereferenced for uncond rows)
     CHECK(st->lat_lay.build(ctx, L));
-    CHECK(st->lat_wk.reserve(ctx, st->lat_lay.rows, st->lat_lay.ns));
+    CHECK(st->lat_wk.reserve(ctx, st->lat_lay.rows, st->lat_lay.ns, ctx->lc_attn_f32 != 0));
   }
   build_code_emb_kernel<<<il.rows, 256, 0, ctx->stream>>>(st->lat_wk.H(), st->lat_lay.d_start.as<int>(), st->lat_lay.d_len.as<int>(),
                                                           st->uncond_emb, il.d_row_seq.as<int>(), il.d_row_t.as<int>(), il.d_len.as<int>(),

@@ -62,6 +62,7 @@ struct GemmArgs {
   __half *outVt; int ldvt; // QKV: V channels transposed [h*64+d][row]
   __half *outH2, *outVt2;  // GEMM_OUT_QKV_SPLIT: the low halves (same leading dimensions)
   float alpha;             // GEMM_OUT_F32_SCALED
+  int dual_b;              // 1: the two segments are the hi / lo halves of ONE weight over ONE activation operand -> gemm_f16_vh_dualb_kernel (GEMM_OUT_F32_SCALED only)
   int mode;
   // tile walk, set by launch_gemm_f16: th = 16-row blocks per tile (0: chosen from the problem size), cn = column tiles per L2 chunk
   int th, cn;
@@ -340,6 +341,89 @@ __device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, 
   else gemm_epilogue_vh<MODE, MI, EPI_NO_RESID>(g, acc, m0, n0, wm, wn, fr, fq);
 }
 
+// Split-precision WEIGHT, one activation operand (round 5: proj_out of the default AttentionBlock, out = A (W_hi + W_lo)^T): the two weight tiles of a K
+// tile are staged side by side (16 KB A + 2 x 16 KB B = 48 KB, 3 workgroups per CU) and every A fragment read from LDS feeds both products — against two
+// K segments through gemm_vh_body: 48 instead of 64 KB of DMA, 24 instead of 32 KB of fragment reads and 2 instead of 4 barriers per 64 MFMAs.
+// g.W = [N][ldw_] with the hi half at column w_off_[0] and the lo half at w_off_[1] (custom_w); g.nseg == 2, g.A[0] == g.A[1], equal row offsets.
+static constexpr int GEMM_DUALB_LDS = 49152;
+template <int MODE, int MI>
+__device__ __forceinline__ void gemm_vh_dualb_body(const GemmArgs &g, int m0, int n0, int nblk, int lane, int wave) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  char *smem = smem_dyn;
+  constexpr int MA = MI > 0 ? MI : 1;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int my_pa = (2 * nblk - wave + 3) >> 2;
+  const int ntiles = g.kseg >> 6, ldw = g.ldw_;
+  const int prow = lane >> 3, pslot = lane & 7;
+  int aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = (wave + 4 * i) * 8 + prow;
+    aoff[i] = (m0 + row) * g.lda + (pslot ^ lds_swz(row)) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = (wave * 4 + i) * 8 + prow;
+    boff[i] = (n0 + row) * ldw + (pslot ^ lds_swz(row)) * 8;
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  const bool resid_first = gemm_mode_f32(MODE) && g.resid != nullptr;
+  floatx4 acc[MA][4];
+  if (resid_first) {
+    const float rs = MODE == GEMM_OUT_F32_SCALED ? 1.0f / g.alpha : 1.0f;
+#pragma unroll
+    for (int i = 0; i < MI; i++) {
+      const int row = m0 + vh_blk(wm, i) * 16 + fr;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float4 rr = *(const float4 *)(g.resid + (size_t)row * g.ldo + n0 + wn * 64 + j * 16 + fq * 4);
+        acc[i][j] = (floatx4){rr.x * rs, rr.y * rs, rr.z * rs, rr.w * rs};
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  }
+  char *sa = smem, *sb0 = smem + 16384, *sb1 = smem + 32768;
+  const __half *aseg = g.A[0] + (ptrdiff_t)g.row_off[0] * g.lda;
+  const __half *w0 = g.W + g.w_off_[0], *w1 = g.W + g.w_off_[1];
+  for (int kt = 0; kt < ntiles; kt++) {
+    const __half *abase = aseg + (kt << 6), *b0 = w0 + (kt << 6), *b1 = w1 + (kt << 6);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+      if (i < my_pa) __builtin_amdgcn_global_load_lds((gptr_t)(abase + aoff[i]), (lptr_t)(sa + (wave + 4 * i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) __builtin_amdgcn_global_load_lds((gptr_t)(b0 + boff[i]), (lptr_t)(sb0 + (wave * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) __builtin_amdgcn_global_load_lds((gptr_t)(b1 + boff[i]), (lptr_t)(sb1 + (wave * 4 + i) * 1024), 16, 0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      half8 af[MA], bf[4], bl[4];
+#pragma unroll
+      for (int i = 0; i < MI; i++) af[i] = *(const half8 *)(sa + lds_off(vh_blk(wm, i) * 16 + fr, ks * 4 + fq));
+      if (MI > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) bf[i] = *(const half8 *)(sb0 + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < 4; i++) bl[i] = *(const half8 *)(sb1 + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], af[i], acc[i][j], 0, 0, 0); // the small term first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+  if (resid_first) gemm_epilogue_vh<MODE, MI, EPI_RESID_IN_ACC>(g, acc, m0, n0, wm, wn, fr, fq);
+  else gemm_epilogue_vh<MODE, MI, EPI_NO_RESID>(g, acc, m0, n0, wm, wn, fr, fq);
+}
+
 // Tile walk, shared by both kernels. L2-aware: workgroup b runs on XCD b % 8 (each XCD has its own 4 MB L2). An XCD owns a
 // contiguous range of 16-row blocks, cut into tiles of g.th blocks (the last one shorter), and walks them once per chunk of g.cn
 // column tiles, chunk outermost: the chunk's weight rows (cn * 128 * K * 2 B <= ~2.5 MB) stay L2-resident while the activations
@@ -375,6 +459,19 @@ static __global__ __launch_bounds__(256, WGS) void gemm_f16_vh_kernel(GemmArgs g
   else if (my_mi == 2) gemm_vh_body<MODE, 2>(g, m0, n0, nblk, lane, wave);
   else if (my_mi == 1) gemm_vh_body<MODE, 1>(g, m0, n0, nblk, lane, wave);
   else gemm_vh_body<MODE, 0>(g, m0, n0, nblk, lane, wave); // 1-block tile: this wave only moves operands
+}
+
+template <int MODE>
+static __global__ __launch_bounds__(256, 3) void gemm_f16_vh_dualb_kernel(GemmArgs g) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int m0, n0, nblk;
+  if (!gemm_vh_tile(g, m0, n0, nblk)) return;
+  const int my_mi = (nblk - (wave >> 1) + 1) >> 1;
+  if (my_mi == 4) gemm_vh_dualb_body<MODE, 4>(g, m0, n0, nblk, lane, wave);
+  else if (my_mi == 3) gemm_vh_dualb_body<MODE, 3>(g, m0, n0, nblk, lane, wave);
+  else if (my_mi == 2) gemm_vh_dualb_body<MODE, 2>(g, m0, n0, nblk, lane, wave);
+  else if (my_mi == 1) gemm_vh_dualb_body<MODE, 1>(g, m0, n0, nblk, lane, wave);
+  else gemm_vh_dualb_body<MODE, 0>(g, m0, n0, nblk, lane, wave);
 }
 
 // k = 3 convolution as ONE GEMM with a shared activation slab. The three taps are three row-shifted GEMM
@@ -526,6 +623,8 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
     }
     if (g.mode == GEMM_OUT_F32) gemm_f16_conv3_vh_kernel<GEMM_OUT_F32><<<grid, 256, CONV3_VH_LDS, s>>>(gg);
     else gemm_f16_conv3_vh_kernel<GEMM_OUT_F16><<<grid, 256, CONV3_VH_LDS, s>>>(gg);
+  } else if (g.dual_b && g.mode == GEMM_OUT_F32_SCALED && g.nseg == 2 && g.custom_w && g.A[0] == g.A[1] && g.row_off[0] == g.row_off[1]) {
+    gemm_f16_vh_dualb_kernel<GEMM_OUT_F32_SCALED><<<grid, 256, GEMM_DUALB_LDS, s>>>(gg);
   } else if (g.mode == GEMM_OUT_F32) gemm_f16_vh_kernel<GEMM_OUT_F32, 4><<<grid, 256, GEMM_VH_LDS, s>>>(gg);
   else if (g.mode == GEMM_OUT_F16) gemm_f16_vh_kernel<GEMM_OUT_F16, 4><<<grid, 256, GEMM_VH_LDS, s>>>(gg);
   else if (g.mode == GEMM_OUT_QKV) gemm_f16_vh_kernel<GEMM_OUT_QKV, 4><<<grid, 256, GEMM_VH_LDS, s>>>(gg);
