@@ -560,7 +560,7 @@ def main():
     # HBM bytes per GEMM launch from the committed PMC profile (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, calibration in the
     # file's note); null when the profile is absent. bench.py does not run rocprofv3 itself.
     traffic, traffic_src = None, None
-    for prof_name in ("r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):
+    for prof_name in ("r5_pmc_hbm_traffic.json", "r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))["kernels"]
             gk = [v for k, v in prof.items() if "gemm_f16" in k]
@@ -569,8 +569,20 @@ def main():
             break
         except Exception:
             pass
+    # second denominator: the fp16 MFMA peak at the shader clock the chip actually sustains under these kernels (PMC pass: GRBM_GUI_ACTIVE
+    # over the kernel's duration; 1.95-2.2 GHz under MFMA load against the 2.4 GHz the 2.5 PF figure assumes), launch-weighted over the GEMM kernels
+    sus_clk, sus_src = None, None
+    for prof_name in ("r5_pmc_mfma_util.json", "r4_pmc_mfma_util.json"):
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))["kernels"]
+            gk = [v for k, v in prof.items() if "gemm_f16" in k and v.get("dispatches", 0) >= 20]
+            sus_clk = sum(v["dispatches"] * v["avg_us"] * v["shader_clock_MHz"] for v in gk) / max(1e-9, sum(v["dispatches"] * v["avg_us"] for v in gk))
+            sus_src = "profiles/" + prof_name
+            break
+        except Exception:
+            pass
     dec_traffic, dec_traffic_src = None, None  # L2-miss bytes fetched per decode step (PMC FETCH_SIZE pass over the decode launches, committed profile)
-    for prof_name, what in (("r4_pmc_decode_traffic.json", "round-4 kernels"), ("r2_pmc_decode_traffic.json", "round-2 pass: the same slabs are streamed")):
+    for prof_name, what in (("r5_pmc_decode_traffic.json", "round-5 pass"), ("r4_pmc_decode_traffic.json", "round-4 kernels"), ("r2_pmc_decode_traffic.json", "round-2 pass: the same slabs are streamed")):
         try:
             dec_traffic = int(json.load(open(os.path.join(ROOT, "profiles", prof_name)))["fetch_bytes_per_step"])
             dec_traffic_src = "profiles/%s (%s)" % (prof_name, what)
@@ -614,6 +626,8 @@ def main():
         "collective_ranks": collective_ranks, "collective_backend": (a.backend if dist else None), "gathered_samples": shape.get("gathered_samples"),
         "roofline": {"kernel": "gemm_f16_vh_kernel + gemm_f16_conv3_vh_kernel (diffusion convs/projections)", "bound": "mfma",
                      "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
+                     "sustained_shader_clock_MHz": (round(sus_clk) if sus_clk else None), "sustained_clock_source": sus_src,
+                     "frac_of_sustained_clock_peak": (round(achieved / (MFMA_F16_DENSE_PEAK_TFLOPS * sus_clk / 2400.0), 4) if sus_clk else None),
                      "traffic": traffic, "traffic_source": traffic_src, "launches_timed": int(g_n),
                      "launch_sampling": "every %dth launch of the family is bracketed by HIP events" % a.prof_stride,
                      "avg_launch_us": round(1000.0 * g_ms / max(g_n, 1), 2), "algorithmic_gflop_per_launch": round(g_flops / max(g_n, 1) / 1e9, 2),
