@@ -166,6 +166,8 @@ int tts_sample(tts_ctx *ctx, const float *logits, const int32_t *penalty_ids, in
  * and the RNG consumption are those of the two-call sequence, bit for bit. A candidate whose list cannot decide (ties around the cut, see
  * host_logic.cpp: sample_one_list) is sampled from its full row, fetched on demand; tts_ar_topk_fallbacks counts those (candidates x steps of the last
  * tts_ar_step_sample / tts_autoregressive call). tts_autoregressive's loop runs on this path unless option "device_topk" is 0. */
+/* After a tts_ar_step_sample call the host copy of the logits is UNDEFINED: only the rows the sampler had to fetch in full were refreshed (the pinned buffer is shared),
+ * the others still hold an earlier step's values. A caller that needs the logits uses tts_ar_step. Fails with TTS_ERR_STATE before tts_ar_begin. */
 int tts_ar_step_sample(tts_ctx *ctx, const int32_t *prev_ids, int step_i, unsigned flags, int32_t *samples_out);
 int tts_ar_topk_fallbacks(const tts_ctx *ctx);
 /* The whole autoregressive() driver (main.cpp:5042-5367): prefill, sample/decode loop with the

@@ -52,3 +52,17 @@ def test_packed_f32_arithmetic_stays_out_of_the_time_mlp(tmp_path):
             assert not bad, "%s: packed f32 arithmetic in %s" % (os.path.basename(obj), sorted(bad.items(), key=lambda kv: -kv[1])[:8])
         seen_linear = seen_linear or "linear_nk_kernel" in asm
     assert seen_linear and kernels > 50 and mfma > 1000  # the disassembly really is the device code (gfx950 kernels with their MFMA bodies)
+
+
+@pytest.mark.parametrize("defines,src", [(["-DTTS_DEBUG_CHECKSUM"], "diffusion.hip"), (["-DTTS_DEBUG_CHECKSUM", "-DTTS_DEBUG_NO_TIME_GUARD"], "diffusion.hip"),
+                                         (["-DTTS_DEC_TRACE"], "ar.hip")])
+def test_developer_ifdef_builds_still_compile(defines, src):
+    """The trace / checksum #ifdef paths of csrc (developer builds: tools/build_debug_lib.sh, tools/dec_bench.hip) are not part of the product build, so nothing
+    else keeps them compiling: host + device syntax check, a few seconds each."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    d = os.path.join(ROOT, "tortoise.cpp_amd")
+    r = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Icsrc", "-I../include", "-fsyntax-only"] + defines + ["csrc/" + src],
+                       cwd=d, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]

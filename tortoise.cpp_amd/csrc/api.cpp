@@ -368,7 +368,8 @@ static int autoregressive_impl(tts_ctx *c, const int32_t *text_ids, int n_text, 
     t_step += now() - t0;
     t0 = now();
     next.resize(B);
-    if (sample_candidates_list(c, ar_host_lists(c), ids.data(), 1, B, next.data(), [&](int b) { return ar_fetch_logits_row(c, b); }, &c->topk_fallbacks))
+    if (sample_candidates_list(c, ar_host_lists(c), ids.data(), 1, B, next.data(), [&](int b) { return ar_fetch_logits_row(c, b); }, &c->topk_fallbacks,
+                               retire ? done.data() : nullptr))
       return fail(c, TTS_ERR_HIP, "tts_autoregressive: fetching a logits row failed");
     t_sample += now() - t0;
     have_next = true;

@@ -177,7 +177,7 @@ void sample_candidates(tts_ctx *ctx, const float *logits, const int32_t *ids, in
 // of the 8194, in index order (n = -1: no such threshold, the host samples from the full row).
 enum { TTS_PF_MIN = 64, TTS_PF_MAX = 128, TTS_PF_WORDS = 4 + 2 * TTS_PF_MAX };
 int sample_candidates_list(tts_ctx *ctx, const int32_t *lists, const int32_t *ids, int ids_per_cand, int B, int32_t *out,
-                           const std::function<const float *(int)> &full_row, int *n_fallbacks);
+                           const std::function<const float *(int)> &full_row, int *n_fallbacks, const char *retired = nullptr);
 int host_prefilter_row(const float *row, int keep, int32_t *list);
 int sample_one_row(const float *row, const int32_t *ids, int ids_per_cand, float uniform);
 int sample_one_from_list(const int32_t *list, const int32_t *ids, int ids_per_cand, float uniform);

@@ -459,11 +459,15 @@ void sample_candidates(tts_ctx *ctx, const float *logits, const int32_t *ids, in
 // The decode loop's sampler over the device prefilter's lists (ar.hip: [B][TTS_PF_WORDS] = {n, 0, 0, 0, idx[128], logit[128]}), same
 // uniforms, same ids. A candidate whose list cannot decide (n < 0: the device found no threshold keeping 64..128 logits; or
 // sample_one_list's -1) is sampled from its full row, fetched through `full_row` (which applies the stop mask itself).
+// `retired` (may be null): candidates whose sequence has ended (TTS_AR_RETIRE). Their uniforms are drawn like everybody's — the stream stays the reference's — but
+// nothing is sampled for them (out = 8193): round 5's ragged bench pass spent 27 ms per utterance evaluating lists and fetching full logits rows for candidates whose
+// sample the loop then threw away.
 int sample_candidates_list(tts_ctx *ctx, const int32_t *lists, const int32_t *ids, int ids_per_cand, int B, int32_t *out,
-                           const std::function<const float *(int)> &full_row, int *n_fallbacks) {
+                           const std::function<const float *(int)> &full_row, int *n_fallbacks, const char *retired) {
   std::vector<float> samples;
   draw_uniforms(ctx, B, samples);
   auto one = [&](int c) {
+    if (retired && retired[c]) { out[c] = 8193; return; }
     const int32_t *l = lists + (size_t)c * TTS_PF_WORDS;
     const int n = l[0];
     out[c] = (n < 1 || n > TTS_PF_MAX) ? -1
