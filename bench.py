@@ -194,7 +194,7 @@ def main():
     ap.add_argument("--diff-steps", type=int, default=None)
     ap.add_argument("--decode-steps", type=int, default=192, help="sampled codes per candidate (stop token masked) -> L=200, T=870")
     ap.add_argument("--quick", action="store_true", help="tiny layer counts (plumbing check only; NOT the benchmark)")
-    ap.add_argument("--prof-stride", type=int, default=13, help="every Nth GEMM launch is bracketed by a HIP event pair (roofline timing)")
+    ap.add_argument("--prof-stride", type=int, default=13, help="1 GEMM launch in N (hashed decimation per shape class) is bracketed by a HIP event pair (roofline timing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-share-uncond", action="store_true", help="headline pass with the unconditioned integrator layers evaluated per candidate")
     ap.add_argument("--no-ab", action="store_true", help="skip the extra pass that measures the other share_uncond setting")
@@ -377,9 +377,10 @@ def main():
     for w in range(a.warmup):
         one_pass(-1 - w, record=False)
     if not a.dry_engine:
-        # every 13th GEMM launch is bracketed by a HIP event pair (60 launches per diffusion step, 13 is coprime: every launch position is
-        # sampled equally often). An event pair drains the pipeline around its launch: bracketing all ~9 600 launches of the timed region
-        # cost 5 % of the pass, every 7th 0.5 %, every 29th nothing measurable. The decode step is ONE hipGraph replay per event pair.
+        # 1 GEMM launch in 13 is bracketed by a HIP event pair (a hash of each shape class's launch counter decides: every launch position is sampled
+        # equally often whatever the number of launches per step — round 5: with exactly 13 QKV launches per step a plain stride of 13 bracketed the same
+        # layer every time). An event pair drains the pipeline around its launch: bracketing all ~9 600 launches of the timed region cost 5 % of the pass,
+        # 1 in 7 0.5 %, 1 in 29 nothing measurable. The decode step is ONE hipGraph replay per event pair.
         for fam in GEMM_FAMILIES:
             eng.set_option("prof_only:" + fam, 1)
         eng.set_option("prof_only:ar_decode_step", 1)
@@ -629,7 +630,8 @@ def main():
                      "sustained_shader_clock_MHz": (round(sus_clk) if sus_clk else None), "sustained_clock_source": sus_src,
                      "frac_of_sustained_clock_peak": (round(achieved / (MFMA_F16_DENSE_PEAK_TFLOPS * sus_clk / 2400.0), 4) if sus_clk else None),
                      "traffic": traffic, "traffic_source": traffic_src, "launches_timed": int(g_n),
-                     "launch_sampling": "every %dth launch of the family is bracketed by HIP events" % a.prof_stride,
+                     "launch_sampling": "1 launch in %d of every shape class (hashed decimation of the class's launch counter: no period to resonate with the "
+                                        "13 / 16 launches per sampling step) is bracketed by HIP events" % a.prof_stride,
                      "avg_launch_us": round(1000.0 * g_ms / max(g_n, 1), 2), "algorithmic_gflop_per_launch": round(g_flops / max(g_n, 1) / 1e9, 2),
                      # per shape class: its own bound = max(MFMA floor at 2.5 PF, algorithmic bytes at the 6.29 TB/s a streaming kernel reaches)
                      "kernels": gemm_kernel_table(per_kernel)},

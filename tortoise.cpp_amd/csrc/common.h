@@ -148,7 +148,12 @@ struct ProfScope {
       for (const std::string &f : c->prof_filter) want |= (f == fam) || (strncmp(fam, f.c_str(), f.size()) == 0 && fam[f.size()] == '_'); // a name also selects its sub-families
     if (want) {
       ProfEntry &e = c->prof[fam];
-      if (e.seen++ % c->prof_stride == 0) { // work and time are accumulated over the bracketed launches only
+      // Which launches are bracketed: a hash of the family's launch counter, 1 in prof_stride on average. (Rounds 2-4 took every prof_stride-th launch of the
+      // family; round 5's default arithmetic made the QKV projection exactly 13 launches per sampling step and the stride of 13 then bracketed the SAME layer —
+      // one of the three smaller integrator launches — in every step: a biased family average. A hashed decimation has no period to resonate with.)
+      uint32_t hsh = (uint32_t)e.seen++ * 2654435761u;
+      hsh ^= hsh >> 15; hsh *= 0x2c1b3c6du; hsh ^= hsh >> 12;
+      if (c->prof_stride <= 1 || hsh % (uint32_t)c->prof_stride == 0) { // work and time are accumulated over the bracketed launches only
         a = prof_event(c);
         (void)hipEventRecord(a, c->stream);
         e.work += work;
