@@ -24,6 +24,15 @@ def h16(x):
     return x.float().half().to(x.dtype)
 
 
+def stochastic_h16(x, seed):
+    """unbiased stochastic rounding to fp16: RNE of x + u * ulp(x), u uniform in (-0.5, 0.5), generator seeded per (tensor, variant)"""
+    g = torch.Generator().manual_seed(int(seed) & 0x7fffffff)
+    e = torch.floor(torch.log2(x.abs().float().clamp(min=2.0 ** -14)))
+    ulp = torch.pow(2.0, e - 10.0)
+    u = torch.rand(x.shape, generator=g) - 0.5
+    return h16(x.float() + u * ulp).to(x.dtype)
+
+
 def conv1d_f16(x, w, b, padding=0, dilation=1):
     """x [Cin, T], w [Cout, Cin, K] -> [Cout, Tout]; fp16-rounded operands, f32 accumulate."""
     return F.conv1d(h16(x)[None], h16(w), b, padding=padding, dilation=dilation)[0]
@@ -77,7 +86,10 @@ class TorchDiffusion:
         elif isinstance(f16_attention, str):
             f16_attention = tuple(x for x in f16_attention.split(",") if x)
         self.f16_attention = frozenset(f16_attention or ())
-        assert self.f16_attention <= {"qk", "v", "p", "o", "w"}, self.f16_attention
+        # "wd" (round 5 experiment): the proj_out weight as ONE fp16 operand again, but a DIFFERENT unbiased stochastic rounding of it at every sampling step
+        # (self.w_variant, set by the loop driver): the rounding error stops being the same perturbation at all 80 steps
+        assert self.f16_attention <= {"qk", "v", "p", "o", "w", "wd"}, self.f16_attention
+        self.w_variant = 0
         w = self.w
         self.n_lc = 0
         while w.has("latent_conditioner.%d.norm.weight" % (self.n_lc + 1)):
@@ -116,6 +128,8 @@ class TorchDiffusion:
             if "o" in r:
                 a = h16(a)
             pw = w[p + ".proj_out.weight"]
+            if "wd" in r:
+                pw = stochastic_h16(pw, (hash(p) & 0xffff) * 1009 + self.w_variant)
             o = F.conv1d(a[None], (h16(pw) if "w" in r else pw).reshape(C, C, 1), w[p + ".proj_out.bias"])[0]
             return x + o
         att = torch.einsum("hdi,hdj->hij", q, k) * (1.0 / 8.0) + bias
