@@ -84,6 +84,10 @@ const char *tts_last_error(const tts_ctx *ctx);
  * those products runs on split-precision fp16 pairs (x = hi + lo, three MFMAs per product, 2^-22 relative) and SiLU is the reference's f32 formula: the
  * 80-step sampling loop then stays as close to the CPU restatement as a second f32 evaluation of the reference's graph does (tests/golden/parity_floor.json).
  * Costs about 1.5x the diffusion stage's time; may be switched between calls.
+ * "lc_attn_f32" (1 default): the latent conditioner's AttentionBlocks (main.cpp:3156-3321; evaluated once per utterance, their output enters every sampling step) run in
+ * the reference precision of "attn_f32" whatever that option says — an fp16 rounding inside them would be the same perturbation at all 80 steps; 0 = follow "attn_f32".
+ * With the defaults (attn_f32 0, attn_proj_f16 0, lc_attn_f32 1) the 80-step loop sits on the same floor as attn_f32 = 1 (1.6e-3 max / 7.0e-5 mean at the benchmark's
+ * length against 1.3e-3 / 6.1e-5) at +4 % of the stage's time instead of +46 %; the parity tests hold both to the same gates.
  * "attn_proj_f16" (0 default): the default (throughput) AttentionBlock keeps q, k, v, the softmax numerators and the attention output as fp16 MFMA
  * operands but multiplies proj_out — an F32 linear in the reference — on its weight held as the split pair W_hi + W_lo (two MFMAs per product). Of the five
  * fp16 roundings of the rounds 1-4 block only the WEIGHT's survives 80 steps (the same perturbation at every step; tests/golden/parity_floor.json
