@@ -117,6 +117,33 @@ def test_sampling_loop_200_steps_config5(engine, oracle, small_models):
         engine.set_option("attn_f32", 0)
 
 
+def test_what_the_default_arithmetic_relies_on(engine, oracle, mid_models):
+    """The round-5 finding, on the engine itself (mid depth, T = 52, 80 steps, same explicit noise): the two roundings that are the SAME perturbation at every step — the
+    proj_out weight (option attn_proj_f16) and anything inside the once-per-utterance latent conditioner (option lc_attn_f32) — each move the mean distance from the oracle,
+    the default (neither) sits with the reference-precision mode. CPU emulation of the same ladder: tests/golden/parity_floor.json "ablation"."""
+    engine.load(diffusion=mid_models + "/ggml-diffusion-model.bin")
+    od = oracle.Diffusion(oracle.Model(mid_models + "/ggml-diffusion-model.bin"))
+    L = 12
+    lat = np.random.RandomState(L).randn(L, 1024).astype(np.float32)
+    noise = np.random.RandomState(5).randn(81, 100 * engine.frames(L)).astype(np.float32)
+    want = od.sample(lat, n_steps=80, noise=noise)
+    modes = {"default": (0, 0, 1), "fp16 conditioner": (0, 0, 0), "fp16 proj_out weight": (0, 1, 1), "all fp16 (rounds 1-4)": (0, 1, 0), "attn_f32": (1, 0, 1)}
+    mean = {}
+    try:
+        for name, (f32, pw16, lc) in modes.items():
+            for k, v in (("attn_f32", f32), ("attn_proj_f16", pw16), ("lc_attn_f32", lc)):
+                engine.set_option(k, v)
+            mean[name] = float(np.abs(engine.diffusion([lat], n_steps=80, noise=[noise])[0] - want).mean())
+    finally:
+        for k, v in (("attn_f32", 0), ("attn_proj_f16", 0), ("lc_attn_f32", 1)):
+            engine.set_option(k, v)
+    print("mean abs distance from the oracle, mid depth, 80 steps: " + ", ".join("%s %.2e" % kv for kv in mean.items()))
+    assert mean["default"] < 1.2 * mean["attn_f32"]                       # measured 6.1e-5 vs 5.6e-5
+    assert mean["fp16 conditioner"] > 1.25 * mean["default"]             # 9.1e-5
+    assert mean["fp16 proj_out weight"] > 1.2 * mean["default"]          # 8.2e-5
+    assert mean["all fp16 (rounds 1-4)"] > 1.5 * mean["default"]         # 1.08e-4
+
+
 def test_reference_noise_stream(engine, oracle, small_models):
     """noise_mode REFERENCE consumes the ctx RNG exactly like the reference: x_T then one vector per step."""
     engine.load(diffusion=small_models + "/ggml-diffusion-model.bin")
