@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 5, GPU call 8: the driver's bench command with the hashed launch sampling + rocprofv3 kernel stats of the same command on the same box
+# round 5: the driver's bench command with the hashed launch sampling + rocprofv3 kernel stats of the same command on the same box
 cd "$(dirname "$0")/../.." || exit 1
-R=$(pwd); out=gpurun_out/r5c8; mkdir -p $out
+R=$(pwd); out=gpurun_out/r5bench; mkdir -p $out
 export TMPDIR=/tmp
 t0=$(date +%s)
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_n1.json 2> $out/bench_n1.err; echo "bench rc=$? [$(( $(date +%s) - t0 )) s]"; head -c 300 $out/bench_n1.json; echo

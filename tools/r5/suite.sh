@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 5, GPU call 6: the whole GPU suite + smoke with the unified loop gates
+# round 5: the whole GPU suite + smoke with the unified loop gates
 cd "$(dirname "$0")/../.." || exit 1
-out=gpurun_out/r5c6; mkdir -p $out
+out=gpurun_out/r5suite; mkdir -p $out
 export TMPDIR=/tmp
 t0=$(date +%s)
 timeout 2000 python -m pytest tests -m gpu -q -s > $out/tests.log 2>&1; echo "tests rc=$? [$(( $(date +%s) - t0 )) s]"
