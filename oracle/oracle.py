@@ -93,7 +93,8 @@ class Rng:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_rng_free(self.h)
+            if lib is not None:  # None while the interpreter shuts down (module globals are cleared before the last objects die)
+                lib().orc_rng_free(self.h)
             self.h = None
 
     def seed(self, s):
@@ -180,7 +181,8 @@ class Tokenizer:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_tokenizer_free(self.h)
+            if lib is not None:  # None while the interpreter shuts down (module globals are cleared before the last objects die)
+                lib().orc_tokenizer_free(self.h)
             self.h = None
 
     def encode(self, msg):
@@ -201,7 +203,8 @@ class Model:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_model_free(self.h)
+            if lib is not None:  # None while the interpreter shuts down (module globals are cleared before the last objects die)
+                lib().orc_model_free(self.h)
             self.h = None
 
     def tensor(self, name):
@@ -224,7 +227,8 @@ class AR:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_ar_free(self.h)
+            if lib is not None:  # None while the interpreter shuts down (module globals are cleared before the last objects die)
+                lib().orc_ar_free(self.h)
             self.h = None
 
     @property
@@ -275,7 +279,8 @@ class Diffusion:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_diff_free(self.h)
+            if lib is not None:  # None while the interpreter shuts down (module globals are cleared before the last objects die)
+                lib().orc_diff_free(self.h)
             self.h = None
 
     @staticmethod
@@ -314,7 +319,8 @@ class Vocoder:
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().orc_voc_free(self.h)
+            if lib is not None:  # None while the interpreter shuts down (module globals are cleared before the last objects die)
+                lib().orc_voc_free(self.h)
             self.h = None
 
     def run(self, mel, rng=None, noise=None):
