@@ -282,3 +282,21 @@ def test_cli_rccl_exchange_four_ranks_on_the_cpu(tmp_path, fake_rccl):
     r = subprocess.run(base + ["--output", str(tmp_path / "z.wav"), "--devices", "2", "--exchange", "rccl"], capture_output=True, text=True, timeout=120,
                        env=dict(env, TTS_RCCL_LIB=str(tmp_path / "no_such_lib.so")))
     assert r.returncode != 0 and "TTS_RCCL_LIB" in r.stderr
+
+
+def test_bench_eight_ranks_gloo_dry_engine():
+    """The rank count the driver's scaling run uses: `python bench.py --gpus 8` launches its own eight ranks (torch.distributed.run, 127.0.0.1), every rank a host-only
+    context (--dry-engine), gloo for the collectives: rendezvous, the all_reduce of ones (collective_ranks = 8), prompt / voice broadcast, size all_gather, gather of the
+    results on rank 0, MAX-over-ranks timing — for the strong-scaling workload (configs[3]: 64 candidates, 8 per rank) and the 8-prompt one (configs[4])."""
+    import json
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for config, per_gpu, prompts in ((4, 8, 1), (5, 16, 8)):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--dry-engine", "--config", str(config), "--steps", "1", "--warmup", "0",
+               "--no-cpu-baseline"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert out["n_gpus"] == 8 and out["collective_ranks"] == 8 and out["collective_backend"] == "gloo" and out["scaling"] == "strong"
+        assert out["config"]["candidates_per_gpu"] == per_gpu and out["config"]["prompts"] == prompts and out["gathered_samples"] > 0
