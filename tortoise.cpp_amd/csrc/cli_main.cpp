@@ -99,13 +99,19 @@ int main(int argc, char **argv) {
     // One engine process per GPU. Two on ONE device is not a deployment form: round 4 saw a kernel's packed f32 FMAs return wrong sums while another
     // process's MFMA waves shared the GPU (profiles/r4_two_process_determinism.txt). The library is built without packed f32 arithmetic since round 5
     // (tortoise.cpp_amd/Makefile), but the form stays unsupported: refused unless --allow-shared-device 1 (tests on a one-GPU box).
-    if (!dry && !allow_shared)
-      for (int r = 0; r < devices; r++)
-        for (int q = 0; q < r; q++)
-          if ((r < (int)map.size() ? map[r] : r) == (q < (int)map.size() ? map[q] : q)) {
+    bool shared = false;
+    for (int r = 0; r < devices; r++)
+      for (int q = 0; q < r; q++)
+        if ((r < (int)map.size() ? map[r] : r) == (q < (int)map.size() ? map[q] : q)) {
+          shared = true;
+          if (!dry && !allow_shared) {
             fprintf(stderr, "--device-map %s: workers %d and %d would share a GPU (unsupported; --allow-shared-device 1 to run anyway)\n", device_map.c_str(), q, r);
             return 1;
           }
+        }
+    // --allow-shared-device with --exchange files: the workers run ONE AFTER THE OTHER, so no two engine processes are ever busy on the same GPU (an RCCL exchange
+    // needs all ranks alive at once — and a distinct GPU per rank, which RCCL itself enforces)
+    const bool serial = shared && !dry && exchange == "files";
     if (!have_seed) // every worker must draw from the same stream
       seed = (int)(std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count() & 0x7fffffff);
     std::string id_hex;
@@ -134,7 +140,10 @@ int main(int argc, char **argv) {
         perror("execv");
         _exit(127);
       }
-      pids.push_back(pid);
+      if (serial) {
+        int st = 0;
+        if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) return 1;
+      } else pids.push_back(pid);
     }
     int rc = 0;
     std::vector<pid_t> alive = pids;
