@@ -12,6 +12,8 @@ offline (ggml-fork constants: GroupNorm eps, fp16 activation tables — both exp
 Reference line numbers are /root/reference/main.cpp. The fp16 rounding points are the reference's: conv1d rounds weights and
 the im2col'd input to fp16 and accumulates in f32; the AR stack rounds QKV to fp16 (main.cpp:2789-2790).
 """
+import zlib
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -31,6 +33,30 @@ def stochastic_h16(x, seed):
     ulp = torch.pow(2.0, e - 10.0)
     u = torch.rand(x.shape, generator=g) - 0.5
     return h16(x.float() + u * ulp).to(x.dtype)
+
+
+def dither_h16(x, n, j, seed):
+    """Round 6 (generalised): the j-th member of a PERIOD-n dither cycle of fp16 roundings of x. Every member is one of the two fp16 neighbours
+    of x (floor / ceil on the fp16 grid); over one cycle exactly round(n * frac) members are the upper neighbour, spread evenly (Bresenham) from a per-element random
+    phase, so the cycle MEAN is within ulp / (2 n) of x and every partial sum of the rounding errors stays within one ulp — no linear drift (RNE: the same error at
+    every step) and no random walk (independent stochastic rounding). n = 2 is the antithetic pair; members are plain fp16 tensors (one GEMM operand each)."""
+    xf = x.double()
+    lo = xf.float().half()                                     # RNE, then step to the neighbour at or below x
+    lo = torch.where(lo.double() > xf, torch.nextafter(lo, torch.tensor(-float("inf"), dtype=torch.half)), lo)
+    hi = torch.nextafter(lo, torch.tensor(float("inf"), dtype=torch.half))
+    lod, hid = lo.double(), hi.double()
+    frac = ((xf - lod) / (hid - lod)).clamp(0.0, 1.0)          # position between the neighbours
+    k = torch.round(frac * n)                                  # members of the cycle that take the upper neighbour
+    g = torch.Generator().manual_seed(int(seed) & 0x7fffffff)
+    phase = torch.rand(x.shape, generator=g, dtype=torch.float64)
+    up = torch.floor((j % n + 1) * k / n + phase) - torch.floor((j % n) * k / n + phase)
+    return torch.where(up > 0.5, hid, lod).to(x.dtype)
+
+
+def antithetic_h16(x, j):
+    """VERDICT r5 item 4 as written: W_a = fp16(W) on even steps, W_b = fp16(2 W - W_a) on odd ones"""
+    a = h16(x)
+    return a if j % 2 == 0 else h16(2.0 * x - a)
 
 
 def conv1d_f16(x, w, b, padding=0, dilation=1):
@@ -88,7 +114,13 @@ class TorchDiffusion:
         self.f16_attention = frozenset(f16_attention or ())
         # "wd" (round 5 experiment): the proj_out weight as ONE fp16 operand again, but a DIFFERENT unbiased stochastic rounding of it at every sampling step
         # (self.w_variant, set by the loop driver): the rounding error stops being the same perturbation at all 80 steps
-        assert self.f16_attention <= {"qk", "v", "p", "o", "w", "wd"}, self.f16_attention
+        # "wa" / "wb<n>" (round 6): the antithetic pair / a period-n Bresenham dither cycle of fp16 roundings of the proj_out weight, member = sampling step mod n
+        self.w_dither = 0
+        for name in self.f16_attention:
+            if name.startswith("wb"):
+                self.w_dither = int(name[2:])
+        assert all(x in {"qk", "v", "p", "o", "w", "wd", "wa"} or x.startswith("wb") for x in self.f16_attention), self.f16_attention
+        self.step_index = 0  # set by the loop driver for "wa" / "wb<n>"
         self.w_variant = 0
         w = self.w
         self.n_lc = 0
@@ -129,7 +161,11 @@ class TorchDiffusion:
                 a = h16(a)
             pw = w[p + ".proj_out.weight"]
             if "wd" in r:
-                pw = stochastic_h16(pw, (hash(p) & 0xffff) * 1009 + self.w_variant)
+                pw = stochastic_h16(pw, (zlib.crc32(p.encode()) & 0xffff) * 1009 + self.w_variant)  # (a str hash is randomised per process)
+            if "wa" in r:
+                pw = antithetic_h16(pw, self.step_index)
+            if self.w_dither:
+                pw = dither_h16(pw, self.w_dither, self.step_index, zlib.crc32(p.encode()))
             o = F.conv1d(a[None], (h16(pw) if "w" in r else pw).reshape(C, C, 1), w[p + ".proj_out.bias"])[0]
             return x + o
         att = torch.einsum("hdi,hdj->hij", q, k) * (1.0 / 8.0) + bias

@@ -148,6 +148,7 @@ def ablate(kind, L, seed, steps=80, sets=None):
             t = steps - 1 - idx
             te = O.timestep_embedding(int(tm[t]))
             xc = x.reshape(100, T)
+            net.step_index = idx  # "wa" / "wb<n>": member of the antithetic pair / dither cycle = sampling step
             net.w_variant = idx % int(os.environ.get("TTS_ABLATION_WD_VARIANTS", "1000"))  # "wd": a different stochastic rounding of the proj_out weights per step
             x = O.diffusion_update(tm, t, net.forward(ce, xc, te), net.forward(None, xc, te), x, noise[idx + 1], T)
         d = np.abs(x.reshape(100, T) - want)

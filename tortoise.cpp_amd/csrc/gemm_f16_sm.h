@@ -1,0 +1,403 @@
+// Small-problem ("latency mode") GEMM family of the diffusion stage for gfx950: one utterance = 2 sequences x 870 frames = 1 792 packed rows,
+// which the batch kernels of gemm_f16.h run at a tenth of the matrix peak (one 4-wave workgroup alone on a CU walking a 16..48-step chain of
+// exposed DMA round trips, and a GroupNorm launch in front of every GEMM: 125 launches per sampling step).
+//
+//   C[m][n] = sum_tap sum_k  op(A)[m + tap - (TAPS == 3)][k] * W[n][tap * K + k]      (+ bias, + residual, guard rows forced to zero)
+//
+// One workgroup = 8 waves (2 x 4) on a 64 x (64 NJ) output tile, ONE workgroup per CU (the grid of a 1 792-row problem offers no more), so what
+// the batch kernels get from four co-resident workgroups has to come from inside the workgroup:
+//  * every operand is double-buffered in LDS and requested one phase (one 64-deep K tile x one tap) ahead by global_load_lds_dwordx4; a phase is
+//    [s_waitcnt vmcnt(0); s_barrier; issue the next phase's loads; fragment reads + MFMAs (+ the operand transform for the next K chunk)]:
+//    one barrier per phase, the loads of phase p + 1 in flight under the MFMAs of phase p, two waves per SIMD;
+//  * AGN: the A operand is the f32 residual stream itself. Its raw 64 (+ 2 halo rows for the k = 3 taps) x 64-channel tile is DMA'd into LDS two K
+//    chunks ahead and turned into the fp16 MFMA image by the workgroup — GroupNorm(32) normalise, gamma / beta, the timestep's scale / shift, SiLU,
+//    fp16 round: the arithmetic of gn_reg_kernel, element for element in the same order — while the matrix pipe works on the previous chunk. The
+//    GroupNorm launches (43 of the 125 per step) disappear; their statistics come from the PRODUCING GEMM's epilogue:
+//  * STATS: the epilogue of every f32 output reduces sum / sum of squares of the stored values per (8-row chunk, 32-channel group) — sequences start at
+//    multiples of 8 rows, so a chunk belongs to one sequence — and adds them to a per-(sequence, group) accumulator in 128-bit fixed point (two int64
+//    atomics per quantity: units 2^-8 and 2^-60): integer addition is associative, so the statistics do not depend on the order the workgroups
+//    finish in — the mode is deterministic run to run, although not bit-identical to the batch path (different K order, statistics from
+//    E[x^2] - E[x]^2 in f64 instead of the two-pass form).
+//  * QKV (NJ = 6: 64 x 384 = two heads per tile, 224 workgroups for N = 3 072): q | k columns with swapped operands (16-byte stores), V columns in
+//    natural order (stored transposed), chosen per 16-column block at compile time; DUALB: proj_out on the split-precision weight (both halves of
+//    a K tile staged, every A fragment feeds two MFMAs).
+// Used by diffusion.hip when option latency_mode = 1 and the packed layout has at most LAT_MAX_ROWS rows; the batch path (and its bit-for-bit
+// batch invariance) is untouched.
+#pragma once
+#include "gemm_f16.h"
+
+namespace tts {
+
+struct GemmSmArgs {
+  // A operand. AGN == 0: fp16 rows [-1 .. M][lda] (zero halo rows), TAPS == 1: up to two K segments (channel concat); AGN == 1: f32 rows [M][lda]
+  const __half *A16[2];
+  const float *A32;
+  int lda, nseg, kseg; // kseg % 64 == 0
+  // GroupNorm of the A operand (AGN)
+  const long long *st_in;                    // [ns][32][4]: {sum hi, sum lo, sum of squares hi, lo} fixed point (see fx_add)
+  const float *gamma, *beta, *scale, *shift; // [K]; scale / shift point at zeros when the block has no timestep conditioning
+  const int *seq_len;                        // [ns]
+  const int4 *tile_seqs;                     // [M / 64]: the (at most 4) sequences owning rows of the window [m0 - 1, m0 + 66), -1 = none
+  float eps;
+  int silu;
+  // weights [N][ldw] fp16; TAPS == 3: tap-major K (ldw = 3 kseg); DUALB: the low half of the split pair starts at column w_lo_off
+  const __half *W;
+  int ldw, w_lo_off;
+  int M, N; // M % 64 == 0, N % (64 NJ) == 0
+  const float *bias;  // [N]
+  const int *row_seq; // [M]: < 0 = guard / padding row (output forced to zero, A operand zero)
+  // GEMM_OUT_F32 / GEMM_OUT_F32_SCALED: out = alpha * acc + bias + resid
+  float *outF; int ldo; const float *resid; float alpha;
+  // GEMM_OUT_QKV
+  __half *outH; int ldh; __half *outVt; int ldvt;
+  // STATS of the output
+  long long *st_out;    // [ns][32][4]
+  const int *chunk_seq; // [M / 8]: owning sequence of an aligned 8-row chunk, -1 = all guard rows
+};
+
+// 128-bit fixed point accumulation of an f32 partial sum: hi in units of 2^-8 (|p| < 2^55), the exact remainder in units of 2^-60.
+__device__ __forceinline__ void fx_add(long long *dst, float p) {
+  const float h = rintf(p * 256.0f);
+  const float rem = p - h * (1.0f / 256.0f); // exact: |rem| <= 2^-9, or 0 when ulp(p) >= 2^-8
+  atomicAdd((unsigned long long *)dst, (unsigned long long)(long long)h);
+  atomicAdd((unsigned long long *)dst + 1, (unsigned long long)(long long)rintf(rem * 4503599627370496.0f)); // 2^52
+}
+__host__ __device__ __forceinline__ double fx_value(long long hi, long long lo) { return (double)hi * (1.0 / 256.0) + (double)lo * (1.0 / 1152921504606846976.0); }
+
+template <int CTRL> __device__ __forceinline__ float sm_dpp(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+// sum over the lanes that differ in bits 0-2 and 4-5 (the 8 rows of a half block x the 4 column quads of a 16x16 accumulator): lanes 0 and 8 of the
+// wave end up with the totals of rows 0-7 / 8-15. Fixed tree: deterministic.
+__device__ __forceinline__ float sm_red_half_block(float x) {
+  x += sm_dpp<0xB1>(x);  // quad_perm [1,0,3,2]: lane ^ 1
+  x += sm_dpp<0x4E>(x);  // quad_perm [2,3,0,1]: lane ^ 2
+  x += sm_dpp<0x141>(x); // row_half_mirror: quads are uniform now, 7 - l swaps the two quads of a half row: lane ^ 4
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+template <int NJ, int TAPS, bool AGN, bool DUALB> constexpr int gemm_sm_lds() {
+  constexpr int AROWS = TAPS == 3 ? 72 : 64;
+  return 2 * AROWS * 128 + (AGN ? 2 * AROWS * 256 + 2 * 1024 + 1024 : 0) + 2 * NJ * 64 * 128 * (DUALB ? 2 : 1);
+}
+
+template <int MODE, int NJ, int TAPS, bool AGN, bool DUALB, bool STATS>
+static __global__ __launch_bounds__(512, 2) void gemm_f16_sm_kernel(GemmSmArgs g) {
+  static_assert(!(AGN && DUALB), "not instantiated");
+  constexpr int BN = NJ * 64, AROWS = TAPS == 3 ? 72 : 64, AUSED = TAPS == 3 ? 66 : 64;
+  constexpr int IMG_B = AROWS * 128, RAW_B = AGN ? AROWS * 256 : 0, PAR_B = AGN ? 1024 : 0, MR_B = AGN ? 1024 : 0;
+  constexpr int BHALF = BN * 128, BST_B = BHALF * (DUALB ? 2 : 1);
+  constexpr int O_RAW = 2 * IMG_B, O_PAR = O_RAW + 2 * RAW_B, O_MR = O_PAR + 2 * PAR_B, O_B = O_MR + MR_B;
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[]; // ONE LDS object (a second one makes hipcc drain the DMA queue in front of every fragment read)
+  char *smem = smem_dyn;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3, fr = lane & 15, fq = lane >> 4;
+  // tile walk: workgroup b runs on XCD b % 8; an XCD owns a contiguous range of 64-row tiles and every column tile of them (its activations stay in its L2)
+  const int MT = g.M >> 6, NT = g.N / BN;
+  int m0, n0, tile;
+  {
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int t0 = MT * xcd >> 3, t1 = MT * (xcd + 1) >> 3;
+    if (idx >= (t1 - t0) * NT) return;
+    tile = t0 + idx / NT;
+    m0 = tile << 6;
+    n0 = (idx % NT) * BN;
+  }
+  const int cps = g.kseg >> 6, nchunks = g.nseg * cps, nph = nchunks * TAPS;
+  const int prow = lane >> 3, pslot = lane & 7;
+  // per-lane DMA source offsets
+  int boff[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; i++) {
+    const int row = (wave * NJ + i) * 8 + prow;
+    boff[i] = (n0 + row) * g.ldw + (pslot ^ lds_swz(row)) * 8;
+  }
+  int aoff[2] = {0, 0}; // fp16 A: piece `wave` (8 image rows), wave 0 also piece 8 (the halo rows of the k = 3 slab)
+  int roff[3] = {0, 0, 0}; // raw f32 A: pieces 2 wave, 2 wave + 1 (4 rows each), wave 0 also piece 16
+  const float *parp = nullptr;
+  if (!AGN) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int s = (wave + 8 * i) * 8 + prow;
+      aoff[i] = min(m0 - (TAPS == 3 ? 1 : 0) + s, g.M) * g.lda + (pslot ^ lds_swz(s)) * 8;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int s = (i < 2 ? wave * 2 + i : 16) * 4 + (lane >> 4);
+      roff[i] = min(max(m0 - (TAPS == 3 ? 1 : 0) + s, 0), g.M - 1) * g.lda + (lane & 15) * 4;
+    }
+    const int which = lane >> 4;
+    parp = (which == 0 ? g.gamma : which == 1 ? g.beta : which == 2 ? g.scale : g.shift) + (lane & 15) * 4;
+  }
+  auto issueB = [&](int p, int buf) {
+    const int kc = p / TAPS, tap = p - kc * TAPS;
+    const __half *src = g.W + (TAPS == 3 ? tap * g.kseg : 0) + (kc << 6);
+    char *dst = smem + O_B + buf * BST_B + wave * NJ * 1024;
+#pragma unroll
+    for (int i = 0; i < NJ; i++) __builtin_amdgcn_global_load_lds((gptr_t)(src + boff[i]), (lptr_t)(dst + i * 1024), 16, 0, 0);
+    if (DUALB) {
+#pragma unroll
+      for (int i = 0; i < NJ; i++) __builtin_amdgcn_global_load_lds((gptr_t)(src + g.w_lo_off + boff[i]), (lptr_t)(dst + BHALF + i * 1024), 16, 0, 0);
+    }
+  };
+  auto issueA16 = [&](int kc, int buf) {
+    const int seg = TAPS == 3 ? 0 : kc / cps;
+    const __half *src = g.A16[seg] + ((kc - seg * cps) << 6);
+    char *dst = smem + buf * IMG_B;
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + aoff[0]), (lptr_t)(dst + wave * 1024), 16, 0, 0);
+    if (TAPS == 3 && wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(src + aoff[1]), (lptr_t)(dst + 8 * 1024), 16, 0, 0);
+  };
+  auto issueRAW = [&](int kc, int buf) {
+    const float *src = g.A32 + (kc << 6);
+    char *dst = smem + O_RAW + buf * RAW_B;
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + roff[0]), (lptr_t)(dst + (wave * 2) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(src + roff[1]), (lptr_t)(dst + (wave * 2 + 1) * 1024), 16, 0, 0);
+    if (TAPS == 3 && wave == 0) __builtin_amdgcn_global_load_lds((gptr_t)(src + roff[2]), (lptr_t)(dst + 16 * 1024), 16, 0, 0);
+    if (wave == 7) __builtin_amdgcn_global_load_lds((gptr_t)(parp + (kc << 6)), (lptr_t)(smem + O_PAR + buf * PAR_B), 16, 0, 0);
+  };
+  // operand transform of one K chunk: raw f32 tile -> GroupNorm / affine / scale-shift / SiLU -> fp16 image (the arithmetic of gn_reg_kernel)
+  int myslot[3] = {-1, -1, -1};
+  auto transform = [&](int kc, int buf) {
+    const char *raw = smem + O_RAW + buf * RAW_B, *par = smem + O_PAR + buf * PAR_B;
+    char *img = smem + buf * IMG_B;
+    const int quad = tid & 15, row0 = tid >> 4, grp = kc * 2 + (quad >> 3);
+    const float4 ga = *(const float4 *)(par + quad * 16), be = *(const float4 *)(par + 256 + quad * 16);
+    const float4 sc = *(const float4 *)(par + 512 + quad * 16), sh = *(const float4 *)(par + 768 + quad * 16);
+    const float ge[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+    const float s1[4] = {sc.x + 1.0f, sc.y + 1.0f, sc.z + 1.0f, sc.w + 1.0f}, s0[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+    for (int k = 0; k < (AUSED > 64 ? 3 : 2); k++) {
+      const int s = row0 + 32 * k;
+      if (k < 2 || s < AUSED) {
+        const float4 x = *(const float4 *)(raw + s * 256 + quad * 16);
+        const int sl = myslot[k];
+        const float2 mr = *(const float2 *)(smem + O_MR + ((max(sl, 0) * 32 + grp) << 3));
+        float e[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          float u = (e[i] - mr.x) * mr.y;
+          u = u * ge[i];
+          u = u + bb[i];
+          u = u * s1[i];
+          u = u + s0[i];
+          if (g.silu) u = u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(u * -1.44269504088896f));
+          e[i] = sl < 0 ? 0.f : u;
+        }
+        *(uint2 *)(img + lds_off(s, quad >> 1) + (quad & 1) * 8) = pack_half4(e[0], e[1], e[2], e[3]);
+      }
+    }
+  };
+  // accumulators start from the residual (see gemm_vh_body); acc[i][j][r] = C[m0 + wm*32 + i*16 + fr][n0 + wn*16 NJ + j*16 + fq*4 + r] (swapped operand order)
+  floatx4 acc[2][NJ];
+  const int col0 = n0 + wn * NJ * 16 + fq * 4;
+  if (gemm_mode_f32(MODE) && g.resid != nullptr) {
+    const float rs = MODE == GEMM_OUT_F32_SCALED ? 1.0f / g.alpha : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const float *rp = g.resid + (size_t)(m0 + wm * 32 + i * 16 + fr) * g.ldo + col0;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const float4 rr = *(const float4 *)(rp + j * 16);
+        acc[i][j] = (floatx4){rr.x * rs, rr.y * rs, rr.z * rs, rr.w * rs};
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++) acc[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
+  }
+  if (AGN) {
+    const int4 ts = g.tile_seqs[tile];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int s = (tid >> 4) + 32 * k, grow = m0 - (TAPS == 3 ? 1 : 0) + s;
+      const int sq = (s < AUSED && grow >= 0 && grow < g.M) ? g.row_seq[grow] : -1;
+      myslot[k] = sq < 0 ? -1 : sq == ts.x ? 0 : sq == ts.y ? 1 : sq == ts.z ? 2 : sq == ts.w ? 3 : -1;
+    }
+    if (tid < 128) { // mean / rstd of (slot, group) from the producer's fixed-point sums
+      const int slot = tid >> 5, grp = tid & 31;
+      const int seq = slot == 0 ? ts.x : slot == 1 ? ts.y : slot == 2 ? ts.z : ts.w;
+      float2 mr = make_float2(0.f, 0.f);
+      if (seq >= 0) {
+        const long long *sp = g.st_in + (size_t)(seq * 32 + grp) * 4;
+        const double n = (double)g.seq_len[seq] * 32.0;
+        const double mean = fx_value(sp[0], sp[1]) / n;
+        const double var = fmax(fx_value(sp[2], sp[3]) / n - mean * mean, 0.0);
+        mr = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)g.eps)));
+      }
+      *(float2 *)(smem + O_MR + (tid << 3)) = mr;
+    }
+    issueRAW(0, 0);
+    if (nchunks > 1) issueRAW(1, 1);
+  } else {
+    issueA16(0, 0);
+  }
+  issueB(0, 0);
+  if (AGN) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    transform(0, 0);
+  }
+  // one phase = one 64-deep K tile of one tap. NAT_FROM: 16-column blocks j >= NAT_FROM use the natural operand order (V columns of the QKV projection)
+  auto run = [&](auto nat_c) {
+    constexpr int NAT_FROM = decltype(nat_c)::value;
+    for (int kc = 0; kc < nchunks; kc++) {
+#pragma unroll
+      for (int tap = 0; tap < TAPS; tap++) {
+        const int p = kc * TAPS + tap;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // everything requested one phase ago has landed; this wave's LDS reads / image writes are done
+        __builtin_amdgcn_s_barrier();
+        if (p + 1 < nph) issueB(p + 1, (p + 1) & 1);
+        if (tap == 0) {
+          if (AGN) { if (kc + 2 < nchunks) issueRAW(kc + 2, kc & 1); }
+          else if (kc + 1 < nchunks) issueA16(kc + 1, (kc + 1) & 1);
+        }
+        const char *img = smem + (kc & 1) * IMG_B, *bst = smem + O_B + (p & 1) * BST_B;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+          half8 af[2], bf[NJ], bl[DUALB ? NJ : 1];
+#pragma unroll
+          for (int i = 0; i < 2; i++) af[i] = *(const half8 *)(img + lds_off(wm * 32 + i * 16 + fr + tap, ks * 4 + fq));
+#pragma unroll
+          for (int j = 0; j < NJ; j++) bf[j] = *(const half8 *)(bst + lds_off(wn * NJ * 16 + j * 16 + fr, ks * 4 + fq));
+          if (DUALB) {
+#pragma unroll
+            for (int j = 0; j < NJ; j++) bl[j] = *(const half8 *)(bst + BHALF + lds_off(wn * NJ * 16 + j * 16 + fr, ks * 4 + fq));
+          }
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) {
+              if (DUALB) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], af[i], acc[i][j], 0, 0, 0); // the small term first
+              if (j >= NAT_FROM) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+              else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (AGN && tap == TAPS - 1 && kc + 1 < nchunks) transform(kc + 1, (kc + 1) & 1);
+      }
+    }
+  };
+  // QKV, N tile = two heads: wave wn covers columns wn * 96 .. + 95 of 384 = [q 64 | k 64 | v 64] x 2: odd waves hold k (j 0-1) and v (j 2-5)
+  const bool has_v = MODE == GEMM_OUT_QKV && (wn & 1);
+  if (MODE == GEMM_OUT_QKV && has_v) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, NJ>{});
+
+  // ---- epilogue: every load first, then the stores
+  const bool hb = g.bias != nullptr;
+  const float *bp = hb ? g.bias : (const float *)g.W;
+  int sq[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) sq[i] = g.row_seq[m0 + wm * 32 + i * 16 + fr];
+  if (MODE == GEMM_OUT_QKV) {
+    static_assert(MODE != GEMM_OUT_QKV || NJ == 6, "QKV tiles are two heads wide");
+    const int c0 = n0 + wn * 96; // 192 | n0
+    float4 b4[NJ];
+    float bn[NJ];
+    int4 sqn[2];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { b4[j] = *(const float4 *)(bp + c0 + j * 16 + fq * 4); bn[j] = bp[c0 + j * 16 + fr]; }
+#pragma unroll
+    for (int i = 0; i < 2; i++) sqn[i] = *(const int4 *)(g.row_seq + m0 + wm * 32 + i * 16 + fq * 4);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const int cj = c0 + j * 16, h = cj / 192, w = cj - h * 192;
+      if (has_v && j >= 2) { // natural order: acc[i][j][r] = C[row = .. + fq*4 + r][col = cj + fr] -> V^T[h*64 + w - 128 + fr][row]
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          const int rbase = m0 + wm * 32 + i * 16 + fq * 4;
+          const bool gd[4] = {sqn[i].x < 0, sqn[i].y < 0, sqn[i].z < 0, sqn[i].w < 0};
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; r++) v[r] = gd[r] ? 0.f : acc[i][j][r] + (hb ? bn[j] : 0.f);
+          *(uint2 *)(g.outVt + (size_t)(h * 64 + w - 128 + fr) * g.ldvt + rbase) = pack_half4(v[0], v[1], v[2], v[3]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          const float4 b = hb ? b4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+          float4 v = make_float4(acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w);
+          if (sq[i] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          *(uint2 *)(g.outH + (size_t)(m0 + wm * 32 + i * 16 + fr) * g.ldh + h * 128 + w + fq * 4) = pack_half4(v.x, v.y, v.z, v.w);
+        }
+      }
+    }
+    return;
+  }
+  float4 b4[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) b4[j] = *(const float4 *)(bp + col0 + j * 16);
+  int cseq[2] = {-1, -1};
+  if (STATS) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) cseq[i] = g.chunk_seq[((m0 + wm * 32 + i * 16) >> 3) + (fr >> 3)];
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    float *op = g.outF + (size_t)(m0 + wm * 32 + i * 16 + fr) * g.ldo + col0;
+    float4 v[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      if (MODE == GEMM_OUT_F32_SCALED) acc[i][j] *= g.alpha;
+      const float4 b = hb ? b4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[j] = make_float4(acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w);
+      if (sq[i] < 0) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      *(float4 *)(op + j * 16) = v[j];
+    }
+    if (STATS) {
+#pragma unroll
+      for (int jp = 0; jp < NJ / 2; jp++) { // 32 columns = one GroupNorm group
+        const float4 a = v[2 * jp], b = v[2 * jp + 1];
+        float s = ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+        float q = ((a.x * a.x + a.y * a.y) + (a.z * a.z + a.w * a.w)) + ((b.x * b.x + b.y * b.y) + (b.z * b.z + b.w * b.w));
+        s = sm_red_half_block(s);
+        q = sm_red_half_block(q);
+        if ((lane & 0x37) == 0 && cseq[i] >= 0) { // lanes 0 and 8: rows 0-7 / 8-15 of the block
+          long long *dst = g.st_out + (size_t)(cseq[i] * 32 + ((n0 + wn * NJ * 16) >> 5) + jp) * 4;
+          fx_add(dst, s);
+          fx_add(dst + 2, q);
+        }
+      }
+    }
+  }
+}
+
+template <int MODE, int NJ, int TAPS, bool AGN, bool DUALB, bool STATS>
+static inline hipError_t launch_gemm_sm_t(const GemmSmArgs &g, hipStream_t s) {
+  // at least 84 KB: never two of these workgroups on one CU (the grid is sized for one per CU; a pair would leave another CU idle)
+  constexpr int LDS = gemm_sm_lds<NJ, TAPS, AGN, DUALB>() > 86016 ? gemm_sm_lds<NJ, TAPS, AGN, DUALB>() : 86016;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void *)gemm_f16_sm_kernel<MODE, NJ, TAPS, AGN, DUALB, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  const int MT = g.M >> 6, NT = g.N / (NJ * 64);
+  int mx = 0;
+  for (int x = 0; x < 8; x++) mx = std::max(mx, (MT * (x + 1) >> 3) - (MT * x >> 3));
+  gemm_f16_sm_kernel<MODE, NJ, TAPS, AGN, DUALB, STATS><<<8 * mx * NT, 512, LDS, s>>>(g);
+  return hipGetLastError();
+}
+
+// The shapes of the diffusion network (diffusion.hip: network_forward_lat)
+enum { SM_K1_GN = 0,      // in_layers: silu(gn(x)) . W, f32 out + stats
+       SM_K3_GN = 1,      // out_layers: k = 3 conv of silu(gn(h)(1 + scale) + shift), + residual, f32 out + stats
+       SM_QKV_GN = 2,     // AttentionBlock norm + qkv projection
+       SM_PROJ_DUALB = 3, // proj_out on the split-precision weight, + residual, f32 out + stats
+       SM_K1_F16 = 4 };   // fp16 operands (integrating conv over [inp | code_emb]), f32 out + stats
+static inline hipError_t launch_gemm_sm(int kind, const GemmSmArgs &g, hipStream_t s) {
+  switch (kind) {
+    case SM_K1_GN: return launch_gemm_sm_t<GEMM_OUT_F32, 2, 1, true, false, true>(g, s);
+    case SM_K3_GN: return launch_gemm_sm_t<GEMM_OUT_F32, 2, 3, true, false, true>(g, s);
+    case SM_QKV_GN: return launch_gemm_sm_t<GEMM_OUT_QKV, 6, 1, true, false, false>(g, s);
+    case SM_PROJ_DUALB: return launch_gemm_sm_t<GEMM_OUT_F32_SCALED, 2, 1, false, true, true>(g, s);
+    case SM_K1_F16: return launch_gemm_sm_t<GEMM_OUT_F32, 2, 1, false, false, true>(g, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+} // namespace tts
