@@ -198,6 +198,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-share-uncond", action="store_true", help="headline pass with the unconditioned integrator layers evaluated per candidate")
     ap.add_argument("--no-ab", action="store_true", help="skip the extra pass that measures the other share_uncond setting")
+    ap.add_argument("--latency-mode", action="store_true", help="option latency_mode for the headline pass too (it only acts on diffusion batches of <= 4096 packed rows: "
+                    "--candidates 1 or 2); the single-utterance A/B below always measures both settings")
     ap.add_argument("--no-diff-graph", action="store_true", help="A/B: launch every diffusion step eagerly instead of replaying the captured step graph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU plumbing test with --dry-engine)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (and run every collective of the N > 1 path) even for ONE rank: "
@@ -293,6 +295,8 @@ def main():
         eng.load(model_dir)
     if a.no_diff_graph and not a.dry_engine:
         eng.set_option("diff_graph", 0)
+    if a.latency_mode and not a.dry_engine:
+        eng.set_option("latency_mode", 1)
     if cand_total:
         eng.set_option("rng_shard_offset", cand0)
         eng.set_option("rng_shard_total", cand_total)
@@ -482,7 +486,7 @@ def main():
                                     ": sampled ids follow the f32 run until the first draw that lands on the other side of a CDF edge"}
         f16, fp8 = reports["f16"], reports["fp8"]
     # ---- what a real batch looks like, outside the headline's timed region like the other A/B passes -------------------------
-    ragged = single_ms = first_audio = clvp = None
+    ragged = single_ms = single_lat = first_audio = clvp = None
     if world == 1 and not a.no_ab and not a.dry_engine and a.config == 3:
         eng.set_option("share_uncond", 1)
         # (a) RAGGED batch: trained weights stop every candidate at its own step (main.cpp:5188-5249); random-init ones never stop, so a stop SCHEDULE
@@ -512,21 +516,34 @@ def main():
                           "vocoder shapes; second of two passes. tests/test_ragged_gpu.py: every candidate of this batch equals the candidate run alone"}
         # (b) ONE utterance (what ./tortoise runs, main.cpp:6570), (c) time to the first audio: AR + the whole diffusion loop (GroupNorm and attention are global
         # over the utterance: no chunked diffusion) + ONE vocoder window of 32 frames (tts_vocoder_chunk, 0.34 s of audio) instead of the full vocoder pass
-        tl = []
-        for rep in range(3):
-            eng.seed(31)
-            t_a = time.time()
-            _, _, lats_1, _ = eng.autoregressive(prompts[0], voice, 1, S, mask_stop=True)
-            t_b = time.time()
-            mels_1 = eng.diffusion(lats_1, n_steps=n_diff, noise_mode=pkg.NOISE_DEVICE)
-            t_c = time.time()
-            eng.vocoder(mels_1, noise_mode=pkg.NOISE_DEVICE)
-            t_d = time.time()
-            nz1 = np.random.RandomState(3).randn(64, mels_1[0].shape[1] + 10).astype(np.float32)
-            t_e = time.time()
-            first = eng.vocoder_chunk(mels_1[0], nz1, 0, 32)
-            t_f = time.time()
-            tl.append((t_d - t_a, t_b - t_a, t_c - t_b, t_d - t_c, t_f - t_e))
+        def one_utterance(reps):
+            out = []
+            for rep in range(reps):
+                eng.seed(31)
+                t_a = time.time()
+                _, _, lats_1, _ = eng.autoregressive(prompts[0], voice, 1, S, mask_stop=True)
+                t_b = time.time()
+                mels_1 = eng.diffusion(lats_1, n_steps=n_diff, noise_mode=pkg.NOISE_DEVICE)
+                t_c = time.time()
+                eng.vocoder(mels_1, noise_mode=pkg.NOISE_DEVICE)
+                t_d = time.time()
+                nz1 = np.random.RandomState(3).randn(64, mels_1[0].shape[1] + 10).astype(np.float32)
+                t_e = time.time()
+                first = eng.vocoder_chunk(mels_1[0], nz1, 0, 32)
+                t_f = time.time()
+                out.append((t_d - t_a, t_b - t_a, t_c - t_b, t_d - t_c, t_f - t_e))
+            return out, first, mels_1
+        eng.set_option("latency_mode", 0)
+        tl, first, mels_def = one_utterance(3)
+        # the same utterance with option latency_mode (GroupNorm statistics from the GEMM epilogues; opt-in: not bit-identical to the batch path, same oracle gates)
+        eng.set_option("latency_mode", 1)
+        tl_lat, _, mels_lat = one_utterance(3)
+        eng.set_option("latency_mode", 1 if a.latency_mode else 0)
+        bl = min(tl_lat[1:])
+        single_lat = {"ms": round(1e3 * bl[0], 1), "stage_ms": {"ar": round(1e3 * bl[1], 1), "diffusion": round(1e3 * bl[2], 1), "vocoder": round(1e3 * bl[3], 1)},
+                      "mel_max_abs_diff_vs_default": float(np.abs(mels_lat[0] - mels_def[0]).max()),
+                      "note": "option latency_mode = 1: same seed, same device noise; the mel differs from the default path's by the chaos of 80 steps (both sit inside the "
+                              "same oracle gates: tests/test_latency_mode_gpu.py)"}
         best = min(tl[1:])
         single_ms = round(1e3 * best[0], 1)
         first_audio = {"one_utterance_ms": round(1e3 * (best[1] + best[2] + best[4]), 1),
@@ -622,7 +639,7 @@ def main():
         "ar_weights_f16_option": f16,
         "ar_weights_fp8_option": fp8,
         "reference_precision_option": ref_prec,
-        "ragged_batch": ragged, "single_utterance_ms": single_ms, "first_audio_ms": first_audio, "clvp_ms": clvp,
+        "ragged_batch": ragged, "single_utterance_ms": single_ms, "single_utterance_latency_mode": single_lat, "first_audio_ms": first_audio, "clvp_ms": clvp,
         # the collective backend has seen this many ranks (all_reduce of ones) and rank 0 has gathered this many audio samples in the last pass
         "collective_ranks": collective_ranks, "collective_backend": (a.backend if dist else None), "gathered_samples": shape.get("gathered_samples"),
         "roofline": {"kernel": "gemm_f16_vh_kernel + gemm_f16_conv3_vh_kernel (diffusion convs/projections)", "bound": "mfma",

@@ -256,9 +256,24 @@ int main(int argc, char **argv) {
 #endif
       fflush(stdout);
     }
-    auto l_b = [&] { CK(launch_gemm_f16(b, s)); };
-    printf("%-44s batch  %10.1f %10.1f\n", sh_.name, time_warm(l_b), time_cold(l_b));
-    fflush(stdout);
+    // the batch kernel, K tiles per barrier pair (ku) x tile height in 16-row blocks (th; 0 = the launcher's choice): bit-identical results required
+    std::vector<float> base((size_t)M * N);
+    std::vector<__half> baseqk((size_t)(M + 128) * 2048);
+    for (int ku : {1, 2, 4})
+      for (int th : {0, 2, 4, 8}) {
+        if (sh_.taps == 3 || sh_.kind == SM_PROJ_DUALB) { if (ku > 1) continue; }
+        GemmArgs bb = b; bb.ku = ku; bb.th = th;
+        CK(hipMemsetAsync(dRef, 0xff, (size_t)M * N * 4, s)); CK(hipMemsetAsync(dQK, 0xff, (size_t)(M + 128) * 2048 * 2, s));
+        CK(launch_gemm_f16(bb, s)); CK(hipStreamSynchronize(s));
+        std::vector<float> o((size_t)M * N); std::vector<__half> oqk((size_t)(M + 128) * 2048);
+        CK(hipMemcpy(o.data(), dRef, o.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(oqk.data(), dQK, oqk.size() * 2, hipMemcpyDeviceToHost));
+        const bool qkv = sh_.kind == SM_QKV_GN;
+        if (ku == 1 && th == 0) { base = o; baseqk = oqk; }
+        const bool same = qkv ? !memcmp(oqk.data(), baseqk.data(), (size_t)M * 2048 * 2) : !memcmp(o.data(), base.data(), o.size() * 4);
+        auto l_b = [&] { CK(launch_gemm_f16(bb, s)); };
+        printf("%-44s batch ku=%d th=%d %8.1f %10.1f   %s\n", sh_.name, ku, th, time_warm(l_b), time_cold(l_b), same ? "bit-identical to ku=1 th=auto" : "DIFFERS");
+        fflush(stdout);
+      }
   }
   return 0;
 }

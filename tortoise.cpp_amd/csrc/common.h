@@ -106,6 +106,7 @@ struct tts_ctx {
   int attn_f32_drop = 0;   // option "attn_f32_drop" (developer ablation inside attn_f32 = 1): bit 0 q/k, bit 1 v, bit 2 attention output lose their low halves (= the fp16 rounding of the default mode, one operand at a time)
   int lc_attn_f32 = 1;     // option "lc_attn_f32": the latent conditioner's AttentionBlocks (once per utterance; their output enters every step) in reference precision whatever attn_f32 says; 0 = follow attn_f32 (rounds 1-4)
   int attn_proj_f16 = 0;   // option "attn_proj_f16": 1 = proj_out's weight as ONE fp16 operand (the all-fp16 AttentionBlock of rounds 1-4, A/B only); 0 default = split pair W_hi + W_lo (F32-accurate weight, round 5)
+  int latency_mode = 0;    // option "latency_mode": small diffusion batches (<= 4096 packed rows) take the GroupNorm statistics from the producing GEMM's epilogue (diffusion.hip: gn_apply_kernel); not bit-identical to the batch path
   bool capturing = false;  // a hipGraph is being captured on the stream: ProfScope records nothing (event records would become graph nodes)
   int diff_graph = 1;      // option "diff_graph": the diffusion step is captured once per call and replayed (0: every step launched eagerly)
   int prof_eager_every = 8; // while a diff_* family is profiled, every Nth diffusion step runs eagerly with its event pairs; the others replay the graph

@@ -24,6 +24,7 @@
 namespace tts {
 
 static constexpr int C = 1024, NHEAD = 16, XTC = 128 /* x_t channels padded 100 -> 128 */;
+static constexpr int LAT_MAX_ROWS = 4096; // option latency_mode applies to packed layouts of at most this many rows (two utterances, both guidance branches)
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -779,7 +780,7 @@ struct ResDev { float *in_g, *in_b, *in_bias, *emb_w, *emb_b, *out_g, *out_b, *o
 struct Layout {
   int ns = 0, rows = 0;
   std::vector<int> start, len;
-  DevBuf d_row_seq, d_row_t, d_start, d_len;
+  DevBuf d_row_seq, d_row_t, d_start, d_len, d_chunk_seq; // chunk_seq[r / 8]: owning sequence of an aligned 8-row chunk (-1: guard rows only)
   int build(tts_ctx *ctx, const std::vector<int> &lens) {
     ns = (int)lens.size();
     len = lens;
@@ -796,6 +797,11 @@ struct Layout {
     TTS_HIP(ctx, hipMemcpy(d_row_t.p, rt.data(), rows * 4, hipMemcpyHostToDevice));
     TTS_HIP(ctx, hipMemcpy(d_start.p, start.data(), ns * 4, hipMemcpyHostToDevice));
     TTS_HIP(ctx, hipMemcpy(d_len.p, len.data(), ns * 4, hipMemcpyHostToDevice));
+    std::vector<int> cs(rows / 8, -1);
+    for (int s = 0; s < ns; s++)
+      for (int t = 0; t < lens[s]; t++) cs[(start[s] + t) >> 3] = s; // start % 8 == 0 and a guard row follows every sequence: one owner per chunk
+    TTS_HIP(ctx, d_chunk_seq.reserve(rows / 8 * 4));
+    TTS_HIP(ctx, hipMemcpy(d_chunk_seq.p, cs.data(), rows / 8 * 4, hipMemcpyHostToDevice));
     return TTS_OK;
   }
   int max_len() const { return len.empty() ? 0 : *std::max_element(len.begin(), len.end()); }
@@ -807,6 +813,9 @@ struct Work {
   int rows = 0;
   DevBuf x, hbuf, a16, att16, qk16, vt16, stats;
   DevBuf att16_lo, qk16_lo, vt16_lo; // low halves of the split-precision pairs (option attn_f32)
+  // option latency_mode: fixed-point GroupNorm statistics (gemm_f16.h: fx_add) of the tensor the blocks of this layout work on (X or the code embedding) and of H,
+  // left by the epilogue of the GEMM that produced them; nullptr = not available (the batch path reduces them in the GroupNorm kernel)
+  long long *st_x = nullptr, *st_h = nullptr;
   float *X() { return x.as<float>(); }
   float *H() { return hbuf.as<float>(); }
   __half *A16() { return a16.as<__half>() + C; }
@@ -854,6 +863,12 @@ struct DiffState {
   bool share_integ = false;
   DevBuf ce_src, iseq_src;
   DevBuf h0; // in_layers of the first integrator ResBlock applied to the code embedding: the same at every step
+  // option latency_mode (small layouts): per sampling step one statistics slot per f32 GEMM output, zeroed at the start of the step; h0's slot persists
+  bool lat = false;
+  DevBuf gn_stats, gn_stats_h0;
+  int gn_site = 0, gn_sites_max = 0;
+  size_t gn_slot_ll = 0, gn_stripe_ll = 0; // long longs per slot = FX_STRIPES stripes x (sequences x 32 groups x 4)
+  long long *new_stats_slot() { long long *p = gn_stats.as<long long>() + (size_t)gn_site * gn_slot_ll; gn_site++; return p; }
   DevBuf step_tab, step_ctr, ss_cur; // StepEntry[n_steps] | int step counter | this step's scale/shift block (fixed address)
   hipGraph_t step_graph = nullptr;
   hipGraphExec_t step_exec = nullptr;
@@ -1220,12 +1235,106 @@ static int gn_fused(tts_ctx *ctx, const Layout &lay, const float *x, const float
   return TTS_OK;
 }
 
+// GroupNorm with the statistics already reduced (option latency_mode): the epilogue of the GEMM that produced x left sum / sum of squares per (sequence, group) in
+// fixed point (gemm_f16.h: GEMM_OUT_*_STATS, fx_add), so nothing here waits for a reduction over the sequence. One workgroup = 4 packed rows x 1024 channels (half an
+// aligned 8-row chunk: one sequence): 448 workgroups for one utterance against the 64 (one per sequence and group, each streaming its 111 KB slab alone) of
+// gn_reg_kernel, whose 8.7 us per launch x 43 launches are 18 % of the single-utterance sampling step. Same arithmetic per element, in the same order, as
+// gn_reg_kernel; mean / variance from E[x] and E[x^2] - E[x]^2 in f64 (the sums are exact integers) instead of its two-pass f32 form. Every row of the layout is
+// written (guard rows: zeros). Weight touch as in gn_reg_kernel.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const int *__restrict__ chunk_seq, const int *__restrict__ seq_start,
+                                                       const int *__restrict__ seq_len, const long long *__restrict__ st, int stripe_ll, float eps, const float *__restrict__ g,
+                                                       const float *__restrict__ b, const float *__restrict__ ss, int do_silu, int lut, __half *__restrict__ y,
+                                                       const char *__restrict__ pf0, int pf0_lines, const char *__restrict__ pf1, int pf1_lines) {
+  __shared__ float2 mr[32];
+  __shared__ unsigned pf_sink[4][64];
+  const int r0 = blockIdx.x * 4, s = chunk_seq[blockIdx.x >> 1], c = threadIdx.x * 4;
+  float4 v[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) v[r] = *(const float4 *)(x + (size_t)(r0 + r) * C + c);
+  {
+    const int gi = blockIdx.x * 256 + threadIdx.x, tt = gridDim.x * 256;
+    unsigned *sink = &pf_sink[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)][0];
+    for (int l = gi; l < pf0_lines; l += tt) __builtin_amdgcn_global_load_lds((gptr_t)(pf0 + (size_t)l * 128), (lptr_t)sink, 4, 0, 0);
+    for (int l = gi; l < pf1_lines; l += tt) __builtin_amdgcn_global_load_lds((gptr_t)(pf1 + (size_t)l * 128), (lptr_t)sink, 4, 0, 0);
+  }
+  int nvalid = 0; // rows of this workgroup inside the sequence (its start is chunk-aligned: only the end can fall inside)
+  if (s >= 0) {
+    nvalid = min(max(seq_start[s] + seq_len[s] - r0, 0), 4);
+    if (threadIdx.x < 32) {
+      long long a[4] = {0, 0, 0, 0};
+      longlong2 u[FX_STRIPES][2];
+#pragma unroll
+      for (int k = 0; k < FX_STRIPES; k++) { // all stripes requested at once: one round trip
+        const long long *sp = st + (size_t)k * stripe_ll + (size_t)(s * 32 + threadIdx.x) * 4;
+        u[k][0] = *(const longlong2 *)sp; u[k][1] = *(const longlong2 *)(sp + 2);
+      }
+#pragma unroll
+      for (int k = 0; k < FX_STRIPES; k++) { a[0] += u[k][0].x; a[1] += u[k][0].y; a[2] += u[k][1].x; a[3] += u[k][1].y; } // integer sums: exact, any order
+      const double n = (double)seq_len[s] * 32.0;
+      const double mean = fx_value(a[0], a[1]) / n;
+      const double var = fmax(fx_value(a[2], a[3]) / n - mean * mean, 0.0);
+      mr[threadIdx.x] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+    }
+  }
+  __syncthreads();
+  const float2 m = mr[c >> 5];
+  const float4 gg = *(const float4 *)(g + c), bb = *(const float4 *)(b + c);
+  float sc4[4] = {1.f, 1.f, 1.f, 1.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ss) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) { sc4[i] = ss[c + i] + 1.0f; sh4[i] = ss[C + c + i]; }
+  }
+  const float ge[4] = {gg.x, gg.y, gg.z, gg.w}, be[4] = {bb.x, bb.y, bb.z, bb.w};
+  auto apply = [&](auto mode) {
+    constexpr int MODE = decltype(mode)::value; // as gn_reg_kernel
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      float e[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float u = (e[i] - m.x) * m.y;
+        u = u * ge[i];
+        u = u + be[i];
+        u = u * sc4[i];
+        u = u + sh4[i];
+        if (MODE) u = silu_dev(u, MODE - 1);
+        e[i] = r < nvalid ? u : 0.f;
+      }
+      const __half2 p0 = __floats2half2_rn(e[0], e[1]), p1 = __floats2half2_rn(e[2], e[3]);
+      uint2 o;
+      o.x = *(const unsigned *)&p0;
+      o.y = *(const unsigned *)&p1;
+      *(uint2 *)(y + (size_t)(r0 + r) * C + c) = o;
+    }
+  };
+  if (!do_silu) apply(std::integral_constant<int, 0>{});
+  else if (lut == 0) apply(std::integral_constant<int, 1>{});
+  else if (lut == 1) apply(std::integral_constant<int, 2>{});
+  else apply(std::integral_constant<int, 3>{});
+  if (pf0_lines | pf1_lines) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// GroupNorm front end: st_x != nullptr (option latency_mode, statistics left by the producing GEMM) -> gn_apply_kernel, else the reducing kernels of gn_fused
+static int gn(tts_ctx *ctx, const DiffState *st, const Layout &lay, const float *x, const long long *st_x, const float *g, const float *b, const float *ss, int do_silu,
+              __half *y, const void *wa = nullptr, size_t wa_bytes = 0, const void *wb = nullptr, size_t wb_bytes = 0) {
+  if (!st_x) return gn_fused(ctx, lay, x, g, b, ss, do_silu, y, wa, wa_bytes, wb, wb_bytes);
+  ProfScope ps(ctx, "diff_gn_apply");
+  const int silu_mode = ctx->ggml_lut ? 1 : ctx->attn_f32 ? 2 : 0; // see silu_dev
+  gn_apply_kernel<<<lay.rows / 4, 256, 0, ctx->stream>>>(x, lay.d_chunk_seq.as<int>(), lay.d_start.as<int>(), lay.d_len.as<int>(), st_x, (int)st->gn_stripe_ll, ctx->gn_eps, g, b,
+                                                          ss, do_silu, silu_mode, y, (const char *)wa, (int)(wa_bytes >> 7), (const char *)wb, (int)(wb_bytes >> 7));
+  TTS_HIP(ctx, hipGetLastError());
+  return TTS_OK;
+}
+
 // in_layers of a ResBlock (GroupNorm, SiLU, conv k=1): H = conv(silu(gn(x))). No timestep dependence.
-static int res_in_layers(tts_ctx *ctx, const Layout &lay, Work &wk, const float *x, const ResDev &w, float *H) {
-  CHECK(gn_fused(ctx, lay, x, w.in_g, w.in_b, nullptr, 1, wk.A16(), w.in_w, (size_t)C * C * 2));
+// st_x: statistics of x (nullptr: reduce them here); st_h_out: where the GEMM's epilogue leaves the statistics of H (nullptr: none) — option latency_mode
+static int res_in_layers(tts_ctx *ctx, const DiffState *st, const Layout &lay, Work &wk, const float *x, const ResDev &w, float *H,
+                         const long long *st_x = nullptr, long long *st_h_out = nullptr) {
+  CHECK(gn(ctx, st, lay, x, st_x, w.in_g, w.in_b, nullptr, 1, wk.A16(), w.in_w, (size_t)C * C * 2));
   DBG_SUM("res.in gn", wk.A16(), (size_t)lay.rows * C * 2);
   GemmArgs g = gemm_base(lay, wk.A16(), C, 1, C, w.in_w, C, w.in_bias);
-  g.mode = GEMM_OUT_F32; g.outF = H; g.ldo = C; g.resid = nullptr;
+  g.mode = st_h_out ? GEMM_OUT_F32_STATS : GEMM_OUT_F32; g.outF = H; g.ldo = C; g.resid = nullptr;
+  g.st_out = st_h_out; g.st_stripe_ll = (int)st->gn_stripe_ll; g.chunk_seq = lay.d_chunk_seq.as<int>();
   CHECK(gemm(ctx, "diff_gemm", g, lay));
   DBG_SUM("res.in conv", H, (size_t)lay.rows * C * 4);
   return TTS_OK;
@@ -1244,8 +1353,11 @@ static int res_in_layers(tts_ctx *ctx, const Layout &lay, Work &wk, const float 
 static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, float *X, const AttnDev &w, bool force_ref = false) {
   const bool f32 = ctx->attn_f32 != 0 || force_ref;
   const bool pw16 = !f32 && ctx->attn_proj_f16; // weight touch for the two GEMMs that follow: the proj_out matrix this mode will stream
-  CHECK(gn_fused(ctx, lay, X, w.norm_g, w.norm_b, nullptr, 0, wk.A16(), w.qkv_w, (size_t)3 * C * C * 2, pw16 ? w.proj_w : w.proj_w_split,
-                 (size_t)C * C * (pw16 ? 2 : 4)));
+  const bool lat = st->lat && wk.st_x != nullptr; // option latency_mode: X's statistics come from (and go to) the GEMM epilogues
+  CHECK(gn(ctx, st, lay, X, lat ? wk.st_x : nullptr, w.norm_g, w.norm_b, nullptr, 0, wk.A16(), w.qkv_w, (size_t)3 * C * C * 2, pw16 ? w.proj_w : w.proj_w_split,
+           (size_t)C * C * (pw16 ? 2 : 4)));
+  long long *st_out = lat ? st->new_stats_slot() : nullptr;
+  wk.st_x = st_out;
   DBG_SUM("attn gn", wk.A16(), (size_t)lay.rows * C * 2);
   GemmArgs g = gemm_base(lay, wk.A16(), C, 1, C, w.qkv_w, 3 * C, w.qkv_b);
   g.mode = f32 ? GEMM_OUT_QKV_SPLIT : GEMM_OUT_QKV;
@@ -1279,20 +1391,23 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
     p.A[0] = wk.ATT16(); p.A[1] = wk.att16_lo.as<__half>() + C; p.A[2] = wk.ATT16();
     p.row_off[0] = p.row_off[1] = p.row_off[2] = 0;
     p.custom_w = 1; p.ldw_ = 2 * C; p.w_off_[0] = 0; p.w_off_[1] = 0; p.w_off_[2] = C;
-    p.mode = GEMM_OUT_F32_SCALED; p.alpha = 1.0f / 64.0f; p.outF = X; p.ldo = C; p.resid = X;
+    p.mode = st_out ? GEMM_OUT_F32_SCALED_STATS : GEMM_OUT_F32_SCALED; p.alpha = 1.0f / 64.0f; p.outF = X; p.ldo = C; p.resid = X;
+    p.st_out = st_out; p.st_stripe_ll = (int)st->gn_stripe_ll; p.chunk_seq = lay.d_chunk_seq.as<int>();
     return gemm(ctx, "diff_gemm", p, lay, 0, C);
   }
   if (!ctx->attn_proj_f16) { // default: att16 . (W_hi + W_lo)^T — proj_out's F32 weight to 2^-22, the attention output stays one fp16 operand
     GemmArgs p = gemm_base(lay, wk.ATT16(), C, 2, C, w.proj_w_split, C, w.proj_b);
     p.custom_w = 1; p.ldw_ = 2 * C; p.w_off_[0] = 0; p.w_off_[1] = C;
-    p.mode = GEMM_OUT_F32_SCALED; p.alpha = 1.0f / 64.0f; p.outF = X; p.ldo = C; p.resid = X;
+    p.mode = st_out ? GEMM_OUT_F32_SCALED_STATS : GEMM_OUT_F32_SCALED; p.alpha = 1.0f / 64.0f; p.outF = X; p.ldo = C; p.resid = X;
+    p.st_out = st_out; p.st_stripe_ll = (int)st->gn_stripe_ll; p.chunk_seq = lay.d_chunk_seq.as<int>();
     p.dual_b = ctx->proj_dual_b; // both weight halves per staged activation tile (gemm_f16_vh_dualb_kernel); 0 = two K segments (A/B)
     CHECK(gemm(ctx, "diff_gemm", p, lay, 0, C));
     DBG_SUM("attn proj", X, (size_t)lay.rows * C * 4);
     return TTS_OK;
   }
   GemmArgs p = gemm_base(lay, wk.ATT16(), C, 1, C, w.proj_w, C, w.proj_b);
-  p.mode = GEMM_OUT_F32; p.outF = X; p.ldo = C; p.resid = X;
+  p.mode = st_out ? GEMM_OUT_F32_STATS : GEMM_OUT_F32; p.outF = X; p.ldo = C; p.resid = X;
+  p.st_out = st_out; p.st_stripe_ll = (int)st->gn_stripe_ll; p.chunk_seq = lay.d_chunk_seq.as<int>();
   CHECK(gemm(ctx, "diff_gemm", p, lay));
   DBG_SUM("attn proj", X, (size_t)lay.rows * C * 4);
   return TTS_OK;
@@ -1301,19 +1416,27 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
 // ResBlock: X = Xin + out_layers(in_layers(Xin) with the step's scale/shift); Xin == nullptr: in place on X.
 // ss = this step's [scale | shift] for this block (device, 2048 floats). Hpre: in_layers(Xin) computed earlier (it does
 // not depend on the timestep), nullptr: computed here.
+// st_hpre: the statistics of Hpre (option latency_mode; the first integrator block's h0 keeps them across the steps)
 static int res_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work &wk, float *X, const ResDev &w, const float *ss,
-                     const float *Xin = nullptr, const float *Hpre = nullptr) {
+                     const float *Xin = nullptr, const float *Hpre = nullptr, const long long *st_hpre = nullptr) {
   const float *xin = Xin ? Xin : X;
+  const bool lat = st->lat && (Hpre ? st_hpre != nullptr : wk.st_x != nullptr);
+  const long long *st_h = st_hpre;
   if (!Hpre) {
-    CHECK(res_in_layers(ctx, lay, wk, xin, w, wk.H()));
+    long long *slot = lat ? st->new_stats_slot() : nullptr;
+    CHECK(res_in_layers(ctx, st, lay, wk, xin, w, wk.H(), lat ? wk.st_x : nullptr, slot));
     Hpre = wk.H();
+    st_h = slot;
   }
   DBG_SUM("res.out ss", ss, (size_t)2 * C * 4);
   DBG_SUM("res.out hpre", Hpre, (size_t)lay.rows * C * 4);
-  CHECK(gn_fused(ctx, lay, Hpre, w.out_g, w.out_b, ss, 1, wk.A16(), w.out_w, (size_t)3 * C * C * 2));
+  CHECK(gn(ctx, st, lay, Hpre, lat ? st_h : nullptr, w.out_g, w.out_b, ss, 1, wk.A16(), w.out_w, (size_t)3 * C * C * 2));
   DBG_SUM("res.out gn", wk.A16(), (size_t)lay.rows * C * 2);
   GemmArgs c3 = gemm_base(lay, wk.A16(), C, 3, C, w.out_w, C, w.out_bias);
-  c3.mode = GEMM_OUT_F32; c3.outF = X; c3.ldo = C; c3.resid = xin;
+  long long *st_out = lat ? st->new_stats_slot() : nullptr;
+  c3.mode = st_out ? GEMM_OUT_F32_STATS : GEMM_OUT_F32; c3.outF = X; c3.ldo = C; c3.resid = xin;
+  c3.st_out = st_out; c3.st_stripe_ll = (int)st->gn_stripe_ll; c3.chunk_seq = lay.d_chunk_seq.as<int>();
+  wk.st_x = st_out;
   CHECK(gemm(ctx, "diff_gemm", c3, lay));
   DBG_SUM("res.out conv", X, (size_t)lay.rows * C * 4);
   return TTS_OK;
@@ -1489,10 +1612,14 @@ static int network_forward(tts_ctx *ctx, DiffState *st, const float *ss) {
   Work &iw = st->share_integ ? st->iwk : st->wk;
   float *ce = st->ce.as<float>();
   if (st->n_integ == 0) TTS_HIP(ctx, hipMemcpyAsync(ce, st->code_emb.p, (size_t)il.rows * C * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  // option latency_mode: the statistics slots of this evaluation start empty (one memset node; every f32 GEMM of the step takes the next slot)
+  st->gn_site = 0;
+  iw.st_x = wk.st_x = iw.st_h = wk.st_h = nullptr;
+  if (st->lat) TTS_HIP(ctx, hipMemsetAsync(st->gn_stats.p, 0, (size_t)st->gn_sites_max * st->gn_slot_ll * 8, ctx->stream));
   int j = 0;
   for (int i = 0; i < st->n_integ; i++, j++) {
     // first block: reads the code embedding directly, its timestep-independent half (st->h0) comes from setup_batch
-    if (i == 0) CHECK(res_block(ctx, st, il, iw, ce, st->integ_res[0], ss, st->code_emb.as<float>(), st->h0.as<float>()));
+    if (i == 0) CHECK(res_block(ctx, st, il, iw, ce, st->integ_res[0], ss, st->code_emb.as<float>(), st->h0.as<float>(), st->lat ? st->gn_stats_h0.as<long long>() : nullptr));
     else CHECK(res_block(ctx, st, il, iw, ce, st->integ_res[i], ss + (size_t)j * 2 * C));
     CHECK(attention_block(ctx, st, il, iw, ce, st->integ_attn[i]));
   }
@@ -1508,7 +1635,9 @@ static int network_forward(tts_ctx *ctx, DiffState *st, const float *ss) {
   // integrating conv k1 over concat[inp | code_emb]
   GemmArgs gc = gemm_base(lay, inp16, C, 2, C, st->integ_w, C, st->integ_bias);
   gc.A[1] = ce16;
-  gc.mode = GEMM_OUT_F32; gc.outF = wk.X(); gc.ldo = C; gc.resid = nullptr;
+  wk.st_x = st->lat ? st->new_stats_slot() : nullptr;
+  gc.mode = wk.st_x ? GEMM_OUT_F32_STATS : GEMM_OUT_F32; gc.outF = wk.X(); gc.ldo = C; gc.resid = nullptr;
+  gc.st_out = wk.st_x; gc.st_stripe_ll = (int)st->gn_stripe_ll; gc.chunk_seq = lay.d_chunk_seq.as<int>();
   CHECK(gemm(ctx, "diff_gemm", gc, lay));
   DBG_SUM("integ conv", wk.X(), (size_t)lay.rows * C * 4);
   for (int i = 0; i < st->n_main; i++, j++) {
@@ -1516,12 +1645,13 @@ static int network_forward(tts_ctx *ctx, DiffState *st, const float *ss) {
     CHECK(attention_block(ctx, st, lay, wk, wk.X(), st->main_attn[i]));
   }
   for (int i = 0; i < st->n_tail; i++, j++) CHECK(res_block(ctx, st, lay, wk, wk.X(), st->tail_res[i], ss + (size_t)j * 2 * C));
-  CHECK(gn_fused(ctx, lay, wk.X(), st->outn_g, st->outn_b, nullptr, 1, wk.A16()));
+  CHECK(gn(ctx, st, lay, wk.X(), st->lat ? wk.st_x : nullptr, st->outn_g, st->outn_b, nullptr, 1, wk.A16()));
   GemmArgs go = gemm_base(lay, wk.A16(), C, 3, C, st->out_w, 256, st->out_bias);
   go.mode = GEMM_OUT_F32; go.outF = st->net.as<float>(); go.ldo = 256; go.resid = nullptr;
   DBG_SUM("out gn", wk.A16(), (size_t)lay.rows * C * 2);
   CHECK(gemm(ctx, "diff_gemm", go, lay, 200, 0));
   DBG_SUM("net", st->net.p, (size_t)lay.rows * 256 * 4);
+  if (st->lat && st->gn_site > st->gn_sites_max) return fail(ctx, TTS_ERR_STATE, "latency_mode: %d statistics slots used, %d reserved", st->gn_site, st->gn_sites_max);
   return TTS_OK;
 }
 
@@ -1588,9 +1718,23 @@ static int setup_batch(tts_ctx *ctx, DiffState *st, const float *latents, const 
                                                           st->uncond_emb, il.d_row_seq.as<int>(), il.d_row_t.as<int>(), il.d_len.as<int>(),
                                                           (st->share_integ ? st->iseq_src : st->seq_src).as<int>(), st->code_emb.as<float>());
   TTS_HIP(ctx, hipGetLastError());
+  // Option latency_mode, small layouts only (one or two utterances: the GroupNorm kernels are latency-bound there, 64 workgroups each): the f32 GEMMs of the sampling
+  // step leave the GroupNorm statistics of their outputs in per-step slots and the GroupNorms become gn_apply_kernel. Not bit-identical to the batch path (variance from
+  // exact sums instead of the two-pass f32 form): opt-in, the default keeps a candidate's result independent of its batch.
+  st->lat = ctx->latency_mode != 0 && lay.rows <= LAT_MAX_ROWS && il.rows <= LAT_MAX_ROWS;
+  if (st->lat) {
+    st->gn_stripe_ll = (size_t)std::max(lay.ns, il.ns) * 32 * 4;
+    st->gn_slot_ll = st->gn_stripe_ll * FX_STRIPES;
+    st->gn_sites_max = 3 * (st->n_integ + st->n_main + st->n_tail) + 2;
+    TTS_HIP(ctx, st->gn_stats.reserve((size_t)st->gn_sites_max * st->gn_slot_ll * 8));
+    TTS_HIP(ctx, st->gn_stats_h0.reserve(st->gn_slot_ll * 8));
+    TTS_HIP(ctx, hipMemsetAsync(st->gn_stats_h0.p, 0, st->gn_slot_ll * 8, ctx->stream));
+  }
   if (st->n_integ > 0) {
     TTS_HIP(ctx, rz(st->h0, (size_t)il.rows * C * 4));
-    CHECK(res_in_layers(ctx, il, st->share_integ ? st->iwk : st->wk, st->code_emb.as<float>(), st->integ_res[0], st->h0.as<float>()));
+    // (the code embedding's own statistics are reduced by the GroupNorm kernel: once per utterance)
+    CHECK(res_in_layers(ctx, st, il, st->share_integ ? st->iwk : st->wk, st->code_emb.as<float>(), st->integ_res[0], st->h0.as<float>(), nullptr,
+                        st->lat ? st->gn_stats_h0.as<long long>() : nullptr));
   }
   return TTS_OK;
 }

@@ -30,6 +30,7 @@
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -41,9 +42,13 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 // GEMM_OUT_QKV_SPLIT: the QKV projection of the reference-precision AttentionBlock (option attn_f32): every f32 result x is stored as the
 // fp16 pair hi = fp16(x), lo = fp16(x - hi) (hi + lo = x to 2^-22) in outH / outH2 and outVt / outVt2.
 // GEMM_OUT_F32_SCALED: out = alpha * acc + bias + resid (split-precision operands whose weights were scaled by 1 / alpha at load).
-enum { GEMM_OUT_F32 = 0, GEMM_OUT_F16 = 1, GEMM_OUT_QKV = 2, GEMM_OUT_QKV_SPLIT = 3, GEMM_OUT_F32_SCALED = 4 };
+// GEMM_OUT_F32_STATS / GEMM_OUT_F32_SCALED_STATS (round 6, option latency_mode): the f32 output + the GroupNorm statistics of the stored values, accumulated per
+// (sequence, 32-channel group) in fixed point (fx_add) — the GroupNorm that consumes the output needs no reduction pass of its own (diffusion.hip: gn_apply_kernel).
+enum { GEMM_OUT_F32 = 0, GEMM_OUT_F16 = 1, GEMM_OUT_QKV = 2, GEMM_OUT_QKV_SPLIT = 3, GEMM_OUT_F32_SCALED = 4, GEMM_OUT_F32_STATS = 5, GEMM_OUT_F32_SCALED_STATS = 6 };
 constexpr bool gemm_mode_qkv(int mode) { return mode == GEMM_OUT_QKV || mode == GEMM_OUT_QKV_SPLIT; }
-constexpr bool gemm_mode_f32(int mode) { return mode == GEMM_OUT_F32 || mode == GEMM_OUT_F32_SCALED; }
+constexpr bool gemm_mode_f32(int mode) { return mode == GEMM_OUT_F32 || mode == GEMM_OUT_F32_SCALED || mode == GEMM_OUT_F32_STATS || mode == GEMM_OUT_F32_SCALED_STATS; }
+constexpr bool gemm_mode_scaled(int mode) { return mode == GEMM_OUT_F32_SCALED || mode == GEMM_OUT_F32_SCALED_STATS; }
+constexpr bool gemm_mode_stats(int mode) { return mode == GEMM_OUT_F32_STATS || mode == GEMM_OUT_F32_SCALED_STATS; }
 
 struct GemmArgs {
   const __half *A[3];  // per segment base (row 0 of the packed layout)
@@ -62,10 +67,14 @@ struct GemmArgs {
   __half *outVt; int ldvt; // QKV: V channels transposed [h*64+d][row]
   __half *outH2, *outVt2;  // GEMM_OUT_QKV_SPLIT: the low halves (same leading dimensions)
   float alpha;             // GEMM_OUT_F32_SCALED
+  long long *st_out;       // GEMM_OUT_*_STATS: [FX_STRIPES][st_stripe_ll]: per stripe [sequences][32 groups][4] fixed-point {sum hi, sum lo, sum of squares hi, lo}
+  int st_stripe_ll;        //                   (fx_add), accumulated into; a workgroup adds to stripe blockIdx % FX_STRIPES, the reader sums the stripes (exact)
+  const int *chunk_seq;    //                   [M / 8]: owning sequence of an aligned 8-row chunk (sequences start at multiples of 8 rows), -1 = guard rows only
   int dual_b;              // 1: the two segments are the hi / lo halves of ONE weight over ONE activation operand -> gemm_f16_vh_dualb_kernel (GEMM_OUT_F32_SCALED only)
   int mode;
   // tile walk, set by launch_gemm_f16: th = 16-row blocks per tile (0: chosen from the problem size), cn = column tiles per L2 chunk
   int th, cn;
+  int ku; // K tiles per barrier pair of gemm_f16_vh_kernel (0 / 1: one; 2, 4: small problems, set by launch_gemm_f16 or a tool)
   // developer tools only (tools/gemm_tab_bench.hip): explicit per-XCD tile lists [8][tab_len] of {first row, blocks, first column, 0}
   const int4 *tiles; int tab_len;
 };
@@ -97,6 +106,39 @@ __device__ __forceinline__ uint2 pack_half4(float a, float b, float c, float d) 
   u.x = *(const unsigned *)&p0;
   u.y = *(const unsigned *)&p1;
   return u;
+}
+
+// Statistics accumulators are striped: one utterance sends ~440 atomics to each (sequence, group) record per GEMM, and same-line atomics are served one after the
+// other by that line's L2 channel (~12 ns each: 5 us behind the kernel). 8 stripes and one set of atomics per wave instead of per chunk -> a dozen per line; the consumer adds the stripes (integers: still exact).
+static constexpr int FX_STRIPES = 8;
+// 128-bit fixed-point accumulation of an f32 partial sum: hi in units of 2^-8 (|p| < 2^55), the exact remainder in units of 2^-60. Integer addition is associative: the
+// totals do not depend on the order in which workgroups arrive, and a per-chunk partial is computed by one wave in a fixed lane tree -> the statistics are reproducible
+// run to run and independent of what else is in the batch.
+__device__ __forceinline__ void fx_add(long long *dst, float p) {
+  const float h = rintf(p * 256.0f);
+  const float rem = p - h * (1.0f / 256.0f); // exact: |rem| <= 2^-9, or 0 when ulp(p) >= 2^-8
+  atomicAdd((unsigned long long *)dst, (unsigned long long)(long long)h);
+  atomicAdd((unsigned long long *)dst + 1, (unsigned long long)(long long)rintf(rem * 4503599627370496.0f)); // 2^52
+}
+__device__ __forceinline__ void fx_split(float p, long long &hi, long long &lo) {
+  const float h = rintf(p * 256.0f);
+  hi = (long long)h;
+  lo = (long long)rintf((p - h * (1.0f / 256.0f)) * 4503599627370496.0f);
+}
+__host__ __device__ __forceinline__ double fx_value(long long hi, long long lo) { return (double)hi * (1.0 / 256.0) + (double)lo * (1.0 / 1152921504606846976.0); }
+template <int CTRL> __device__ __forceinline__ float gemm_dpp(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+// sum over the lanes that differ in bits 0-2 and 4-5 (the 8 rows of a half block x the 4 column quads of a swapped-order 16x16 accumulator): lanes 0 and 8 of the wave end
+// up with the totals of rows 0-7 / 8-15 of the block. Fixed tree.
+__device__ __forceinline__ float red_half_block(float x) {
+  x += gemm_dpp<0xB1>(x);  // quad_perm [1,0,3,2]: lane ^ 1
+  x += gemm_dpp<0x4E>(x);  // quad_perm [2,3,0,1]: lane ^ 2
+  x += gemm_dpp<0x141>(x); // row_half_mirror: quads are uniform now, 7 - l swaps the two quads of a half row: lane ^ 4
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
 // Epilogues. For F32/F16 outputs the MFMA operands are swapped (A-operand = weight rows, B-operand =
@@ -173,12 +215,53 @@ __device__ __forceinline__ void gemm_epilogue_vh(const GemmArgs &g, floatx4 (&ac
 #pragma unroll
   for (int i = 0; i < MI; i++) sq[i] = hs ? sq[i] : 0;
   auto finish = [&](int i, int j) { // bias, guard
-    if (MODE == GEMM_OUT_F32_SCALED) acc[i][j] *= g.alpha;
+    if (gemm_mode_scaled(MODE)) acc[i][j] *= g.alpha;
     float4 v = make_float4(acc[i][j][0] + b4[j].x, acc[i][j][1] + b4[j].y, acc[i][j][2] + b4[j].z, acc[i][j][3] + b4[j].w);
     if (sq[i] < 0) v = make_float4(0.f, 0.f, 0.f, 0.f);
     return v;
   };
   if (gemm_mode_f32(MODE)) {
+    // GroupNorm statistics of the stored values (GEMM_OUT_*_STATS): a lane's partial sums over its 2 x 4 values of a (block, 32-column group), reduced over the 8 rows of
+    // each half block after the stores
+    float ssum[MA][2], ssq[MA][2];
+    auto stat_add = [&](int i, int j, const float4 &v) {
+      const float a = (v.x + v.y) + (v.z + v.w), b = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      if (j & 1) { ssum[i][j >> 1] += a; ssq[i][j >> 1] += b; }
+      else { ssum[i][j >> 1] = a; ssq[i][j >> 1] = b; }
+    };
+    auto stat_flush = [&]() {
+      // Every 8-row chunk's partial is converted to fixed point on its own (lanes 0 and 8 of the wave) — the unit whose value does not depend on the tiling — and
+      // the integers of a lane's chunks that belong to one sequence are added up before the atomics: 4 atomics per lane and group instead of 4 per chunk.
+      const int lane = fq * 16 + fr;
+      int cs[MA];
+#pragma unroll
+      for (int i = 0; i < MI; i++) cs[i] = g.chunk_seq[((m0 + vh_blk(wm, i) * 16) >> 3) + (fr >> 3)];
+#pragma unroll
+      for (int jp = 0; jp < 2; jp++) {
+        long long tot[4] = {0, 0, 0, 0};
+        int tseq = -1;
+        auto flush = [&]() {
+          if (tseq >= 0) {
+            long long *dst = g.st_out + (size_t)(blockIdx.x % FX_STRIPES) * g.st_stripe_ll + (size_t)(tseq * 32 + ((n0 + wn * 64) >> 5) + jp) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; k++) atomicAdd((unsigned long long *)dst + k, (unsigned long long)tot[k]);
+          }
+        };
+#pragma unroll
+        for (int i = 0; i < MI; i++) { // lane 0 adds up the upper halves (rows 0-7) of the wave's blocks, lane 8 the lower ones
+          const float sv = red_half_block(ssum[i][jp]), qv = red_half_block(ssq[i][jp]);
+          if ((lane & 0x37) == 0 && cs[i] >= 0) {
+            long long f[4];
+            fx_split(sv, f[0], f[1]);
+            fx_split(qv, f[2], f[3]);
+            if (cs[i] != tseq) { flush(); tseq = cs[i]; tot[0] = tot[1] = tot[2] = tot[3] = 0; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) tot[k] += f[k];
+          }
+        }
+        if ((lane & 0x37) == 0) flush();
+      }
+    };
     if (RESID == EPI_RESID_LOAD) {
       // residual read here (k = 3 kernel): blocks in pairs, the next pair's 8 loads are in flight while this pair is stored
       constexpr int NP = (MI + 1) / 2;
@@ -192,11 +275,12 @@ __device__ __forceinline__ void gemm_epilogue_vh(const GemmArgs &g, floatx4 (&ac
 #pragma unroll
             for (int j = 0; j < 4; j++) {
               // same f32 adds in the same order as before: (acc + bias) + resid
-              if (MODE == GEMM_OUT_F32_SCALED) acc[i][j] *= g.alpha;
+              if (gemm_mode_scaled(MODE)) acc[i][j] *= g.alpha;
               float4 t = make_float4(acc[i][j][0] + b4[j].x, acc[i][j][1] + b4[j].y, acc[i][j][2] + b4[j].z, acc[i][j][3] + b4[j].w);
               t.x += rr[q][j].x; t.y += rr[q][j].y; t.z += rr[q][j].z; t.w += rr[q][j].w;
               if (sq[i] < 0) t = make_float4(0.f, 0.f, 0.f, 0.f);
               v[q][j] = t;
+              if (gemm_mode_stats(MODE)) stat_add(i, j, t);
             }
           }
         }
@@ -216,9 +300,14 @@ __device__ __forceinline__ void gemm_epilogue_vh(const GemmArgs &g, floatx4 (&ac
       for (int i = 0; i < MI; i++) {
         float *op = g.outF + (size_t)(m0 + vh_blk(wm, i) * 16 + fr) * g.ldo + col0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) *(float4 *)(op + j * 16) = finish(i, j);
+        for (int j = 0; j < 4; j++) {
+          const float4 v = finish(i, j);
+          *(float4 *)(op + j * 16) = v;
+          if (gemm_mode_stats(MODE)) stat_add(i, j, v);
+        }
       }
     }
+    if (gemm_mode_stats(MODE)) stat_flush();
   } else if (MODE == GEMM_OUT_F16) {
 #pragma unroll
     for (int i = 0; i < MI; i++) {
@@ -249,7 +338,10 @@ __device__ __forceinline__ void gemm_epilogue_vh(const GemmArgs &g, floatx4 (&ac
 // LDS-DMA, 4 workgroups per CU overlap each other's load / compute phases.
 // The body is instantiated per number of 16-row blocks of the calling WAVE (0..4): the waves of a workgroup may run different
 // instantiations; all of them issue the same DMA pieces and pass the same two barriers per K tile.
-template <int MODE, int MI>
+// KU (round 6): K tiles per barrier pair. KU = 2 stages two 64-deep tiles side by side (64 KB, 2 workgroups per CU) and multiplies them between ONE pair of barriers: a
+// small problem (one utterance: at most two workgroups per CU) pays a DMA round trip + two barriers per pair instead of per tile. Same products in the same order:
+// bit-identical to KU = 1.
+template <int MODE, int MI, int KU = 1>
 __device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, int nblk, int lane, int wave) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[]; // named here: an LDS pointer passed in would become a generic pointer
   char *smem = smem_dyn;
@@ -279,7 +371,7 @@ __device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, 
   const bool resid_first = gemm_mode_f32(MODE) && g.resid != nullptr;
   floatx4 acc[MA][4];
   if (resid_first) {
-    const float rs = MODE == GEMM_OUT_F32_SCALED ? 1.0f / g.alpha : 1.0f;
+    const float rs = gemm_mode_scaled(MODE) ? 1.0f / g.alpha : 1.0f;
 #pragma unroll
     for (int i = 0; i < MI; i++) {
       const int row = m0 + vh_blk(wm, i) * 16 + fr;
@@ -305,23 +397,27 @@ __device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, 
     for (int seg = 0; seg < g.nseg; seg++) {
       const __half *aseg = g.A[seg] + (ptrdiff_t)g.row_off[seg] * g.lda;
       const __half *wseg = g.W + (g.custom_w ? g.w_off_[seg] : seg * g.kseg);
-      for (int kt = 0; kt < tiles_per_seg; kt++) {
-        const __half *abase = aseg + (kt << 6), *wbase = wseg + (kt << 6);
+      for (int kt = 0; kt < tiles_per_seg; kt += KU) { // kseg % (64 KU) == 0 (checked by the launcher)
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-          if (i < my_pa) __builtin_amdgcn_global_load_lds((gptr_t)(abase + aoff[i]), (lptr_t)(sa + (wave + 4 * i) * 1024), 16, 0, 0);
+        for (int u = 0; u < KU; u++) {
+          const __half *abase = aseg + ((kt + u) << 6), *wbase = wseg + ((kt + u) << 6);
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-          __builtin_amdgcn_global_load_lds((gptr_t)(wbase + boff[i]), (lptr_t)(sb + (wave * 4 + i) * 1024), 16, 0, 0);
+          for (int i = 0; i < 4; i++)
+            if (i < my_pa) __builtin_amdgcn_global_load_lds((gptr_t)(abase + aoff[i]), (lptr_t)(sa + u * 32768 + (wave + 4 * i) * 1024), 16, 0, 0);
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wbase + boff[i]), (lptr_t)(sb + u * 32768 + (wave * 4 + i) * 1024), 16, 0, 0);
+        }
         __syncthreads(); // waits vmcnt(0) for the DMA, then barrier
 #pragma unroll
-        for (int ks = 0; ks < 2; ks++) {
+        for (int ks = 0; ks < 2 * KU; ks++) {
+          const char *sau = sa + (ks >> 1) * 32768, *sbu = sb + (ks >> 1) * 32768;
           half8 af[MA], bf[4];
 #pragma unroll
-          for (int i = 0; i < MI; i++) af[i] = *(const half8 *)(sa + lds_off(vh_blk(wm, i) * 16 + fr, ks * 4 + fq));
+          for (int i = 0; i < MI; i++) af[i] = *(const half8 *)(sau + lds_off(vh_blk(wm, i) * 16 + fr, (ks & 1) * 4 + fq));
           if (MI > 0) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) bf[i] = *(const half8 *)(sb + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+            for (int i = 0; i < 4; i++) bf[i] = *(const half8 *)(sbu + lds_off(wn * 64 + i * 16 + fr, (ks & 1) * 4 + fq));
           }
 #pragma unroll
           for (int i = 0; i < MI; i++)
@@ -370,7 +466,7 @@ __device__ __forceinline__ void gemm_vh_dualb_body(const GemmArgs &g, int m0, in
   const bool resid_first = gemm_mode_f32(MODE) && g.resid != nullptr;
   floatx4 acc[MA][4];
   if (resid_first) {
-    const float rs = MODE == GEMM_OUT_F32_SCALED ? 1.0f / g.alpha : 1.0f;
+    const float rs = gemm_mode_scaled(MODE) ? 1.0f / g.alpha : 1.0f;
 #pragma unroll
     for (int i = 0; i < MI; i++) {
       const int row = m0 + vh_blk(wm, i) * 16 + fr;
@@ -448,17 +544,17 @@ __device__ __forceinline__ bool gemm_vh_tile(const GemmArgs &g, int &m0, int &n0
 }
 
 static constexpr int GEMM_VH_LDS = 32768;
-template <int MODE, int WGS>
+template <int MODE, int WGS, int KU = 1>
 static __global__ __launch_bounds__(256, WGS) void gemm_f16_vh_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: LDS-DMA bases stay in SGPRs
   int m0, n0, nblk;
   if (!gemm_vh_tile(g, m0, n0, nblk)) return;
   const int my_mi = (nblk - (wave >> 1) + 1) >> 1; // 16-row blocks of this wave
-  if (my_mi == 4) gemm_vh_body<MODE, 4>(g, m0, n0, nblk, lane, wave);
-  else if (my_mi == 3) gemm_vh_body<MODE, 3>(g, m0, n0, nblk, lane, wave);
-  else if (my_mi == 2) gemm_vh_body<MODE, 2>(g, m0, n0, nblk, lane, wave);
-  else if (my_mi == 1) gemm_vh_body<MODE, 1>(g, m0, n0, nblk, lane, wave);
-  else gemm_vh_body<MODE, 0>(g, m0, n0, nblk, lane, wave); // 1-block tile: this wave only moves operands
+  if (my_mi == 4) gemm_vh_body<MODE, 4, KU>(g, m0, n0, nblk, lane, wave);
+  else if (my_mi == 3) gemm_vh_body<MODE, 3, KU>(g, m0, n0, nblk, lane, wave);
+  else if (my_mi == 2) gemm_vh_body<MODE, 2, KU>(g, m0, n0, nblk, lane, wave);
+  else if (my_mi == 1) gemm_vh_body<MODE, 1, KU>(g, m0, n0, nblk, lane, wave);
+  else gemm_vh_body<MODE, 0, KU>(g, m0, n0, nblk, lane, wave); // 1-block tile: this wave only moves operands
 }
 
 template <int MODE>
@@ -561,7 +657,7 @@ __device__ __forceinline__ void gemm_conv3_vh_body(const GemmArgs &g, int m0, in
     phase(kc, p + 2, std::integral_constant<int, 2>{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // trailing (clamped) pieces must land before the LDS is released
-  if (MODE == GEMM_OUT_F32 && g.resid) gemm_epilogue_vh<MODE, MI, EPI_RESID_LOAD>(g, acc, m0, n0, wm, wn, fr, fq);
+  if ((MODE == GEMM_OUT_F32 || MODE == GEMM_OUT_F32_STATS) && g.resid) gemm_epilogue_vh<MODE, MI, EPI_RESID_LOAD>(g, acc, m0, n0, wm, wn, fr, fq);
   else gemm_epilogue_vh<MODE, MI, EPI_NO_RESID>(g, acc, m0, n0, wm, wn, fr, fq);
 }
 
@@ -581,12 +677,18 @@ static __global__ __launch_bounds__(256, 3) void gemm_f16_conv3_vh_kernel(GemmAr
 // k = 3 convolution (three row-shifted segments of one activation buffer, tap-major weights): shared-slab kernel
 static inline bool gemm_is_conv3(const GemmArgs &g) {
   return g.nseg == 3 && !g.custom_w && g.A[0] == g.A[1] && g.A[1] == g.A[2] && g.row_off[0] == -1 && g.row_off[1] == 0 && g.row_off[2] == 1 &&
-         !gemm_mode_qkv(g.mode) && g.mode != GEMM_OUT_F32_SCALED;
+         !gemm_mode_qkv(g.mode) && !gemm_mode_scaled(g.mode);
 }
 
 static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
   GemmArgs gg = g;
   const int NT = g.N >> 7, ktot = g.nseg * g.kseg, nb = g.M >> 4;
+  if (gemm_mode_scaled(g.mode)) { // the accumulators start from resid / alpha and are scaled back by alpha: exact only for a non-zero power of two
+    int e;
+    if (!(g.alpha != 0.f) || std::fabs(std::frexp(g.alpha, &e)) != 0.5f) return hipErrorInvalidValue;
+  }
+  if (gemm_mode_stats(g.mode) && (!g.st_out || !g.chunk_seq || g.st_stripe_ll <= 0)) return hipErrorInvalidValue;
+  int ku = (g.ku == 2 || g.ku == 4) && (g.kseg % (64 * g.ku)) == 0 ? g.ku : 1;
   int grid;
   if (g.tiles) grid = 8 * g.tab_len;
   else {
@@ -606,6 +708,10 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
     auto tiles_at = [&](int h) { return 8 * ((maxb + h - 1) / h) * NT; };
     int th = g.th;
     if (th <= 0) { th = 2; while (th < 8 && tiles_at(th) > 1024) th *= 2; }
+    // One utterance (M = 1 792 rows, N = 1 024: 224 tiles of 64 rows = at most one workgroup per CU): four K tiles per barrier pair at 64-row tiles — a lone
+    // workgroup pays its DMA round trip and two barriers per 256 of K instead of per 64 (profiles/r6_small_gemm.txt: k = 1 12.6 -> 11.6 us warm, 22.8 -> 17.9 us
+    // with cold weights; the K = 2 048 integrating conv 25.7 / 36.2 -> 20.3 / 27.8). Same products in the same order: bit-identical to every other tiling.
+    if (g.th <= 0 && g.ku == 0 && NT <= 8 && tiles_at(4) <= 256 && (g.kseg % 256) == 0 && !gemm_is_conv3(g) && !g.dual_b) { th = 4; ku = 4; }
     gg.th = th;
     int mt_max = 0;
     for (int x = 0; x < 8; x++) {
@@ -618,18 +724,40 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
       (void)hipFuncSetAttribute((const void *)gemm_f16_conv3_vh_kernel<GEMM_OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV3_VH_LDS);
+      (void)hipFuncSetAttribute((const void *)gemm_f16_conv3_vh_kernel<GEMM_OUT_F32_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV3_VH_LDS);
       (void)hipFuncSetAttribute((const void *)gemm_f16_conv3_vh_kernel<GEMM_OUT_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV3_VH_LDS);
       attr = true;
     }
     if (g.mode == GEMM_OUT_F32) gemm_f16_conv3_vh_kernel<GEMM_OUT_F32><<<grid, 256, CONV3_VH_LDS, s>>>(gg);
+    else if (g.mode == GEMM_OUT_F32_STATS) gemm_f16_conv3_vh_kernel<GEMM_OUT_F32_STATS><<<grid, 256, CONV3_VH_LDS, s>>>(gg);
     else gemm_f16_conv3_vh_kernel<GEMM_OUT_F16><<<grid, 256, CONV3_VH_LDS, s>>>(gg);
-  } else if (g.dual_b && g.mode == GEMM_OUT_F32_SCALED && g.nseg == 2 && g.custom_w && g.A[0] == g.A[1] && g.row_off[0] == g.row_off[1]) {
-    gemm_f16_vh_dualb_kernel<GEMM_OUT_F32_SCALED><<<grid, 256, GEMM_DUALB_LDS, s>>>(gg);
-  } else if (g.mode == GEMM_OUT_F32) gemm_f16_vh_kernel<GEMM_OUT_F32, 4><<<grid, 256, GEMM_VH_LDS, s>>>(gg);
-  else if (g.mode == GEMM_OUT_F16) gemm_f16_vh_kernel<GEMM_OUT_F16, 4><<<grid, 256, GEMM_VH_LDS, s>>>(gg);
-  else if (g.mode == GEMM_OUT_QKV) gemm_f16_vh_kernel<GEMM_OUT_QKV, 4><<<grid, 256, GEMM_VH_LDS, s>>>(gg);
-  else if (g.mode == GEMM_OUT_QKV_SPLIT) gemm_f16_vh_kernel<GEMM_OUT_QKV_SPLIT, 4><<<grid, 256, GEMM_VH_LDS, s>>>(gg);
-  else gemm_f16_vh_kernel<GEMM_OUT_F32_SCALED, 4><<<grid, 256, GEMM_VH_LDS, s>>>(gg);
+  } else if (g.dual_b && gemm_mode_scaled(g.mode) && g.nseg == 2 && g.custom_w && g.A[0] == g.A[1] && g.row_off[0] == g.row_off[1]) {
+    if (g.mode == GEMM_OUT_F32_SCALED) gemm_f16_vh_dualb_kernel<GEMM_OUT_F32_SCALED><<<grid, 256, GEMM_DUALB_LDS, s>>>(gg);
+    else gemm_f16_vh_dualb_kernel<GEMM_OUT_F32_SCALED_STATS><<<grid, 256, GEMM_DUALB_LDS, s>>>(gg);
+  } else {
+    // KU > 1: 64 / 128 KB of LDS -> 2 / 1 workgroups per CU (the occupancy bound of the launch is a compile-time promise: WGS)
+#define TTS_VH_LAUNCH(MODE_)                                                                                                                      \
+  do {                                                                                                                                            \
+    if (ku == 1) gemm_f16_vh_kernel<MODE_, 4><<<grid, 256, GEMM_VH_LDS, s>>>(gg);                                                                 \
+    else if (ku == 2) {                                                                                                                           \
+      static bool a2 = false;                                                                                                                     \
+      if (!a2) { (void)hipFuncSetAttribute((const void *)gemm_f16_vh_kernel<MODE_, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_VH_LDS); a2 = true; } \
+      gemm_f16_vh_kernel<MODE_, 2, 2><<<grid, 256, 2 * GEMM_VH_LDS, s>>>(gg);                                                                     \
+    } else {                                                                                                                                      \
+      static bool a4 = false;                                                                                                                     \
+      if (!a4) { (void)hipFuncSetAttribute((const void *)gemm_f16_vh_kernel<MODE_, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * GEMM_VH_LDS); a4 = true; } \
+      gemm_f16_vh_kernel<MODE_, 1, 4><<<grid, 256, 4 * GEMM_VH_LDS, s>>>(gg);                                                                     \
+    }                                                                                                                                             \
+  } while (0)
+    if (g.mode == GEMM_OUT_F32) TTS_VH_LAUNCH(GEMM_OUT_F32);
+    else if (g.mode == GEMM_OUT_F16) TTS_VH_LAUNCH(GEMM_OUT_F16);
+    else if (g.mode == GEMM_OUT_QKV) TTS_VH_LAUNCH(GEMM_OUT_QKV);
+    else if (g.mode == GEMM_OUT_QKV_SPLIT) TTS_VH_LAUNCH(GEMM_OUT_QKV_SPLIT);
+    else if (g.mode == GEMM_OUT_F32_SCALED) TTS_VH_LAUNCH(GEMM_OUT_F32_SCALED);
+    else if (g.mode == GEMM_OUT_F32_STATS) TTS_VH_LAUNCH(GEMM_OUT_F32_STATS);
+    else TTS_VH_LAUNCH(GEMM_OUT_F32_SCALED_STATS);
+#undef TTS_VH_LAUNCH
+  }
   return hipGetLastError();
 }
 

@@ -55,30 +55,6 @@ struct GemmSmArgs {
   const int *chunk_seq; // [M / 8]: owning sequence of an aligned 8-row chunk, -1 = all guard rows
 };
 
-// 128-bit fixed point accumulation of an f32 partial sum: hi in units of 2^-8 (|p| < 2^55), the exact remainder in units of 2^-60.
-__device__ __forceinline__ void fx_add(long long *dst, float p) {
-  const float h = rintf(p * 256.0f);
-  const float rem = p - h * (1.0f / 256.0f); // exact: |rem| <= 2^-9, or 0 when ulp(p) >= 2^-8
-  atomicAdd((unsigned long long *)dst, (unsigned long long)(long long)h);
-  atomicAdd((unsigned long long *)dst + 1, (unsigned long long)(long long)rintf(rem * 4503599627370496.0f)); // 2^52
-}
-__host__ __device__ __forceinline__ double fx_value(long long hi, long long lo) { return (double)hi * (1.0 / 256.0) + (double)lo * (1.0 / 1152921504606846976.0); }
-
-template <int CTRL> __device__ __forceinline__ float sm_dpp(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, false));
-}
-// sum over the lanes that differ in bits 0-2 and 4-5 (the 8 rows of a half block x the 4 column quads of a 16x16 accumulator): lanes 0 and 8 of the
-// wave end up with the totals of rows 0-7 / 8-15. Fixed tree: deterministic.
-__device__ __forceinline__ float sm_red_half_block(float x) {
-  x += sm_dpp<0xB1>(x);  // quad_perm [1,0,3,2]: lane ^ 1
-  x += sm_dpp<0x4E>(x);  // quad_perm [2,3,0,1]: lane ^ 2
-  x += sm_dpp<0x141>(x); // row_half_mirror: quads are uniform now, 7 - l swaps the two quads of a half row: lane ^ 4
-  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-
 // s_waitcnt vmcnt(n) for a wave-uniform runtime n (the count of DMA pieces this wave has issued after the ones it needs: depends on the wave and, near the
 // ends of the K loop, on the phase)
 __device__ __forceinline__ void sm_wait_vm(int n) {
@@ -419,8 +395,8 @@ static __global__ __launch_bounds__(512, 2) void gemm_f16_sm_kernel(GemmSmArgs g
         const float4 x = v[2 * jp], y = v[2 * jp + 1];
         float s = ((x.x + x.y) + (x.z + x.w)) + ((y.x + y.y) + (y.z + y.w));
         float q = ((x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w)) + ((y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w));
-        s = sm_red_half_block(s);
-        q = sm_red_half_block(q);
+        s = red_half_block(s);
+        q = red_half_block(q);
         if ((lane & 0x37) == 0 && cseq[i] >= 0) { // lanes 0 and 8: rows 0-7 / 8-15 of the block
           long long *dst = g.st_out + (size_t)(cseq[i] * 32 + ((n0 + wn * NJ * 16) >> 5) + jp) * 4;
           fx_add(dst, s);
