@@ -46,7 +46,7 @@ enum { TTS_VOCAB_MEL = 8194, TTS_DMODEL = 1024, TTS_MEL_CH = 100, TTS_CODES = 50
  *       full-length clips and must be regenerated: INTEGRATION.md "voice files"),
  *   5 = round 5: tts_ar_set_stop_schedule, tts_version; option "attn_proj_f16"; the default AttentionBlock multiplies proj_out on an F32-accurate
  *       (split fp16 pair) weight. */
-#define TTS_API_VERSION 5
+#define TTS_API_VERSION 6
 int tts_version(void);
 
 /* replaces ggml_backend_cuda_init(0) (main.cpp:651, 1213, 1777). device = HIP ordinal; returns NULL
@@ -95,7 +95,13 @@ const char *tts_last_error(const tts_ctx *ctx);
  * "device_topk" (1 default): tts_autoregressive's decode loop samples from the device prefilter's lists (tts_ar_step_sample); 0 = every step copies
  * the [B][8194] logits to the host as the reference does (main.cpp:4766-4768). Sampled ids are identical either way.
  * "dec_f32_mfma" (0 default; set BEFORE tts_load_ar): the decode step's LayerNorm-GEMV kernels multiply on v_mfma_f32_16x16x4_f32 (exact f32 products)
- * instead of split-precision fp16 pairs. */
+ * instead of split-precision fp16 pairs.
+ * "latency_mode" (0 default; round 6): small diffusion batches only (at most 4096 packed rows: one or two utterances with both guidance branches — the reference's own
+ * workload is ONE, main.cpp:6570). The GroupNorm statistics of every f32 tensor of the sampling step are accumulated by the epilogue of the GEMM that produces it
+ * (exact fixed-point sums per sequence and 32-channel group) and the 45 GroupNorms of a step become elementwise launches. Results are reproducible run to run and
+ * independent of the other candidates of the (small) batch, held to the same oracle gates as the default, but NOT bit-identical to the default path, which is why it is
+ * opt-in. Measured gain: 1 % of the single-utterance diffusion stage (profiles/r6_small_batch.txt: the launches are bound by their fixed costs, not by the reduction).
+ * "fp16_check" (0 default): see tts_diffusion_fp16_check. */
 int tts_set_option(tts_ctx *ctx, const char *key, double value);
 
 /* ---- weight files (drop-in format: magic 0x67676d6c + name-keyed F32 records) ------------- */
@@ -232,6 +238,12 @@ int tts_diffusion(tts_ctx *ctx, const float *latents, const int32_t *rows, int n
  * returned wrong sums while a second engine process used the same GPU. Number of disagreeing evaluations since the context was created:
  * 0 in every single-process run, and 0 beside a second process since the kernel was rebuilt. */
 int tts_diffusion_time_mlp_retries(const tts_ctx *ctx);
+/* Parity hardening (round 6): with option "fp16_check" = 1 every fp16 GEMM operand the diffusion stage produces (GroupNorm outputs, q | k rows, V^T columns,
+ * attention outputs) is scanned after the launch that wrote it; split-precision weights are checked when they are packed (tts_load_diffusion).
+ * counts[0] = non-finite values, counts[1] = values with |x| > 60000 (fp16 saturates at 65504) seen since the option was set. Returns TTS_OK.
+ * The reference keeps these tensors in F32 (main.cpp:3191-3499, 3848-3875): an fp16 operand that saturates is a parity failure the tolerance tests on
+ * small-sigma weights cannot see. */
+int tts_diffusion_fp16_check(tts_ctx *ctx, int64_t counts[2]);
 
 /* ---- vocoder stage -------------------------------------------------------------------------- */
 int tts_vocoder_samples(int mel_frames); /* (T+10)*256-6, main.cpp:6051, 4459-4478 */

@@ -58,6 +58,19 @@ def mid_models(pkg):
 
 
 @pytest.fixture(scope="session")
+def trained_mid_models(pkg):
+    """mid-depth DIFFUSION weights with trained-network statistics (round 6): normalisation gains 0.1 .. 12, heavy-tailed weights with 30-sigma outliers, relative-position
+    biases of +-10, unit-scale embeddings (tortoise.cpp_amd/synth_weights.py: _TrainedGen)"""
+    d = os.path.join(os.environ.get("TTS_SYNTH_DIR", "/tmp/tts_synth"), "trained_mid")
+    if not os.path.exists(os.path.join(d, ".done")):
+        from tortoise_cpp_amd import synth_weights as sw
+        os.makedirs(d, exist_ok=True)
+        sw.write_diffusion(os.path.join(d, "ggml-diffusion-model.bin"), 3, 1, 1, 2, seed=9001, stats="trained")
+        open(os.path.join(d, ".done"), "w").write("ok")
+    return d
+
+
+@pytest.fixture(scope="session")
 def full_models(pkg):
     """The benchmark's own weights: 30 GPT-2 layers, 4 + 3 + 10 + 3 diffusion blocks, UnivNet (2.4 GB, ~1 min to generate).
     Same directory and seed as bench.py, so the weights bench.py times are the weights these tests check."""
@@ -97,19 +110,33 @@ def loop_gate(kind, attn_f32=False):
     return float(rec["gate_f32"])
 
 
-def loop_gate_mean(kind):
-    """Gate on the MEAN abs distance from the oracle = 1.25 x the largest mean the torch-f32 evaluation kept from the oracle on the class's test problems (the
-    engine's reference-precision mode has been 1.04 .. 1.17 x the same problem's, the default mode 1.09 .. 1.21 x: a stable statistic unlike the maximum)."""
+MEAN_RATIO_MAX = 1.30
+"""Largest allowed ratio between the engine's mean abs distance from the oracle and the distance a torch-f32 evaluation of the reference's graph keeps from the oracle on
+the SAME problem (round 6, VERDICT r5 item 3c). Measured ratios: default arithmetic 1.09 .. 1.24 (the four fp16 activation roundings of the AttentionBlock, which average
+out over the loop but not to nothing), option attn_f32 1.04 .. 1.17, option latency_mode the same as the mode it runs in. The floor itself is one sample of a
+distribution whose relative sigma over (latents, noise) seeds is 2.5 % (tests/golden/parity_floor.json "seed_distribution", tools/regen_parity_floor.py --seeds)."""
+
+
+def loop_gate_mean(kind, problem=None):
+    """Gate on the MEAN abs distance from the oracle (a stable statistic, unlike the maximum). `problem` = the name under which tools/regen_parity_floor.py --problems
+    recorded the torch-f32-vs-oracle distance of exactly these inputs: the gate is MEAN_RATIO_MAX x that problem's own floor. Without a recorded problem: MEAN_RATIO_MAX x
+    max(largest recorded problem mean, mu + 3 sigma of the class's seed distribution) (`gate_f32_mean` in the record). Rounds 4-5 used 1.25 x the largest recorded mean of
+    the class for every problem and passed with 2-3 % of air on the problems that defined it."""
     import json
-    return float(json.load(open(os.path.join(GOLDEN, "parity_floor.json")))[kind]["gate_f32_mean"])
+    rec = json.load(open(os.path.join(GOLDEN, "parity_floor.json")))[kind]
+    if problem is not None:
+        return MEAN_RATIO_MAX * float(rec["problems"][problem]["oracle_vs_t32_mean"])
+    return float(rec["gate_f32_mean"])
 
 
-def check_loop(err, kind, mode, what=""):
-    """assert the loop gates of one comparison (err = |engine - oracle|), the same for both modes; returns the text for the log"""
-    g, gm = loop_gate(kind, mode), loop_gate_mean(kind)
+def check_loop(err, kind, mode, what="", problem=None):
+    """assert the loop gates of one comparison (err = |engine - oracle|), the same for both modes; returns the text for the log (incl. the engine / floor ratio when the
+    problem's own floor is on record)"""
+    g, gm = loop_gate(kind, mode), loop_gate_mean(kind, problem)
     assert err.max() <= g, (what, mode, float(err.max()), float(err.mean()), g)
     assert err.mean() <= gm, (what, mode, float(err.mean()), gm)
-    return "max %.2e (gate %.2e) mean %.2e (gate %.2e)" % (err.max(), g, err.mean(), gm)
+    ratio = " = %.2f x this problem's f32-vs-f32 mean (limit %.2f)" % (err.mean() / (gm / MEAN_RATIO_MAX), MEAN_RATIO_MAX) if problem else ""
+    return "max %.2e (gate %.2e) mean %.2e (gate %.2e)%s" % (err.max(), g, err.mean(), gm, ratio)
 
 
 ATTN_MODES = ((0, "default: fp16 attention operands, F32-accurate proj_out weight, f32 conditioner"), (1, "reference precision: attn_f32"))

@@ -92,7 +92,7 @@ def test_sampling_loop_matches_oracle(engine, oracle, small_models):
             for c, want in enumerate(wants):
                 assert mels[c].shape == want.shape
                 err = np.abs(mels[c] - want)
-                print("80-step sampling loop cand %d [%s]: %s" % (c, what, check_loop(err, "small", mode, "cand %d" % c)))
+                print("80-step sampling loop cand %d [%s]: %s" % (c, what, check_loop(err, "small", mode, "cand %d" % c, problem="test_sampling_loop_matches_oracle[cand %d]" % c)))
     finally:
         engine.set_option("attn_f32", 0)
 
@@ -112,7 +112,7 @@ def test_sampling_loop_200_steps_config5(engine, oracle, small_models):
             mel = engine.diffusion([lat], n_steps=200, noise=[noise])[0]
             err = np.abs(mel - want)
             assert mel.shape == want.shape == (100, T) and np.isfinite(mel).all() and np.abs(mel).max() <= 1.0 + 1e-6
-            print("200-step sampling loop (T=%d) [%s]: %s" % (T, what, check_loop(err, "small", mode)))
+            print("200-step sampling loop (T=%d) [%s]: %s" % (T, what, check_loop(err, "small", mode, problem="test_sampling_loop_200_steps_config5")))
     finally:
         engine.set_option("attn_f32", 0)
 

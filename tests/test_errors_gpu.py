@@ -109,3 +109,31 @@ def test_call_order_and_argument_limits(pkg, small_models, voice):
             eng.autoregressive(DEFAULT_TOKENS, voice, 1, 501)
     finally:
         eng.close()
+
+
+def test_ar_weight_beyond_the_split_precision_range_is_rejected(pkg, small_models, tmp_path):
+    """The AR stage holds 64 W as an fp16 hi | lo pair (ar.hip: W16_SCALE): |W| >= 937 would become an fp16 infinity inside the MFMA operands. Such a file
+    fails at load with the tensor's name (round 6; weights of a trained GPT-2 are three orders of magnitude below), one at |W| = 100 loads."""
+    good = os.path.join(small_models, "ggml-model.bin")
+    eng = pkg.Engine(0)
+
+    def scaled(target, peak):
+        def edit(n, ne, d):
+            if n == target:
+                a = np.frombuffer(d, np.float32).copy()
+                a[7] = peak
+                return n, ne, a.tobytes()
+            return n, ne, d
+        return edit
+    try:
+        name = "inference_model.transformer.h.1.mlp.c_proj.weight"
+        p = str(tmp_path / "w100.bin")
+        _rewrite(good, p, scaled(name, 100.0))
+        eng.load(ar=p)
+        p = str(tmp_path / "w2000.bin")
+        _rewrite(good, p, scaled(name, 2000.0))
+        with pytest.raises(pkg.TtsError, match="h.1.mlp.c_proj.weight.*split-precision"):
+            eng.load(ar=p)
+        eng.load(ar=good)  # the context stays usable
+    finally:
+        eng.close()

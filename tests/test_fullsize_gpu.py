@@ -111,7 +111,7 @@ def test_sampling_loop_80_steps(engine, oracle, small_models, mid_models, models
             mel = engine.diffusion([lat], n_steps=80, noise=[noise])[0]
             err = np.abs(mel - want)
             assert np.abs(want).max() <= 1.5
-            print("80-step loop (%s weights, T=%d) [%s]: %s" % (models, T, what, check_loop(err, models, mode)))
+            print("80-step loop (%s weights, T=%d) [%s]: %s" % (models, T, what, check_loop(err, models, mode, problem="test_sampling_loop_80_steps[%s]" % models)))
     finally:
         engine.set_option("attn_f32", 0)
 
@@ -279,7 +279,7 @@ def test_full_size_80_steps_at_bench_length(full_engine, oracle, full_models):
             mel = full_engine.diffusion([lat], n_steps=80, noise=[noise])[0]
             err = np.abs(mel - want)
             assert T == 870 and np.abs(want).max() <= 1.5
-            print("full-size 80-step loop at T=%d [%s]: %s" % (T, what, check_loop(err, "full", mode)))
+            print("full-size 80-step loop at T=%d [%s]: %s" % (T, what, check_loop(err, "full", mode, problem="test_full_size_80_steps_at_bench_length")))
     finally:
         full_engine.set_option("attn_f32", 0)
 
@@ -319,7 +319,7 @@ def test_config5_shape_200_steps(full_engine, oracle, full_models, pkg):
             eng.set_option("attn_f32", mode)
             mel = eng.diffusion([lat], n_steps=steps, noise=[noise])[0]
             err = np.abs(mel - want)
-            print("configs[4] schedule at full depth, 200 steps, T=%d [%s]: %s" % (T, what, check_loop(err, "full", mode)))
+            print("configs[4] schedule at full depth, 200 steps, T=%d [%s]: %s" % (T, what, check_loop(err, "full", mode, problem="test_config5_shape_200_steps")))
     finally:
         eng.set_option("attn_f32", 0)
 

@@ -72,7 +72,7 @@ def test_sampling_loop_80_steps_latency_mode(lat_engine, oracle, small_models, m
         mel = engine.diffusion([lat], n_steps=80, noise=[noise])[0]
         again = engine.diffusion([lat], n_steps=80, noise=[noise])[0]
         print("80-step loop, latency mode, %s [%s]: %s; batch path on the same problem: max %.2e mean %.2e" %
-              (kind, what, check_loop(np.abs(mel - want), kind, mode), np.abs(base - want).max(), np.abs(base - want).mean()))
+              (kind, what, check_loop(np.abs(mel - want), kind, mode, problem="test_sampling_loop_80_steps[%s]" % kind), np.abs(base - want).max(), np.abs(base - want).mean()))
         assert (mel == again).all(), "latency mode must be reproducible run to run"
 
 
@@ -90,6 +90,6 @@ def test_ragged_pair_latency_mode(lat_engine, oracle, small_models):
     mels = engine.diffusion(lats, n_steps=80, noise=noise)
     for c, l in enumerate(lats):
         want = od.sample(l, n_steps=80, noise=noise[c])
-        print("latency mode, ragged pair cand %d: %s" % (c, check_loop(np.abs(mels[c] - want), "small", 0, "cand %d" % c)))
+        print("latency mode, ragged pair cand %d: %s" % (c, check_loop(np.abs(mels[c] - want), "small", 0, "cand %d" % c, problem="test_sampling_loop_matches_oracle[cand %d]" % c)))
         alone = engine.diffusion([l], n_steps=80, noise=[noise[c]])[0]
         assert (alone == mels[c]).all(), "candidate %d differs between the pair and the single run" % c

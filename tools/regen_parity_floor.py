@@ -159,9 +159,102 @@ def ablate(kind, L, seed, steps=80, sets=None):
         json.dump(rec, open(FLOOR_JSON, "w"), indent=1)
 
 
+MEAN_RATIO_MAX = 1.30  # = tests/conftest.py
+
+
+def finish_mean_gate(f):
+    """class-level mean gate (problems without a floor of their own): MEAN_RATIO_MAX x max(largest recorded problem mean, mu + 3 sigma of the seed distribution)"""
+    means = [p["oracle_vs_t32_mean"] for p in f.get("problems", {}).values()]
+    if means:
+        f["oracle_vs_t32_mean"] = max(means)
+        top = max(means + [f.get("seed_distribution", {}).get("mean_mu_plus_3sigma", 0.0)])
+        f["gate_f32_mean"] = round(MEAN_RATIO_MAX * top, 8)
+
+
+def seed_distribution(kind, L, n_seeds, steps=80):
+    """the torch-f32-vs-oracle distance of ONE problem size under n different (latents, noise) seeds — the spread of the statistic the mean
+    gate is built on. Recorded under rec[kind]["seed_distribution"]; conftest.loop_gate_mean uses mu + 3 sigma of the per-seed means as the class's floor."""
+    path = ensure_models(kind)
+    rec = json.load(open(FLOOR_JSON))
+    dist = rec[kind].setdefault("seed_distribution", {"L": L, "steps": steps, "rows": []})
+    if dist.get("L") != L:
+        dist = rec[kind]["seed_distribution"] = {"L": L, "steps": steps, "rows": []}
+    for seed in range(101, 101 + n_seeds):
+        if any(r["seed"] == seed for r in dist["rows"]):
+            continue
+        T, r = loops(path, L, seed, steps=steps)
+        d = np.abs(r["orc"] - r["t32"])
+        dist["rows"].append({"seed": seed, "T": int(T), "max": float(d.max()), "mean": float(d.mean())})
+        print(kind, "seed", seed, "T", T, "oracle vs torch-f32: max %.3e mean %.3e" % (d.max(), d.mean()), flush=True)
+        rec = json.load(open(FLOOR_JSON))
+        rec[kind]["seed_distribution"] = dist
+        json.dump(rec, open(FLOOR_JSON, "w"), indent=1)
+    means = np.array([r["mean"] for r in dist["rows"]])
+    dist["mean_mu"], dist["mean_sigma"] = float(means.mean()), float(means.std(ddof=1)) if len(means) > 1 else 0.0
+    dist["mean_mu_plus_3sigma"] = dist["mean_mu"] + 3 * dist["mean_sigma"]
+    rec = json.load(open(FLOOR_JSON))
+    rec[kind]["seed_distribution"] = dist
+    finish_mean_gate(rec[kind])
+    json.dump(rec, open(FLOOR_JSON, "w"), indent=1)
+    print(kind, "mean of the means %.3e, sigma %.3e (%.1f %%), mu + 3 sigma %.3e" % (dist["mean_mu"], dist["mean_sigma"], 100 * dist["mean_sigma"] / dist["mean_mu"],
+                                                                                     dist["mean_mu_plus_3sigma"]), flush=True)
+
+
+TRAINED_DIR = os.environ.get("TTS_SYNTH_DIR", "/tmp/tts_synth") + "/trained_mid"
+
+
+def ensure_trained():
+    """mid-depth diffusion weights with 'trained' statistics (tortoise.cpp_amd/synth_weights.py: _TrainedGen) — the same call as tests/conftest.py: trained_mid_models"""
+    import tortoise_cpp_amd_loader
+    tortoise_cpp_amd_loader.load()
+    from tortoise_cpp_amd import synth_weights as sw
+    os.makedirs(TRAINED_DIR, exist_ok=True)
+    path = TRAINED_DIR + "/ggml-diffusion-model.bin"
+    if not os.path.exists(TRAINED_DIR + "/.done"):
+        sw.write_diffusion(path, 3, 1, 1, 2, seed=9001, stats="trained")
+        open(TRAINED_DIR + "/.done", "w").write("ok")
+    return path
+
+
+def trained_class():
+    """the torch-f32-vs-oracle floors of the GPU tests on the trained-statistics weights (tests/test_trained_stats_gpu.py), class "trained"."""
+    path = ensure_trained()
+    rec = json.load(open(FLOOR_JSON))
+    f = rec.setdefault("trained", {"problems": {}})
+    lat = np.random.RandomState(12).randn(12, 1024).astype(np.float32)
+    T = O.Diffusion.T_of(12)
+    probs = {"test_trained_stats_loop_80_steps": (lat, np.random.RandomState(5).randn(81, 100 * T).astype(np.float32), 80)}
+    for name, (latents, noise, steps) in probs.items():
+        if name not in f["problems"]:
+            f["problems"][name] = run_problem(path, latents, noise, steps)
+            print("trained", name, f["problems"][name], flush=True)
+    f["oracle_vs_t32"] = max(p["oracle_vs_t32"] for p in f["problems"].values())
+    f["gate_f32"] = round(max(1e-3, 1.5 * f["oracle_vs_t32"]), 5)
+    finish_mean_gate(f)
+    rec = json.load(open(FLOOR_JSON))
+    rec["trained"] = f
+    json.dump(rec, open(FLOOR_JSON, "w"), indent=1)
+
+
 def main():
     torch.set_num_threads(int(os.environ.get("TTS_FLOOR_THREADS", "4")))
     O.build()
+    if "--trained" in sys.argv:
+        trained_class()
+        return
+    if "--finish-gates" in sys.argv:
+        rec = json.load(open(FLOOR_JSON))
+        for kind in ("small", "mid", "full", "trained"):
+            if kind in rec:
+                finish_mean_gate(rec[kind])
+        json.dump(rec, open(FLOOR_JSON, "w"), indent=1)
+        return
+    if "--seeds" in sys.argv:  # python tools/regen_parity_floor.py --seeds small:L=12,n=5 mid:L=12,n=5 full:L=20,n=5
+        for spec in sys.argv[sys.argv.index("--seeds") + 1:]:
+            kind, kv = spec.split(":")
+            kw = {k: int(v) for k, v in (p.split("=") for p in kv.split(","))}
+            seed_distribution(kind, kw["L"], kw.get("n", 5))
+        return
     if "--ablate" in sys.argv:  # python tools/regen_parity_floor.py --ablate full:L=20,seed=9 mid:L=12,seed=5
         for spec in sys.argv[sys.argv.index("--ablate") + 1:]:
             kind, kv = spec.split(":")
@@ -217,10 +310,7 @@ def main():
         # problem. gate_f32 = max(1e-3 [north star], 1.5 x the largest f32-vs-f32 maximum recorded for the class). The MEAN abs error is stable (engine 1.04 .. 1.17 x the
         # same problem's torch-vs-oracle mean): gate_f32_mean = 1.25 x the largest recorded mean.
         f["gate_f32"] = round(max(1e-3, 1.5 * f["oracle_vs_t32"]), 5)
-        means = [p["oracle_vs_t32_mean"] for p in f.get("problems", {}).values()]
-        if means:
-            f["oracle_vs_t32_mean"] = max(means)
-            f["gate_f32_mean"] = round(1.25 * max(means), 8)
+        finish_mean_gate(f)
         f.pop("gate_f32_provisional", None)
         json.dump(rec, open(FLOOR_JSON, "w"), indent=1)
         print(kind, {k: f[k] for k in ("floor_f32", "oracle", "engine_math", "pair", "oracle_vs_t32", "gate", "gate_f32")}, flush=True)

@@ -59,7 +59,7 @@ def lib():
         "tts_ar_begin": (ci, [vp, _i32p, ci, _f32p, ci, ci]), "tts_ar_prefill": (ci, [vp, _f32p]),
         "tts_ar_step": (ci, [vp, _i32p, ci, _f32p]), "tts_ar_latents": (ci, [vp, _i32p, ci, ci, _f32p]),
         "tts_sample": (ci, [vp, _f32p, _i32p, ci, ci, _i32p]),
-        "tts_ar_step_sample": (ci, [vp, _i32p, ci, C.c_uint, _i32p]), "tts_ar_topk_fallbacks": (ci, [vp]), "tts_diffusion_time_mlp_retries": (ci, [vp]),
+        "tts_ar_step_sample": (ci, [vp, _i32p, ci, C.c_uint, _i32p]), "tts_ar_topk_fallbacks": (ci, [vp]), "tts_diffusion_time_mlp_retries": (ci, [vp]), "tts_diffusion_fp16_check": (ci, [vp, C.POINTER(C.c_int64)]),
         "tts_host_sample_row": (ci, [_f32p, _i32p, ci, cf]), "tts_host_sample_prefiltered": (ci, [_f32p, _i32p, ci, cf, ci]),
         "tts_autoregressive": (ci, [vp, _i32p, ci, _f32p, ci, ci, C.c_uint, _i32p, _i32p, vp, _i32p]),
         "tts_ar_stop_status": (ci, [vp, _i32p, ci]), "tts_ar_set_stop_schedule": (ci, [vp, C.c_void_p, ci]),
@@ -186,6 +186,12 @@ class Engine:
 
     def topk_fallbacks(self):
         return self.L.tts_ar_topk_fallbacks(self.h)
+
+    def fp16_check(self):
+        """(non-finite, saturated) fp16 operand values seen since option fp16_check was set (+ the split weights of the loaded diffusion model)."""
+        c = (C.c_int64 * 2)()
+        self._ck(self.L.tts_diffusion_fp16_check(self.h, c))
+        return int(c[0]), int(c[1])
 
     def time_mlp_retries(self):
         return self.L.tts_diffusion_time_mlp_retries(self.h)

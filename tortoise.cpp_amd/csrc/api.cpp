@@ -84,6 +84,7 @@ void tts_destroy(tts_ctx *c) {
   if (c->clvp) clvp_free(c->clvp);
   if (c->venc) voice_enc_free(c->venc);
   if (c->dcond) diff_cond_enc_free(c->dcond);
+  if (c->fp16_counts) (void)hipFree(c->fp16_counts);
   delete c->tok;
   for (auto &kv : c->prof)
     for (auto &pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -121,6 +122,7 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
   else if (k == "proj_dual_b") c->proj_dual_b = value != 0;
   else if (k == "lc_attn_f32") c->lc_attn_f32 = value != 0;
   else if (k == "latency_mode") c->latency_mode = value != 0;
+  else if (k == "fp16_check") c->fp16_check = value != 0;
   else if (k == "attn_f32_drop") c->attn_f32_drop = (int)value & 7;
   else if (k == "ar_weights") {
     if (value != 0 && value != 1 && value != 2) return fail(c, TTS_ERR_ARG, "ar_weights: 0 (f32), 1 (fp16) or 2 (fp8 e4m3)");
@@ -272,6 +274,10 @@ int tts_ar_step_sample(tts_ctx *c, const int32_t *prev, int i, unsigned flags, i
 }
 int tts_ar_topk_fallbacks(const tts_ctx *c) { return c ? c->topk_fallbacks : -1; }
 int tts_diffusion_time_mlp_retries(const tts_ctx *c) { return c ? c->time_mlp_retries : -1; }
+int tts_diffusion_fp16_check(tts_ctx *c, int64_t counts[2]) {
+  if (!c || !counts) return TTS_ERR_ARG;
+  return guarded(c, [&] { return tts::diff_fp16_check(c, counts); });
+}
 int tts_host_sample_row(const float *row, const int32_t *ids, int ids_per_cand, float uniform) {
   if (!row || !ids || ids_per_cand < 1) return -1;
   return sample_one_row(row, ids, ids_per_cand, uniform);

@@ -1451,14 +1451,26 @@ int ar_load(tts_ctx *ctx, const char *path) {
     FETCHT(p + ".mlp.c_fc.weight", FF, D, &l.w_fc); FETCH(p + ".mlp.c_fc.bias", FF, 1, &l.b_fc);
     FETCHT(p + ".mlp.c_proj.weight", D, FF, &l.w_fc2); FETCH(p + ".mlp.c_proj.bias", D, 1, &l.b_fc2);
     int r;
+    // The split-precision layouts hold 64 W as fp16 hi | lo (W16_SCALE): a trained GPT-2 never comes near |W| = 937, but a file that does must fail loudly instead of
+    // turning into an fp16 infinity inside the MFMA operands (round 6; the diffusion stage's proj_out pair picks its scale per tensor instead)
+    auto split_range = [&](const std::string &name, const float *w, size_t n) -> int {
+      float m = 0.f;
+      for (size_t i = 0; i < n; i++) m = std::max(m, std::fabs(w[i]));
+      if (!(m * W16_SCALE < 60000.0f)) return fail(ctx, TTS_ERR_FORMAT, "tensor '%s': max |w| = %g does not fit the split-precision fp16 layout (|w| < %g)", name.c_str(), m, 60000.0 / W16_SCALE);
+      return TTS_OK;
+    };
+    for (const char *wn : {".attn.c_attn.weight", ".attn.c_proj.weight", ".mlp.c_fc.weight", ".mlp.c_proj.weight"})
+      if ((r = split_range(p + wn, wf.t.at(p + wn).data.data(), wf.t.at(p + wn).data.size()))) return r;
     std::vector<float> wfold, cfold;
     fold_layernorm(wf.t.at(p + ".attn.c_attn.weight").data.data(), D, 3 * D, wf.t.at(p + ".ln_1.weight").data.data(),
                    wf.t.at(p + ".ln_1.bias").data.data(), wf.t.at(p + ".attn.c_attn.bias").data.data(), wfold, cfold);
+    if ((r = split_range(p + ".attn.c_attn.weight (LayerNorm gain folded in)", wfold.data(), wfold.size()))) return r;
     if (st->f32_mfma && (r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, 3 * D), &l.d_attn))) return r;
     if ((r = upload_h(ctx, st.get(), pack_mfma16h(wfold.data(), D, 3 * D), &l.dh_attn))) return r;
     if ((r = upload(ctx, st.get(), cfold, &l.db_attn))) return r;
     fold_layernorm(wf.t.at(p + ".mlp.c_fc.weight").data.data(), D, FF, wf.t.at(p + ".ln_2.weight").data.data(),
                    wf.t.at(p + ".ln_2.bias").data.data(), wf.t.at(p + ".mlp.c_fc.bias").data.data(), wfold, cfold);
+    if ((r = split_range(p + ".mlp.c_fc.weight (LayerNorm gain folded in)", wfold.data(), wfold.size()))) return r;
     if (st->f32_mfma && (r = upload(ctx, st.get(), pack_mfma16(wfold.data(), D, FF), &l.d_fc))) return r;
     if ((r = upload_h(ctx, st.get(), pack_mfma16h(wfold.data(), D, FF), &l.dh_fc))) return r;
     if ((r = upload(ctx, st.get(), cfold, &l.db_fc))) return r;

@@ -106,6 +106,9 @@ struct tts_ctx {
   int attn_f32_drop = 0;   // option "attn_f32_drop" (developer ablation inside attn_f32 = 1): bit 0 q/k, bit 1 v, bit 2 attention output lose their low halves (= the fp16 rounding of the default mode, one operand at a time)
   int lc_attn_f32 = 1;     // option "lc_attn_f32": the latent conditioner's AttentionBlocks (once per utterance; their output enters every step) in reference precision whatever attn_f32 says; 0 = follow attn_f32 (rounds 1-4)
   int attn_proj_f16 = 0;   // option "attn_proj_f16": 1 = proj_out's weight as ONE fp16 operand (the all-fp16 AttentionBlock of rounds 1-4, A/B only); 0 default = split pair W_hi + W_lo (F32-accurate weight, round 5)
+  int fp16_check = 0;      // option "fp16_check": scan every fp16 operand the diffusion stage writes for non-finite / saturated values (tts_diffusion_fp16_check)
+  int64_t fp16_bad_weights[2] = {0, 0}; // the same two counts over the split-precision weights packed by the last tts_load_diffusion
+  void *fp16_counts = nullptr;           // device: int64[2]
   int latency_mode = 0;    // option "latency_mode": small diffusion batches (<= 4096 packed rows) take the GroupNorm statistics from the producing GEMM's epilogue (diffusion.hip: gn_apply_kernel); not bit-identical to the batch path
   bool capturing = false;  // a hipGraph is being captured on the stream: ProfScope records nothing (event records would become graph nodes)
   int diff_graph = 1;      // option "diff_graph": the diffusion step is captured once per call and replayed (0: every step launched eagerly)
@@ -213,6 +216,7 @@ void voc_free(VocState *);
 int diff_cond_enc_load(tts_ctx *ctx, const char *path);
 void diff_cond_enc_free(DiffCondEncState *);
 int diff_cond_enc_latent(tts_ctx *ctx, const float *mel, const int32_t *frames, int n_clips, float *out2048);
+int diff_fp16_check(tts_ctx *ctx, int64_t counts[2]);            // diffusion.hip
 int diff_set_cond_latent(tts_ctx *ctx, const float *latent2048); // diffusion.hip: overrides the weight file's diffusion_conditioning_latent
 int voice_enc_load(tts_ctx *ctx, const char *path);
 void voice_enc_free(VoiceEncState *);

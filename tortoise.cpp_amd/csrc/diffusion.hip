@@ -184,6 +184,18 @@ __global__ __launch_bounds__(256) void to_f16_kernel(const float *__restrict__ x
   *(uint2 *)(y + (size_t)r * C + c) = o;
 }
 
+// Option fp16_check: count non-finite values and values beyond 60000 in an fp16 operand buffer (counts: int64[2]).
+__global__ __launch_bounds__(256) void fp16_scan_kernel(const __half *__restrict__ p, size_t n, unsigned long long *__restrict__ counts) {
+  unsigned long long bad = 0, big = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = __half2float(p[i]);
+    if (!(fabsf(v) <= 65504.0f)) bad++;
+    else if (fabsf(v) > 60000.0f) big++;
+  }
+  if (bad) atomicAdd(counts, bad);
+  if (big) atomicAdd(counts + 1, big);
+}
+
 // f32 -> fp16 copy of rows gathered from another layout: y[r] = x[src_row[r]], zero where src_row[r] < 0 (guard rows).
 __global__ __launch_bounds__(256) void gather_f16_kernel(const float *__restrict__ x, const int *__restrict__ src_row,
                                                          __half *__restrict__ y) {
@@ -771,7 +783,8 @@ __global__ void rows_to_ct_kernel(const float *__restrict__ net, int row0, int T
 struct AttnDev {
   float *norm_g, *norm_b, *qkv_b, *proj_b, *bias_tab;
   __half *qkv_w, *proj_w;
-  __half *proj_w_split; // [C][hi(64 w) | lo(64 w)]: proj_out's F32 weight as a split-precision pair (option attn_f32; the factor 64 keeps the low halves normal)
+  __half *proj_w_split; // [C][hi(s w) | lo(s w)]: proj_out's F32 weight as a split-precision pair; s = 1 / proj_alpha keeps the low halves normal
+  float proj_alpha;     // 1 / s, s = the largest power of two with max|W| s < 30000 (64 for |W| up to 468; round 6: was a fixed 64, whose hi half overflows at |W| > 1023)
 };
 struct ResDev { float *in_g, *in_b, *in_bias, *emb_w, *emb_b, *out_g, *out_b, *out_bias; __half *in_w, *out_w; };
 
@@ -943,13 +956,27 @@ struct Loader {
     {
       const HostTensor *t = get(p + ".proj_out.weight", (int64_t)C * C);
       std::vector<__half> sp((size_t)C * 2 * C);
+      float amax = 0.f;
+      for (float v : t->data) amax = std::max(amax, std::fabs(v));
+      if (!std::isfinite(amax)) { fail(ctx, TTS_ERR_FORMAT, "tensor '%s.proj_out.weight' holds a non-finite value", p.c_str()); return TTS_ERR_FORMAT; }
+      // per-tensor power-of-two scale: as large as keeps the hi half far from fp16's 65504 (the low halves then sit as far above the subnormals as they can);
+      // capped at 2^14 (a weight tensor of zeros would ask for infinity)
+      int e = 14;
+      while (e > -14 && std::ldexp(amax, e) >= 30000.0f) e--;
+      const float scale = std::ldexp(1.0f, e);
+      a.proj_alpha = 1.0f / scale;
       for (int n = 0; n < C; n++)
         for (int k = 0; k < C; k++) {
-          const float w = t->data[(size_t)n * C + k] * 64.0f;
+          const float w = t->data[(size_t)n * C + k] * scale;
           const __half hi = __float2half_rn(w);
           sp[(size_t)n * 2 * C + k] = hi;
           sp[(size_t)n * 2 * C + C + k] = __float2half_rn(w - __half2float(hi));
         }
+      for (const __half &h : sp) {
+        const float v = std::fabs(__half2float(h));
+        if (!(v <= 65504.0f)) ctx->fp16_bad_weights[0]++;
+        else if (v > 60000.0f) ctx->fp16_bad_weights[1]++;
+      }
       if ((r = put(sp, &a.proj_w_split))) return r;
     }
     if ((r = f32(p + ".proj_out.bias", C, &a.proj_b))) return r;
@@ -984,6 +1011,7 @@ struct Loader {
 } // namespace
 
 int diff_load(tts_ctx *ctx, const char *path) {
+  ctx->fp16_bad_weights[0] = ctx->fp16_bad_weights[1] = 0;
   WeightFile wf;
   std::string err;
   int rc = read_weight_file(path, wf, err);
@@ -1069,6 +1097,28 @@ static void dbg_sum(tts_ctx *ctx, const char *tag, const void *p, size_t bytes) 
 #else
 #define DBG_SUM(tag, p, bytes)
 #endif
+// option fp16_check: scan an fp16 operand buffer right after the launch that wrote it
+static int fp16_check(tts_ctx *ctx, const void *p, size_t n_halves) {
+  if (!ctx->fp16_check) return TTS_OK;
+  if (!ctx->fp16_counts) {
+    TTS_HIP(ctx, hipMalloc(&ctx->fp16_counts, 16));
+    TTS_HIP(ctx, hipMemset(ctx->fp16_counts, 0, 16));
+  }
+  fp16_scan_kernel<<<512, 256, 0, ctx->stream>>>((const __half *)p, n_halves, (unsigned long long *)ctx->fp16_counts);
+  TTS_HIP(ctx, hipGetLastError());
+  return TTS_OK;
+}
+int diff_fp16_check(tts_ctx *ctx, int64_t counts[2]) {
+  int64_t dev[2] = {0, 0};
+  if (ctx->fp16_counts) {
+    TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    TTS_HIP(ctx, hipMemcpy(dev, ctx->fp16_counts, 16, hipMemcpyDeviceToHost));
+  }
+  counts[0] = dev[0] + ctx->fp16_bad_weights[0];
+  counts[1] = dev[1] + ctx->fp16_bad_weights[1];
+  return TTS_OK;
+}
+
 static int gemm(tts_ctx *ctx, const char *fam, GemmArgs &g, const Layout &lay, int n_valid = 0, int k_valid = 0) {
   double mv = 0;
   for (int l : lay.len) mv += l;
@@ -1086,6 +1136,12 @@ static int gemm(tts_ctx *ctx, const char *fam, GemmArgs &g, const Layout &lay, i
   }
   ProfScope ps(ctx, fam, 2.0 * mv * (n_valid ? n_valid : g.N) * (k_valid ? k_valid : g.nseg * g.kseg));
   TTS_HIP(ctx, launch_gemm_f16(g, ctx->stream));
+  if (ctx->fp16_check) {
+    if (gemm_mode_qkv(g.mode)) {
+      CHECK(fp16_check(ctx, g.outH, (size_t)g.M * g.ldh));
+      CHECK(fp16_check(ctx, g.outVt, (size_t)(g.N / 3) * g.ldvt));
+    } else if (g.mode == GEMM_OUT_F16) CHECK(fp16_check(ctx, g.outH, (size_t)g.M * g.ldh));
+  }
   return TTS_OK;
 }
 
@@ -1317,13 +1373,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
 // GroupNorm front end: st_x != nullptr (option latency_mode, statistics left by the producing GEMM) -> gn_apply_kernel, else the reducing kernels of gn_fused
 static int gn(tts_ctx *ctx, const DiffState *st, const Layout &lay, const float *x, const long long *st_x, const float *g, const float *b, const float *ss, int do_silu,
               __half *y, const void *wa = nullptr, size_t wa_bytes = 0, const void *wb = nullptr, size_t wb_bytes = 0) {
-  if (!st_x) return gn_fused(ctx, lay, x, g, b, ss, do_silu, y, wa, wa_bytes, wb, wb_bytes);
-  ProfScope ps(ctx, "diff_gn_apply");
-  const int silu_mode = ctx->ggml_lut ? 1 : ctx->attn_f32 ? 2 : 0; // see silu_dev
-  gn_apply_kernel<<<lay.rows / 4, 256, 0, ctx->stream>>>(x, lay.d_chunk_seq.as<int>(), lay.d_start.as<int>(), lay.d_len.as<int>(), st_x, (int)st->gn_stripe_ll, ctx->gn_eps, g, b,
-                                                          ss, do_silu, silu_mode, y, (const char *)wa, (int)(wa_bytes >> 7), (const char *)wb, (int)(wb_bytes >> 7));
-  TTS_HIP(ctx, hipGetLastError());
-  return TTS_OK;
+  if (!st_x) {
+    CHECK(gn_fused(ctx, lay, x, g, b, ss, do_silu, y, wa, wa_bytes, wb, wb_bytes));
+    return fp16_check(ctx, y, (size_t)lay.rows * C);
+  }
+  {
+    ProfScope ps(ctx, "diff_gn_apply");
+    const int silu_mode = ctx->ggml_lut ? 1 : ctx->attn_f32 ? 2 : 0; // see silu_dev
+    gn_apply_kernel<<<lay.rows / 4, 256, 0, ctx->stream>>>(x, lay.d_chunk_seq.as<int>(), lay.d_start.as<int>(), lay.d_len.as<int>(), st_x, (int)st->gn_stripe_ll, ctx->gn_eps, g, b,
+                                                            ss, do_silu, silu_mode, y, (const char *)wa, (int)(wa_bytes >> 7), (const char *)wb, (int)(wb_bytes >> 7));
+    TTS_HIP(ctx, hipGetLastError());
+  }
+  return fp16_check(ctx, y, (size_t)lay.rows * C);
 }
 
 // in_layers of a ResBlock (GroupNorm, SiLU, conv k=1): H = conv(silu(gn(x))). No timestep dependence.
@@ -1384,6 +1445,7 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
     }
     TTS_HIP(ctx, hipGetLastError());
   }
+  CHECK(fp16_check(ctx, wk.ATT16(), (size_t)lay.rows * C));
   if (f32 && (ctx->attn_f32_drop & 4)) TTS_HIP(ctx, hipMemsetAsync(wk.att16_lo.p, 0, (size_t)(wk.rows + 2) * C * 2, ctx->stream));     // attention output as one fp16 value
   DBG_SUM("attn out", wk.ATT16(), (size_t)lay.rows * C * 2);
   if (f32) { // att . W^T = att_hi . W_hi + att_lo . W_hi + att_hi . W_lo  (W scaled by 64 at load)
@@ -1391,14 +1453,14 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
     p.A[0] = wk.ATT16(); p.A[1] = wk.att16_lo.as<__half>() + C; p.A[2] = wk.ATT16();
     p.row_off[0] = p.row_off[1] = p.row_off[2] = 0;
     p.custom_w = 1; p.ldw_ = 2 * C; p.w_off_[0] = 0; p.w_off_[1] = 0; p.w_off_[2] = C;
-    p.mode = st_out ? GEMM_OUT_F32_SCALED_STATS : GEMM_OUT_F32_SCALED; p.alpha = 1.0f / 64.0f; p.outF = X; p.ldo = C; p.resid = X;
+    p.mode = st_out ? GEMM_OUT_F32_SCALED_STATS : GEMM_OUT_F32_SCALED; p.alpha = w.proj_alpha; p.outF = X; p.ldo = C; p.resid = X;
     p.st_out = st_out; p.st_stripe_ll = (int)st->gn_stripe_ll; p.chunk_seq = lay.d_chunk_seq.as<int>();
     return gemm(ctx, "diff_gemm", p, lay, 0, C);
   }
   if (!ctx->attn_proj_f16) { // default: att16 . (W_hi + W_lo)^T — proj_out's F32 weight to 2^-22, the attention output stays one fp16 operand
     GemmArgs p = gemm_base(lay, wk.ATT16(), C, 2, C, w.proj_w_split, C, w.proj_b);
     p.custom_w = 1; p.ldw_ = 2 * C; p.w_off_[0] = 0; p.w_off_[1] = C;
-    p.mode = st_out ? GEMM_OUT_F32_SCALED_STATS : GEMM_OUT_F32_SCALED; p.alpha = 1.0f / 64.0f; p.outF = X; p.ldo = C; p.resid = X;
+    p.mode = st_out ? GEMM_OUT_F32_SCALED_STATS : GEMM_OUT_F32_SCALED; p.alpha = w.proj_alpha; p.outF = X; p.ldo = C; p.resid = X;
     p.st_out = st_out; p.st_stripe_ll = (int)st->gn_stripe_ll; p.chunk_seq = lay.d_chunk_seq.as<int>();
     p.dual_b = ctx->proj_dual_b; // both weight halves per staged activation tile (gemm_f16_vh_dualb_kernel); 0 = two K segments (A/B)
     CHECK(gemm(ctx, "diff_gemm", p, lay, 0, C));

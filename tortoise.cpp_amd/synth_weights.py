@@ -70,6 +70,36 @@ class _Gen:
         return self.normal((n,), 0.05)
 
 
+class _TrainedGen(_Gen):
+    """'Trained-statistics' synthetic weights (round 6): what the small-sigma generator above never shows the fp16 operand paths —
+    normalisation gains of order 0.1 .. 12 (log-uniform) with biases of order 0.5, heavy-tailed conv / linear weights (1 value in 10^4 is an outlier of 30 sigma),
+    relative-position biases of +-10, embeddings at unit scale. The branch gains are divided by the RMS of the preceding normalisation gain, so the residual
+    stream keeps the magnitude a trained network keeps while every GEMM operand carries the large dynamic range."""
+    GAMMA_RMS = float(np.sqrt((12.0 ** 2 - 0.1 ** 2) / (2.0 * np.log(120.0))))  # rms of a log-uniform variable on [0.1, 12] = 3.88
+
+    def normal(self, shape, std):
+        w = self.rng.standard_normal(shape, dtype=np.float32) * np.float32(std)
+        n = int(np.prod(shape))
+        if n >= 4096:
+            k = max(1, n // 10000)
+            idx = self.rng.choice(n, size=k, replace=False)
+            w.reshape(-1)[idx] = np.float32(30.0 * std) * self.rng.choice(np.array([-1.0, 1.0], np.float32), size=k)
+        return w
+
+    def lecun(self, shape, fan_in, gain=1.0):
+        return self.normal(shape, gain / (np.sqrt(fan_in) * self.GAMMA_RMS))
+
+    def gamma(self, n):
+        return np.exp(self.rng.uniform(np.log(0.1), np.log(12.0), n)).astype(np.float32)
+
+    def beta(self, n):
+        return (self.rng.standard_normal(n) * 0.5).astype(np.float32)
+
+
+def _gen(seed, stats):
+    return _TrainedGen(seed) if stats == "trained" else _Gen(seed)
+
+
 def write_ar(path, n_layers=30, seed=1234):
     """ggml-model.bin: GPT-2 30x1024 (main.cpp:682-792)."""
     g = _Gen(seed)
@@ -100,7 +130,10 @@ def _add_attn(w, g, p, D=1024):
     w.add(p + ".norm.weight", g.gamma(D)); w.add(p + ".norm.bias", g.beta(D))
     w.add(p + ".qkv.weight", g.lecun((3 * D, D), D, 1.0)); w.add(p + ".qkv.bias", g.normal((3 * D,), 0.02))
     w.add(p + ".proj_out.weight", g.lecun((D, D), D, 0.5)); w.add(p + ".proj_out.bias", g.normal((D,), 0.02))
-    w.add(p + ".relative_pos_embeddings.relative_attention_bias.weight", g.normal((32, 16), 0.1))
+    if isinstance(g, _TrainedGen):  # bias = 8 x table (main.cpp:3232-3275): +-10
+        w.add(p + ".relative_pos_embeddings.relative_attention_bias.weight", g.rng.uniform(-1.25, 1.25, (32, 16)).astype(np.float32))
+    else:
+        w.add(p + ".relative_pos_embeddings.relative_attention_bias.weight", g.normal((32, 16), 0.1))
 
 
 def _add_res(w, g, p, D=1024):
@@ -111,12 +144,12 @@ def _add_res(w, g, p, D=1024):
     w.add(p + ".out_layers.3.weight", g.lecun((D, D, 3), 3 * D, 0.5)); w.add(p + ".out_layers.3.bias", g.normal((D,), 0.02))
 
 
-def write_diffusion(path, n_main=10, n_tail=3, n_integ=3, n_lc=4, seed=1235):
-    """ggml-diffusion-model.bin (main.cpp:1244-1536)."""
-    g = _Gen(seed)
+def write_diffusion(path, n_main=10, n_tail=3, n_integ=3, n_lc=4, seed=1235, stats="small"):
+    """ggml-diffusion-model.bin (main.cpp:1244-1536). stats = "trained": see _TrainedGen."""
+    g = _gen(seed, stats)
     w = GgmlWriter(path)
     D = 1024
-    w.add("diffusion_conditioning_latent", g.normal((1, 2 * D), 0.1))
+    w.add("diffusion_conditioning_latent", g.normal((1, 2 * D), 1.0 if stats == "trained" else 0.1))
     w.add("latent_conditioner.0.weight", g.lecun((D, D, 3), 3 * D, 1.0)); w.add("latent_conditioner.0.bias", g.normal((D,), 0.02))
     for i in range(1, 1 + n_lc):
         _add_attn(w, g, "latent_conditioner.%d" % i)
@@ -135,7 +168,7 @@ def write_diffusion(path, n_main=10, n_tail=3, n_integ=3, n_lc=4, seed=1235):
         _add_res(w, g, "layers.%d" % i)
     w.add("out.0.weight", g.gamma(D)); w.add("out.0.bias", g.beta(D))
     w.add("out.2.weight", g.lecun((200, D, 3), 3 * D, 0.5)); w.add("out.2.bias", g.normal((200,), 0.02))
-    w.add("unconditioned_embedding", g.normal((1, D, 1), 0.5).reshape(D))
+    w.add("unconditioned_embedding", g.normal((1, D, 1), 1.0 if stats == "trained" else 0.5).reshape(D))
     w.close()
 
 
