@@ -284,14 +284,20 @@ def main():
         voice = tv.cpu().numpy()
         prompts = {p: tt[p].cpu().numpy() for p in range(8)}
 
+    placement = {"node": -1, "cpulist": "", "cpus": 0}  # NUMA node of this rank's GPU / CPUs the rank was pinned to (0: not pinned)
     if a.dry_engine:
         eng = pkg.Engine.__new__(pkg.Engine)
         eng.L = pkg.lib()
         eng.h = eng.L.tts_create(-1)
     else:
         eng = pkg.Engine(device)  # raises without the HIP library/device: there is no fallback path
-        if world > 1:  # N processes share the host: leave each rank's sampler pool its share of the cores
-            eng.set_option("sampler_threads", max(0, min(7, (os.cpu_count() or 8) // world - 2)))
+        if world > 1:
+            # N processes share the host: each rank — its Python thread and the sampler pool it creates — stays on the CPUs of its own GPU's NUMA node (the sampler's
+            # top-k lists and the logits fallback rows arrive in pinned memory next to that GPU), and the pool takes its share of those cores
+            placement["cpus"] = eng.pin_to_numa_node()
+            ncpu = placement["cpus"] or (os.cpu_count() or 8) // world
+            eng.set_option("sampler_threads", max(0, min(7, ncpu - 2)))
+        placement["node"], placement["cpulist"] = eng.numa_node()
         eng.load(model_dir)
     if a.no_diff_graph and not a.dry_engine:
         eng.set_option("diff_graph", 0)
@@ -355,6 +361,8 @@ def main():
                 torch.cuda.synchronize()
         # every engine call is synchronous (ends with hipStreamSynchronize on its stream)
 
+    per_rank = []
+
     def timed(steps, share):
         if not a.dry_engine:
             eng.set_option("share_uncond", 1 if share else 0)
@@ -369,6 +377,12 @@ def main():
         dt = time.time() - t0
         if dist:
             import torch
+            mine = torch.tensor([dt, float(placement["node"]), float(placement["cpus"])], dtype=torch.float64, device=dev)
+            every = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in range(world)]
+            dist.all_gather(every, mine)  # every rank's own time: a straggler is visible in the line, not only the maximum
+            per_rank.clear()
+            per_rank.extend({"rank": r, "ms_per_step": round(1e3 * float(e[0].item()) / steps, 2), "numa_node": int(e[1].item()), "pinned_cpus": int(e[2].item())}
+                            for r, e in enumerate(every))
             t = torch.tensor([dt, 0.0], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t[0].item())
@@ -641,6 +655,7 @@ def main():
         "reference_precision_option": ref_prec,
         "ragged_batch": ragged, "single_utterance_ms": single_ms, "single_utterance_latency_mode": single_lat, "first_audio_ms": first_audio, "clvp_ms": clvp,
         # the collective backend has seen this many ranks (all_reduce of ones) and rank 0 has gathered this many audio samples in the last pass
+        "per_rank": (per_rank if per_rank else [{"rank": 0, "ms_per_step": None, "numa_node": placement["node"], "pinned_cpus": placement["cpus"]}]),
         "collective_ranks": collective_ranks, "collective_backend": (a.backend if dist else None), "gathered_samples": shape.get("gathered_samples"),
         "roofline": {"kernel": "gemm_f16_vh_kernel + gemm_f16_conv3_vh_kernel (diffusion convs/projections)", "bound": "mfma",
                      "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4),

@@ -44,6 +44,8 @@ enum { TTS_VOCAB_MEL = 8194, TTS_DMODEL = 1024, TTS_MEL_CH = 100, TTS_CODES = 50
 /* Interface version: bumped whenever a prototype in this file changes incompatibly (a caller built against another value must not call in).
  *   4 = round 4: tts_host_mel_diffusion100 gained `normalize` (voice files written by the earlier tools/make_voice.py hold a NORMALISED mel of
  *       full-length clips and must be regenerated: INTEGRATION.md "voice files"),
+ *   6 = round 6: options "latency_mode", "fp16_check"; tts_diffusion_fp16_check, tts_device_numa_node, tts_pin_to_device_numa_node; the split proj_out weight is
+ *       scaled per tensor
  *   5 = round 5: tts_ar_set_stop_schedule, tts_version; option "attn_proj_f16"; the default AttentionBlock multiplies proj_out on an F32-accurate
  *       (split fp16 pair) weight. */
 #define TTS_API_VERSION 6
@@ -53,6 +55,12 @@ int tts_version(void);
  * when there is no such device. device = -1 gives a host-only context (tokenizer, RNG, sampler):
  * every stage call on it fails with TTS_ERR_HIP — there is no CPU compute path. */
 tts_ctx *tts_create(int device);
+/* Host placement of a device context (round 6; multi-GPU runs: one process per GPU, each with a pool of sampler threads): the NUMA node of the context's GPU
+ * (hipDeviceGetPCIBusId -> /sys/bus/pci/devices/<id>/numa_node), -1 if unknown or a host-only context; cpulist_out receives that node's CPU list in the kernel's
+ * "0-31,128-159" form (empty when the node is unknown). tts_pin_to_device_numa_node restricts the calling thread — and the sampler threads it creates later — to it
+ * (sched_setaffinity) and returns the number of CPUs in the mask, 0 if nothing was changed. The reference has no counterpart (single device, main.cpp:651). */
+int tts_device_numa_node(const tts_ctx *ctx, char *cpulist_out, int cpulist_cap);
+int tts_pin_to_device_numa_node(tts_ctx *ctx);
 void tts_destroy(tts_ctx *ctx);
 const char *tts_last_error(const tts_ctx *ctx);
 /* Options (all have reference defaults): "gn_eps" (1e-6; ggml's GroupNorm epsilon),

@@ -31,11 +31,17 @@ static bool wr(int fd, const void *p, size_t n) {
   }
   return true;
 }
+// FAKE_RCCL_HANG_ON_PEER_LOSS=1: a rank whose peer went away blocks for ever instead of failing — what the real library does when a rank dies inside a collective;
+// the parent process has to end such ranks (csrc/cli_main.cpp: SIGTERM to the workers still alive when one exits with an error)
+static bool peer_lost() {
+  if (getenv("FAKE_RCCL_HANG_ON_PEER_LOSS")) for (;;) pause();
+  return false;
+}
 static bool rd(int fd, void *p, size_t n) {
   char *c = (char *)p;
   while (n) {
     const ssize_t k = read(fd, c, n);
-    if (k == 0) return false;
+    if (k == 0) return peer_lost();
     if (k < 0) { if (errno == EINTR) continue; return false; }
     c += k; n -= (size_t)k;
   }

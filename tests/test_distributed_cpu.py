@@ -284,6 +284,50 @@ def test_cli_rccl_exchange_four_ranks_on_the_cpu(tmp_path, fake_rccl):
     assert r.returncode != 0 and "TTS_RCCL_LIB" in r.stderr
 
 
+def test_cli_rccl_exchange_eight_ranks_slow_rank_and_failing_rank(tmp_path, fake_rccl):
+    """The rank count of the first 8-GPU lease, on the CPU: `tortoise --devices 8 --exchange rccl` through the stand-in library.
+    (1) eight ranks, files equal the single process's; (2) one rank arrives 2 s late at the final exchange (--test-slow-shard): same files; (3) one rank dies after the
+    conditioning broadcast (--test-fail-shard): with a stand-in that FAILS on a lost peer every other rank ends with an error by itself; with one that BLOCKS for ever
+    (FAKE_RCCL_HANG_ON_PEER_LOSS — what librccl does when a rank dies inside a collective) the parent ends the waiting workers (SIGTERM): either way the command returns a
+    non-zero status within 10 s and leaves no worker behind; (4) --dry-run without the stand-in refuses to hand host buffers to the real library."""
+    import time
+    exe = os.path.join(ROOT, "tortoise.cpp_amd", "tortoise")
+    if not os.path.exists(exe):
+        pytest.skip("CLI binary not built")
+    models = os.path.join(ROOT, "models")
+    env = dict(os.environ, TTS_RCCL_LIB=fake_rccl, TMPDIR=str(tmp_path))
+    base = [exe, "--dry-run", "1", "--models", models, "--voice", os.path.join(models, "mol.bin"), "--seed", "29", "--codes", "5", "--candidates", "16"]
+
+    def wavs(out):
+        files = [out] + ["%s.%d.wav" % (out, c) for c in range(1, 16)]
+        assert all(os.path.exists(f) for f in files), sorted(os.listdir(tmp_path))
+        return [np.frombuffer(open(f, "rb").read()[44:], np.float32) for f in files]
+
+    runs = {}
+    for tag, extra in (("one", []), ("rccl8", ["--devices", "8", "--exchange", "rccl"]), ("slow", ["--devices", "8", "--exchange", "rccl", "--test-slow-shard", "5"])):
+        out = str(tmp_path / (tag + ".wav"))
+        r = subprocess.run(base + ["--output", out] + extra, capture_output=True, text=True, timeout=120, env=env)
+        assert r.returncode == 0, (tag, r.stdout + r.stderr)
+        runs[tag] = wavs(out)
+    for tag in ("rccl8", "slow"):
+        for c in range(16):
+            assert (runs[tag][c] == runs["one"][c]).all(), (tag, c)
+    for hang in (False, True):
+        e = dict(env, FAKE_RCCL_HANG_ON_PEER_LOSS="1") if hang else env
+        t0 = time.time()
+        r = subprocess.run(base + ["--output", str(tmp_path / ("fail%d.wav" % hang)), "--devices", "8", "--exchange", "rccl", "--test-fail-shard", "3"],
+                           capture_output=True, text=True, timeout=60, env=e)
+        dt = time.time() - t0
+        assert r.returncode != 0 and "--test-fail-shard" in r.stderr, (hang, r.returncode, r.stderr[-500:])
+        assert dt < 10.0, (hang, dt)
+        # the parent reaps every worker before it returns: nothing of this command is left running
+        left = subprocess.run(["pgrep", "-f", str(tmp_path / ("fail%d.wav" % hang))], capture_output=True, text=True).stdout.split()
+        assert not left, (hang, left)
+    e = {k: v for k, v in env.items() if k != "TTS_RCCL_LIB"}
+    r = subprocess.run(base + ["--output", str(tmp_path / "nolib.wav"), "--devices", "2", "--exchange", "rccl"], capture_output=True, text=True, timeout=120, env=e)
+    assert r.returncode != 0 and "TTS_RCCL_LIB" in r.stderr, r.stderr[-500:]
+
+
 def test_bench_eight_ranks_gloo_dry_engine():
     """The rank count the driver's scaling run uses: `python bench.py --gpus 8` launches its own eight ranks (torch.distributed.run, 127.0.0.1), every rank a host-only
     context (--dry-engine), gloo for the collectives: rendezvous, the all_reduce of ones (collective_ranks = 8), prompt / voice broadcast, size all_gather, gather of the
@@ -300,3 +344,7 @@ def test_bench_eight_ranks_gloo_dry_engine():
         out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert out["n_gpus"] == 8 and out["collective_ranks"] == 8 and out["collective_backend"] == "gloo" and out["scaling"] == "strong"
         assert out["config"]["candidates_per_gpu"] == per_gpu and out["config"]["prompts"] == prompts and out["gathered_samples"] > 0
+        # round 6: every rank's own time and host placement are in the line (a straggler shows up in the first SCALE_r*.json, not only as the maximum)
+        assert [r["rank"] for r in out["per_rank"]] == list(range(8)) and all(r["ms_per_step"] > 0 for r in out["per_rank"])
+        assert max(r["ms_per_step"] for r in out["per_rank"]) == pytest.approx(out["ms_per_step"], rel=1e-3, abs=0.02)
+        assert all(r["numa_node"] == -1 and r["pinned_cpus"] == 0 for r in out["per_rank"])  # host-only contexts: nothing to pin to

@@ -60,6 +60,7 @@ def lib():
         "tts_ar_step": (ci, [vp, _i32p, ci, _f32p]), "tts_ar_latents": (ci, [vp, _i32p, ci, ci, _f32p]),
         "tts_sample": (ci, [vp, _f32p, _i32p, ci, ci, _i32p]),
         "tts_ar_step_sample": (ci, [vp, _i32p, ci, C.c_uint, _i32p]), "tts_ar_topk_fallbacks": (ci, [vp]), "tts_diffusion_time_mlp_retries": (ci, [vp]), "tts_diffusion_fp16_check": (ci, [vp, C.POINTER(C.c_int64)]),
+        "tts_device_numa_node": (ci, [vp, C.c_char_p, ci]), "tts_pin_to_device_numa_node": (ci, [vp]),
         "tts_host_sample_row": (ci, [_f32p, _i32p, ci, cf]), "tts_host_sample_prefiltered": (ci, [_f32p, _i32p, ci, cf, ci]),
         "tts_autoregressive": (ci, [vp, _i32p, ci, _f32p, ci, ci, C.c_uint, _i32p, _i32p, vp, _i32p]),
         "tts_ar_stop_status": (ci, [vp, _i32p, ci]), "tts_ar_set_stop_schedule": (ci, [vp, C.c_void_p, ci]),
@@ -186,6 +187,16 @@ class Engine:
 
     def topk_fallbacks(self):
         return self.L.tts_ar_topk_fallbacks(self.h)
+
+    def numa_node(self):
+        """(NUMA node of this context's GPU or -1, that node's cpulist)"""
+        buf = C.create_string_buffer(1024)
+        node = self.L.tts_device_numa_node(self.h, buf, 1024)
+        return node, buf.value.decode()
+
+    def pin_to_numa_node(self):
+        """restrict this process (and the sampler threads created later) to the CPUs of the GPU's NUMA node; returns the number of CPUs, 0 = unchanged"""
+        return self.L.tts_pin_to_device_numa_node(self.h)
 
     def fp16_check(self):
         """(non-finite, saturated) fp16 operand values seen since option fp16_check was set (+ the split weights of the loaded diffusion model)."""

@@ -1,5 +1,7 @@
 // C ABI of libtortoise_mi355x.so (see include/tortoise_mi355x.h for the reference call sites).
 #include "common.h"
+#include <sched.h>
+#include <cctype>
 #include <algorithm>
 #include <chrono>
 #include <fstream>
@@ -70,6 +72,52 @@ tts_ctx *tts_create(int device) {
                       std::chrono::system_clock::now().time_since_epoch()).count();
   c->generator.seed(c->seed_value);
   return c;
+}
+
+// NUMA node of the context's GPU and that node's CPU list (sysfs); -1 / "" when unknown
+static int device_numa(const tts_ctx *c, std::string &cpulist) {
+  cpulist.clear();
+  if (!c || c->device < 0) return -1;
+  char bus[64] = {};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, c->device) != hipSuccess) return -1;
+  for (char *p = bus; *p; p++) *p = (char)tolower(*p);
+  FILE *f = fopen((std::string("/sys/bus/pci/devices/") + bus + "/numa_node").c_str(), "r");
+  int node = -1;
+  if (f) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+  if (node < 0) return -1;
+  f = fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r");
+  if (f) {
+    char buf[1024] = {};
+    if (fgets(buf, sizeof buf, f)) { cpulist = buf; while (!cpulist.empty() && isspace((unsigned char)cpulist.back())) cpulist.pop_back(); }
+    fclose(f);
+  }
+  return node;
+}
+int tts_device_numa_node(const tts_ctx *c, char *out, int cap) {
+  std::string cl;
+  const int node = device_numa(c, cl);
+  if (out && cap > 0) snprintf(out, (size_t)cap, "%s", cl.c_str());
+  return node;
+}
+int tts_pin_to_device_numa_node(tts_ctx *c) {
+  std::string cl;
+  if (device_numa(c, cl) < 0 || cl.empty()) return 0;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  int n = 0;
+  for (size_t i = 0; i < cl.size();) { // "a-b,c,d-e"
+    char *end = nullptr;
+    const long a = strtol(cl.c_str() + i, &end, 10);
+    long b = a;
+    if (*end == '-') b = strtol(end + 1, &end, 10);
+    for (long k = a; k <= b && k < CPU_SETSIZE; k++) { CPU_SET((int)k, &set); n++; }
+    i = (size_t)(end - cl.c_str());
+    if (i < cl.size() && cl[i] == ',') i++;
+    else if (i < cl.size() && !isdigit((unsigned char)cl[i])) break;
+  }
+  if (n == 0 || sched_setaffinity(0, sizeof set, &set) != 0) return 0;
+  if (c->sampler_pool) { sampler_pool_free(c->sampler_pool); c->sampler_pool = nullptr; } // its threads are re-created (inside the mask) at the next use
+  return n;
 }
 
 void tts_destroy(tts_ctx *c) {

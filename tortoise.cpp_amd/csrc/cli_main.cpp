@@ -54,6 +54,7 @@ int main(int argc, char **argv) {
   int seed = 0, candidates = 1, steps = 80, device = 0, fixed_codes = 0, devices = 1, shard = -1, nshards = 1;
   std::string device_map, clvpPath, exchange = "files", rccl_id, diffLatentPath;
   bool dry = false, allow_shared = false;
+  int test_fail_shard = -1, test_slow_shard = -1;
   std::vector<std::pair<std::string, double>> engine_options; // --option key=value (repeatable): tts_set_option before the models are loaded
   for (int i = 1; i < argc - 1; ++i) {
     std::string a(argv[i]);
@@ -72,6 +73,8 @@ int main(int argc, char **argv) {
     else if (a == "--clvp") clvpPath = argv[i + 1];
     else if (a == "--exchange") exchange = argv[i + 1];
     else if (a == "--dry-run") dry = argv[i + 1][0] != '0'; // plumbing check without a device, see below
+    else if (a == "--test-fail-shard") test_fail_shard = std::stoi(argv[i + 1]); // test hooks (tests/test_distributed_cpu.py): worker r exits with status 3 after the
+    else if (a == "--test-slow-shard") test_slow_shard = std::stoi(argv[i + 1]); // conditioning broadcast / sleeps 2 s before the final exchange
     else if (a == "--option") { // engine option, e.g. --option attn_f32=1 (include/tortoise_mi355x.h: tts_set_option)
       const std::string kv = argv[i + 1];
       const size_t eq = kv.find('=');
@@ -97,8 +100,9 @@ int main(int argc, char **argv) {
       p = q + 1;
     }
     // One engine process per GPU. Two on ONE device is not a deployment form: round 4 saw a kernel's packed f32 FMAs return wrong sums while another
-    // process's MFMA waves shared the GPU (profiles/r4_two_process_determinism.txt). The library is built without packed f32 arithmetic since round 5
-    // (tortoise.cpp_amd/Makefile), but the form stays unsupported: refused unless --allow-shared-device 1 (tests on a one-GPU box).
+    // process's MFMA waves shared the GPU (profiles/r4_two_process_determinism.txt). The default build KEEPS the packed f32 forms (a build without them is one make
+    // variable away: `make PK=...`, profiles/r5_packed_f32_ab.txt); what protects a run is this refusal — and, with --exchange files, running the workers that share a
+    // device one after the other. --allow-shared-device 1 with --exchange rccl still puts two engine processes on one GPU at once (tests on a one-GPU box only).
     bool shared = false;
     for (int r = 0; r < devices; r++)
       for (int q = 0; q < r; q++)
@@ -116,6 +120,10 @@ int main(int argc, char **argv) {
       seed = (int)(std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count() & 0x7fffffff);
     std::string id_hex;
     if (exchange == "rccl") { // the communicator's id is created here and handed to every worker
+      if (dry && !getenv("TTS_RCCL_LIB")) {
+        fprintf(stderr, "--dry-run with --exchange rccl needs TTS_RCCL_LIB=<stand-in library> (tests/fake_rccl.cpp): librccl cannot take the host buffers of a dry run\n");
+        return 1;
+      }
       RcclApi api;
       ncclUniqueId id;
       if (!api.open()) return 1;
@@ -219,7 +227,9 @@ int main(int argc, char **argv) {
     n = cond.n;
     tokens.assign(cond.ids, cond.ids + n);
     memcpy(voice.data(), cond.voice, 4096);
+    if (shard == test_fail_shard) { fprintf(stderr, "worker %d: --test-fail-shard\n", shard); _exit(3); } // the others are left waiting in the final exchange
   }
+  if (shard >= 0 && shard == test_slow_shard) sleep(2);
   // results of the three stages (or of their stand-in under --dry-run): B output candidates, candidate c has nsamp[c] samples in `audio`
   int B = candidates, kept_gc = -1;
   double kept_score = 0;

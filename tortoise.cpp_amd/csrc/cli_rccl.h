@@ -86,6 +86,8 @@ struct RcclWorld {
   hipError_t sync() { return host_only ? hipSuccess : hipStreamSynchronize(stream); }
   bool init(const std::string &hex_id, int rank_, int n_, bool host_only_ = false) { // the calling process has already selected its device (tts_create)
     rank = rank_; n = n_; host_only = host_only_;
+    // host staging buffers and no stream: only a stand-in library that moves host memory can take them; the real librccl would dereference them as device pointers
+    if (host_only && !getenv("TTS_RCCL_LIB")) { err = "--dry-run with --exchange rccl needs TTS_RCCL_LIB=<stand-in library> (tests/fake_rccl.cpp): librccl cannot take host buffers"; return false; }
     ncclUniqueId id;
     if (!rccl_id_from_hex(hex_id, id)) { err = "bad --rccl-id"; return false; }
     if (!api.open()) { err = "librccl.so not available"; return false; }
