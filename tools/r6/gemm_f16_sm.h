@@ -21,8 +21,9 @@
 //  * QKV (NJ = 6: 64 x 384 = two heads per tile, 224 workgroups for N = 3 072): q | k columns with swapped operands (16-byte stores), V columns in
 //    natural order (stored transposed), chosen per 16-column block at compile time; DUALB: proj_out on the split-precision weight (both halves of
 //    a K tile staged, every A fragment feeds two MFMAs).
-// Used by diffusion.hip when option latency_mode = 1 and the packed layout has at most LAT_MAX_ROWS rows; the batch path (and its bit-for-bit
-// batch invariance) is untouched.
+// MEASURED AND REJECTED (round 6, profiles/r6_small_gemm.txt): correct at every ring depth, 2-3x slower than the batch kernels at the single-utterance shape (a phase
+// period of 1 900-3 700 cycles around ~130 cycles of MFMA per wave: per-phase fixed costs, and the GroupNorm transform re-done by every column-tile workgroup). Kept as a
+// developer header (tools/r6/gemm_sm_probe.hip); the product's option latency_mode uses the batch kernels with GEMM_OUT_*_STATS epilogues + gn_apply_kernel instead.
 #pragma once
 #include "gemm_f16.h"
 

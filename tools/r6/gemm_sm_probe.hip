@@ -2,7 +2,7 @@
 // batch kernels of gemm_f16.h, at the single-utterance shape (2 sequences x 870 frames = 1 792 packed rows). For each of the five shapes of the diffusion
 // network: result check (operand transform incl. GroupNorm statistics from fixed-point sums, GEMM, epilogue, output statistics), then us / launch warm
 // (back to back) and with cold weights (1 GB fill between launches, activations re-touched: the in-situ condition of the sampling step).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I tortoise.cpp_amd/csrc -I include tools/r6/gemm_sm_probe.hip -o tools/bin/gemm_sm_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I tortoise.cpp_amd/csrc -I tools/r6 -I include tools/r6/gemm_sm_probe.hip -o tools/bin/gemm_sm_probe
 #include "gemm_f16_sm.h"
 #include <algorithm>
 #include <cmath>
