@@ -169,6 +169,12 @@ def finish_mean_gate(f):
         f["oracle_vs_t32_mean"] = max(means)
         top = max(means + [f.get("seed_distribution", {}).get("mean_mu_plus_3sigma", 0.0)])
         f["gate_f32_mean"] = round(MEAN_RATIO_MAX * top, 8)
+    # the maximum: 1.5 x the largest f32-vs-f32 maximum on record for the class — samples, test problems and the seed distribution
+    mx = [x["oracle_vs_t32"] for x in f.get("samples", [])] + [p["oracle_vs_t32"] for p in f.get("problems", {}).values()] + \
+         [r["max"] for r in f.get("seed_distribution", {}).get("rows", [])]
+    if mx:
+        f["oracle_vs_t32"] = max(mx)
+        f["gate_f32"] = round(max(1e-3, 1.5 * max(mx)), 5)
 
 
 def seed_distribution(kind, L, n_seeds, steps=80):
