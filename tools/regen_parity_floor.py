@@ -182,9 +182,10 @@ def seed_distribution(kind, L, n_seeds, steps=80):
     gate is built on. Recorded under rec[kind]["seed_distribution"]; conftest.loop_gate_mean uses mu + 3 sigma of the per-seed means as the class's floor."""
     path = ensure_models(kind)
     rec = json.load(open(FLOOR_JSON))
-    dist = rec[kind].setdefault("seed_distribution", {"L": L, "steps": steps, "rows": []})
+    key = "seed_distribution" if steps == 80 else "seed_distribution_%d" % steps
+    dist = rec[kind].setdefault(key, {"L": L, "steps": steps, "rows": []})
     if dist.get("L") != L:
-        dist = rec[kind]["seed_distribution"] = {"L": L, "steps": steps, "rows": []}
+        dist = rec[kind][key] = {"L": L, "steps": steps, "rows": []}
     for seed in range(101, 101 + n_seeds):
         if any(r["seed"] == seed for r in dist["rows"]):
             continue
@@ -193,13 +194,13 @@ def seed_distribution(kind, L, n_seeds, steps=80):
         dist["rows"].append({"seed": seed, "T": int(T), "max": float(d.max()), "mean": float(d.mean())})
         print(kind, "seed", seed, "T", T, "oracle vs torch-f32: max %.3e mean %.3e" % (d.max(), d.mean()), flush=True)
         rec = json.load(open(FLOOR_JSON))
-        rec[kind]["seed_distribution"] = dist
+        rec[kind][key] = dist
         json.dump(rec, open(FLOOR_JSON, "w"), indent=1)
     means = np.array([r["mean"] for r in dist["rows"]])
     dist["mean_mu"], dist["mean_sigma"] = float(means.mean()), float(means.std(ddof=1)) if len(means) > 1 else 0.0
     dist["mean_mu_plus_3sigma"] = dist["mean_mu"] + 3 * dist["mean_sigma"]
     rec = json.load(open(FLOOR_JSON))
-    rec[kind]["seed_distribution"] = dist
+    rec[kind][key] = dist
     finish_mean_gate(rec[kind])
     json.dump(rec, open(FLOOR_JSON, "w"), indent=1)
     print(kind, "mean of the means %.3e, sigma %.3e (%.1f %%), mu + 3 sigma %.3e" % (dist["mean_mu"], dist["mean_sigma"], 100 * dist["mean_sigma"] / dist["mean_mu"],
@@ -259,7 +260,7 @@ def main():
         for spec in sys.argv[sys.argv.index("--seeds") + 1:]:
             kind, kv = spec.split(":")
             kw = {k: int(v) for k, v in (p.split("=") for p in kv.split(","))}
-            seed_distribution(kind, kw["L"], kw.get("n", 5))
+            seed_distribution(kind, kw["L"], kw.get("n", 5), kw.get("steps", 80))
         return
     if "--ablate" in sys.argv:  # python tools/regen_parity_floor.py --ablate full:L=20,seed=9 mid:L=12,seed=5
         for spec in sys.argv[sys.argv.index("--ablate") + 1:]:

@@ -748,13 +748,21 @@ __global__ __launch_bounds__(128) void ddpm_update_kernel(const float *__restric
   const float eps_c = net[(size_t)r * 256 + ch], var_c = net[(size_t)r * 256 + 100 + ch];
   const float eps_u = net[(size_t)(seq_start[s + ncand] + t) * 256 + ch];
   const float xv = x[xi];
-  const float frac = (var_c + 1) / 2;
-  // calculate_model_variance is called with (min_log, max_log) swapped (main.cpp:5998-5999)
-  const float model_log_variance = frac * sc.min_log + (1 - frac) * sc.max_log;
-  const float eps = (1 + sc.cfk) * eps_c - sc.cfk * eps_u;
-  float x0 = sc.sqrt_recip * xv - sc.sqrt_recipm1 * eps;
-  x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
-  const float mean = sc.coef1 * x0 + sc.coef2 * xv;
+  // Every f32 operation below is the reference's, one rounding each (main.cpp:5970-6030 is plain C++ built without FMA contraction; the oracle's copy is compiled with
+  // -ffp-contract=off). hipcc would contract a * b + c * d into FMAs: a last-bit difference in x_t at EVERY step that the torch-f32 yardstick of the parity floor (which
+  // shares the oracle's update) does not have, and that a chaotic 80- / 200-step loop amplifies like any other f32 difference (round 6: the 200-step loop at full depth
+  // sat at 1.44-1.58 x its f32-vs-f32 floor in BOTH arithmetic modes).
+  float mean, model_log_variance;
+  {
+#pragma clang fp contract(off)
+    const float frac = (var_c + 1) / 2;
+    // calculate_model_variance is called with (min_log, max_log) swapped (main.cpp:5998-5999)
+    model_log_variance = frac * sc.min_log + (1 - frac) * sc.max_log;
+    const float eps = (1 + sc.cfk) * eps_c - sc.cfk * eps_u;
+    float x0 = sc.sqrt_recip * xv - sc.sqrt_recipm1 * eps;
+    x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+    mean = sc.coef1 * x0 + sc.coef2 * xv;
+  }
   float outv = mean;
   if (!sc.is_last) {
     const float nz = noise ? noise[xi] : philox_normal(seed, stream0 + (uint32_t)s, step, (uint32_t)(ch * T + t));
@@ -1439,7 +1447,8 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
                                                                                  wk.vt16_lo.as<__half>(), wk.rows + 128, lay.d_start.as<int>(),
                                                                                  lay.d_len.as<int>(), w.bias_tab, wk.ATT16(), wk.att16_lo.as<__half>() + C, nq);
     } else {
-      // one K/V tile in flight at 4 workgroups per CU (162.5-163.0 us per launch) beat two tiles in flight at 3 per CU (168.2-168.9 us; round 2)
+      // one K/V tile in flight at 4 workgroups per CU (162.5-163.0 us per launch) beat two tiles in flight at 3 per CU (168.2-168.9 us; round 2). Round 6: the deeper ring
+      // does not help one utterance either (224 workgroups, at most one per CU: 20.6 us with one tile in flight, 21.1 with two — profiles/r6_small_batch.txt)
       diff_attn_kernel<2><<<nq * NHEAD * lay.ns, 256, att_lds<2>(), ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128,
                                                                                lay.d_start.as<int>(), lay.d_len.as<int>(), w.bias_tab, wk.ATT16(), nq);
     }
