@@ -204,9 +204,10 @@ int tts_autoregressive(tts_ctx *ctx, const int32_t *text_ids, int n_text, const 
                        int32_t *rows_out, float *latents_out, int32_t *steps_out);
 /* Stop schedule (benchmark / test device; random-init weights never sample a stop token, trained ones stop at different steps per candidate —
  * main.cpp:5188-5249): candidate b of the following tts_autoregressive calls samples the stop token 8193 at iteration stop_at[b] (= after stop_at[b]
- * codes) whatever its logits say; the uniforms are consumed as always. Meant to be combined with TTS_AR_MASK_STOP | TTS_AR_RETIRE: the batch then
- * becomes RAGGED in a reproducible way (decode steps with retired candidates, a latent pass / diffusion row space / vocoder batch of unequal
- * lengths). stop_at == NULL or n_candidates == 0 clears it; a call whose candidate count differs from the schedule's fails with TTS_ERR_ARG. */
+ * codes) whatever its logits say; the uniforms are consumed as always. It applies ONLY to calls that pass TTS_AR_MASK_STOP | TTS_AR_RETIRE (round 6: any other
+ * call ignores it and says so once on stderr — a forgotten schedule cannot truncate a strict run): the batch then becomes RAGGED in a reproducible way (decode steps
+ * with retired candidates, a latent pass / diffusion row space / vocoder batch of unequal lengths). stop_at == NULL or n_candidates == 0 clears it; a call whose
+ * candidate count differs from the schedule's fails with TTS_ERR_ARG before any device work. */
 int tts_ar_set_stop_schedule(tts_ctx *ctx, const int32_t *stop_at, int n_candidates);
 /* Per candidate of the last tts_autoregressive call: 1 = the sequence ends in a sampled stop token (what main.cpp:5214-5222
  * waits for), 0 = it was cut at max_steps (TTS_AR_RETIRE / TTS_AR_MASK_STOP) and padded like a finished one. */

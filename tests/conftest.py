@@ -83,6 +83,30 @@ def full_models(pkg):
     return d
 
 
+@pytest.fixture(scope="session", autouse=True)
+def oracle_bg(request):
+    """{name: Future}: the long engine-independent oracle computations of tests/test_fullsize_gpu.py (tests/oracle_jobs.py), started in worker processes at the start of
+    a GPU session; None when there is no GPU here, when GPU tests are not selected, or with TTS_NO_ORACLE_BG=1 (the tests then compute in-line)."""
+    mexpr = request.config.getoption("-m") or ""
+    if not os.path.exists("/dev/kfd") or os.environ.get("TTS_NO_ORACLE_BG") or "gpu" not in mexpr or "not gpu" in mexpr:
+        yield None
+        return
+    if not any("test_fullsize_gpu" in item.nodeid for item in request.session.items):
+        yield None
+        return
+    import multiprocessing
+    from concurrent.futures import ProcessPoolExecutor
+    import oracle_jobs
+    models = request.getfixturevalue("full_models")
+    request.getfixturevalue("oracle")  # liboracle.so is built before the workers look for it
+    threads = max(4, min(64, (os.cpu_count() or 8) // 4))
+    ex = ProcessPoolExecutor(3, mp_context=multiprocessing.get_context("spawn"), initializer=oracle_jobs._init, initargs=(threads,))
+    futs = {"bench_length": ex.submit(oracle_jobs.bench_length, models), "config5": ex.submit(oracle_jobs.config5, models),
+            "config1": ex.submit(oracle_jobs.config1, models, os.path.join(MODELS, "mol.bin"), [int(t) for t in DEFAULT_TOKENS], 40, 0)}
+    yield futs
+    ex.shutdown(wait=False, cancel_futures=True)
+
+
 @pytest.fixture(scope="session")
 def engine(pkg):
     eng = pkg.Engine(0)

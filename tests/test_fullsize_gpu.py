@@ -116,7 +116,7 @@ def test_sampling_loop_80_steps(engine, oracle, small_models, mid_models, models
         engine.set_option("attn_f32", 0)
 
 
-def test_config1_end_to_end(full_engine, oracle, full_models, voice):
+def test_config1_end_to_end(full_engine, oracle, full_models, voice, oracle_bg):
     """configs[1]: the default message, mol.bin voice, --seed 0, ONE candidate, 80 diffusion steps, full-size weights, every stage
     against the oracle with the RNG stream in lock-step (AR uniforms -> x_T -> 80 noise vectors -> vocoder noise, the reference's
     order). The stop token is masked (random weights do not produce one): 40 codes -> L = 48, T = 208."""
@@ -124,15 +124,19 @@ def test_config1_end_to_end(full_engine, oracle, full_models, voice):
     toks, S, seed = DEFAULT_TOKENS, 40, 0
     eng.seed(seed)
     codes, rows, lats, steps = eng.autoregressive(toks, voice, 1, S, mask_stop=True)
-    ar = oracle.AR(oracle.Model(full_models + "/ggml-model.bin"))
-    rng = oracle.Rng(seed)
-    rc, codes_o, steps_o, _ = ar.generate(toks, voice, 1, rng, S, mask_stop=True)
+    if oracle_bg:  # the oracle's whole chain was computed beside the earlier tests of the session (tests/oracle_jobs.py: config1)
+        o = oracle_bg["config1"].result(timeout=1800)
+    else:
+        import oracle_jobs
+        o = oracle_jobs.config1(full_models, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "models", "mol.bin"), [int(t) for t in toks], S, seed)
+    rc, codes_o, steps_o = o["rc"], o["codes_o"], o["steps_o"]
     assert rc == 0 and steps == steps_o == S
     ids_identical = bool((codes == codes_o).all())
     if not ids_identical:
         # A split must be explained by sub-tolerance logits at the first divergent step (the reference's fp16 rounding of QKV turns 1e-7
         # round-off into occasional 5e-4 jumps that can flip a multinomial draw) — and then the later stages are STILL checked, teacher-forced:
         # the engine continues on the oracle's codes (both sides have consumed 2 uniforms per step, so the RNG stream is in lock-step).
+        ar = oracle.AR(oracle.Model(full_models + "/ggml-model.bin"))
         j = int(np.argwhere(codes[0] != codes_o[0])[0][0])
         ar.start(toks, voice, 1, len(toks) + 2 + S + 1)
         eng.ar_begin(toks, voice, 1, S)
@@ -143,10 +147,11 @@ def test_config1_end_to_end(full_engine, oracle, full_models, voice):
         print("configs[1]: AR trajectories split at step %d with logits within %.1e; later stages teacher-forced on the oracle's codes" % (j - 1, rel_err(lg, lo)))
         rows = np.array([oracle.trimmed_rows(codes_o[0])], np.int32)
         lats = [eng.ar_latents(codes_o, int(rows[0]) + 1)[0, :int(rows[0])]]
+        del ar
     L = int(rows[0])
-    lat_o = ar.latents(codes_o, L + 1)[0, :L]
+    assert L == o["L"]
+    lat_o = o["lat_o"]
     e_lat = rel_err(lats[0], lat_o)
-    del ar
     # diffusion: reference noise order from the shared stream; the oracle runs on ITS latents (end-to-end comparison). Both arithmetic
     # modes of the AttentionBlock start from the same RNG state; the reference-precision run is the one carried on to the vocoder.
     state = os.path.join(os.environ.get("TMPDIR", "/tmp"), "tts_cfg1_rng_state.txt")
@@ -158,19 +163,16 @@ def test_config1_end_to_end(full_engine, oracle, full_models, voice):
         mel = eng.diffusion([lats[0]], n_steps=80)[0]
     finally:
         eng.set_option("attn_f32", 0)
-    od = oracle.Diffusion(oracle.Model(full_models + "/ggml-diffusion-model.bin"))
-    mel_o = od.sample(lat_o, n_steps=80, rng=rng)
-    del od
+    mel_o = o["mel_o"]
     dm, dm_fast = np.abs(mel - mel_o), np.abs(mel_fast - mel_o)
     au = eng.vocoder([mel])[0]
-    ov = oracle.Vocoder(oracle.Model(full_models + "/ggml-vocoder-model.bin"))
-    au_o = ov.run(mel_o, rng=rng)
+    au_o = o["au_o"]
     da = np.abs(au - au_o)
-    assert eng.rng_uniform() == rng.uniform()  # every stage consumed the stream exactly like the reference
+    assert eng.rng_uniform() == o["u_final"]  # every stage consumed the stream exactly like the reference
     # vocoder gate proper: same mel, same explicit noise on both sides (the end-to-end audio difference above also carries the
     # mel difference through a network that amplifies it; it is reported, the reference gates each stage on its own fixture)
     nz = np.random.RandomState(4).randn(64, mel_o.shape[1] + 10).astype(np.float32)
-    e_voc = rel_err(eng.vocoder([mel_o], noise=[nz])[0], ov.run(mel_o, noise=nz))
+    e_voc = rel_err(eng.vocoder([mel_o], noise=[nz])[0], o["voc_on_mel_o"])
     print("configs[1] end to end: ids %s (%d codes), latents rel %.1e, mel max abs %.2e mean %.2e in reference precision / %.2e mean %.2e in the "
           "default mode (gates %.2e / %.2e for both), vocoder on the oracle's mel rel %.2e; end-to-end audio max abs %.2e of range %.2f"
           % ("identical" if ids_identical else "teacher-forced", S, e_lat, dm.max(), dm.mean(), dm_fast.max(), dm_fast.mean(),
@@ -264,15 +266,17 @@ def test_config2_full_shape_batch_invariance(full_engine, pkg):
 
 
 @pytest.mark.skipif(bool(os.environ.get("TTS_SKIP_LONG_TESTS")), reason="TTS_SKIP_LONG_TESTS set (about 2.5 minutes of oracle time on the host)")
-def test_full_size_80_steps_at_bench_length(full_engine, oracle, full_models):
+def test_full_size_80_steps_at_bench_length(full_engine, oracle, full_models, oracle_bg):
     """The benchmark's own diffusion problem for one candidate — full-size weights, L = 200 latent rows, T = 870 mel frames, all 80 steps — against
     the oracle with the same explicit noise (160 full-size oracle forwards, about 2.5 minutes of host time; runs by default since round 3)."""
+    import oracle_jobs
     L = 200
-    od = oracle.Diffusion(oracle.Model(full_models + "/ggml-diffusion-model.bin"))
-    lat = np.random.RandomState(31).randn(L, 1024).astype(np.float32)
     T = full_engine.frames(L)
-    noise = np.random.RandomState(6).randn(81, 100 * T).astype(np.float32)
-    want = od.sample(lat, n_steps=80, noise=noise)
+    lat, noise = oracle_jobs.bench_length_inputs(full_engine.frames)
+    if oracle_bg:  # computed beside the earlier tests of the session (tests/oracle_jobs.py)
+        want = oracle_bg["bench_length"].result(timeout=1800)
+    else:
+        want = oracle.Diffusion(oracle.Model(full_models + "/ggml-diffusion-model.bin")).sample(lat, n_steps=80, noise=noise)
     try:
         for mode, what in ATTN_MODES:
             full_engine.set_option("attn_f32", mode)
@@ -284,7 +288,7 @@ def test_full_size_80_steps_at_bench_length(full_engine, oracle, full_models):
         full_engine.set_option("attn_f32", 0)
 
 
-def test_config5_shape_200_steps(full_engine, oracle, full_models, pkg):
+def test_config5_shape_200_steps(full_engine, oracle, full_models, pkg, oracle_bg):
     """configs[4] on one GPU at its real shapes: 2 distinct prompts x 16 candidates of L = 200 latent rows (T = 870), 200 diffusion steps
     (timestep_map = round(i * 3999 / 199)), full-size weights, device noise. Size-independent property at that size: a candidate of either
     prompt's batch equals the same candidate run alone (noise stream = global candidate id). Against the oracle where the oracle can follow
@@ -309,11 +313,14 @@ def test_config5_shape_200_steps(full_engine, oracle, full_models, pkg):
         finally:
             eng.set_option("rng_shard_offset", 0)
             eng.set_option("rng_shard_total", 0)
-    od = oracle.Diffusion(oracle.Model(full_models + "/ggml-diffusion-model.bin"))
-    lat = rs.randn(9, 1024).astype(np.float32)
+    import oracle_jobs
     T = eng.frames(9)
-    noise = np.random.RandomState(8).randn(steps + 1, 100 * T).astype(np.float32)
-    want = od.sample(lat, n_steps=steps, noise=noise)
+    lat, noise = oracle_jobs.config5_inputs(eng.frames, steps)
+    assert np.array_equal(lat, rs.randn(9, 1024).astype(np.float32))  # the same stream as the two batches above
+    if oracle_bg:
+        want = oracle_bg["config5"].result(timeout=1800)
+    else:
+        want = oracle.Diffusion(oracle.Model(full_models + "/ggml-diffusion-model.bin")).sample(lat, n_steps=steps, noise=noise)
     try:
         for mode, what in ATTN_MODES:
             eng.set_option("attn_f32", mode)

@@ -81,7 +81,10 @@ def test_stop_schedule_errors(engine, pkg, small_models, voice):
             engine.autoregressive(DEFAULT_TOKENS, voice, 2, 8, mask_stop=True, retire=True)
         with pytest.raises(pkg.TtsError, match="before its first code"):
             engine.set_stop_schedule([0, 4])
+        # a schedule only acts on TTS_AR_MASK_STOP | TTS_AR_RETIRE calls: a strict / masked call with a (wrong-sized) schedule still set runs untouched
+        codes, rows, _, steps = engine.autoregressive(DEFAULT_TOKENS, voice, 2, 8, mask_stop=True)
+        assert steps == 8 and (codes[:, 1:9] < 8192).all()
     finally:
         engine.set_stop_schedule(None)
-    codes, rows, _, steps = engine.autoregressive(DEFAULT_TOKENS, voice, 2, 8, mask_stop=True)
-    assert steps == 8 and (codes[:, 1:9] < 8192).all()
+    codes2, _, _, steps = engine.autoregressive(DEFAULT_TOKENS, voice, 2, 8, mask_stop=True)
+    assert steps == 8 and (codes2 == codes).all()

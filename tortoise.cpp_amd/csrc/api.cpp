@@ -356,6 +356,14 @@ static int autoregressive_impl(tts_ctx *c, const int32_t *text_ids, int n_text, 
   double t_begin = now(), t_sample = 0, t_step = 0;
   if (!codes_out || !rows_out) return fail(c, TTS_ERR_ARG, "tts_autoregressive: null output");
   if (max_steps > 500) return fail(c, TTS_ERR_LIMIT, "max_steps %d exceeds the 500 codes apply_padding accepts", max_steps);
+  // The stop schedule (tts_ar_set_stop_schedule: a bench / test device, not a reference feature) is checked BEFORE any device work, applies only to calls that pass
+  // TTS_AR_MASK_STOP | TTS_AR_RETIRE (the combination it is documented for: a strict call is never truncated by a forgotten schedule) and says so on stderr once.
+  const bool sched = !c->stop_schedule.empty() && (flags & TTS_AR_MASK_STOP) && (flags & TTS_AR_RETIRE);
+  if (!c->stop_schedule.empty() && !sched) {
+    static bool warned = false;
+    if (!warned) { fprintf(stderr, "tts_autoregressive: a stop schedule is set but the call does not pass TTS_AR_MASK_STOP | TTS_AR_RETIRE: ignored\n"); warned = true; }
+  }
+  if (sched && (int)c->stop_schedule.size() != B) return fail(c, TTS_ERR_ARG, "tts_autoregressive: the stop schedule holds %d candidates, the call %d", (int)c->stop_schedule.size(), B);
   int rc = ar_begin(c, text_ids, n_text, voice, B, max_steps);
   if (rc) return rc;
   const int V = TTS_VOCAB_MEL;
@@ -379,8 +387,6 @@ static int autoregressive_impl(tts_ctx *c, const int32_t *text_ids, int n_text, 
   // The uniforms are consumed exactly as in strict mode (two per candidate and step, candidate order), so every
   // sequence is the one strict mode would have produced.
   const bool retire = (flags & TTS_AR_RETIRE) != 0;
-  const bool sched = !c->stop_schedule.empty();
-  if (sched && (int)c->stop_schedule.size() != B) return fail(c, TTS_ERR_ARG, "tts_autoregressive: the stop schedule holds %d candidates, the call %d", (int)c->stop_schedule.size(), B);
   if ((rc = shard_check(c, B))) return rc;
   std::vector<char> done(B, 0);
   std::vector<int32_t> next; // the samples of the coming iteration when the device-top-k step already produced them
@@ -471,11 +477,13 @@ int tts_autoregressive(tts_ctx *c, const int32_t *text_ids, int n_text, const fl
 
 int tts_ar_set_stop_schedule(tts_ctx *c, const int32_t *stop_at, int n_candidates) {
   if (!c || n_candidates < 0) return TTS_ERR_ARG;
-  if (!stop_at || n_candidates == 0) { c->stop_schedule.clear(); return TTS_OK; }
-  for (int b = 0; b < n_candidates; b++)
-    if (stop_at[b] < 1) return fail(c, TTS_ERR_ARG, "tts_ar_set_stop_schedule: candidate %d would stop before its first code", b);
-  c->stop_schedule.assign(stop_at, stop_at + n_candidates);
-  return TTS_OK;
+  return guarded(c, [&]() -> int { // (vector::assign may throw: nothing crosses the C ABI)
+    if (!stop_at || n_candidates == 0) { c->stop_schedule.clear(); return TTS_OK; }
+    for (int b = 0; b < n_candidates; b++)
+      if (stop_at[b] < 1) return fail(c, TTS_ERR_ARG, "tts_ar_set_stop_schedule: candidate %d would stop before its first code", b);
+    c->stop_schedule.assign(stop_at, stop_at + n_candidates);
+    return TTS_OK;
+  });
 }
 
 int tts_ar_stop_status(tts_ctx *c, int32_t *stopped_out, int n_candidates) {

@@ -688,6 +688,8 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
     if (!(g.alpha != 0.f) || std::fabs(std::frexp(g.alpha, &e)) != 0.5f) return hipErrorInvalidValue;
   }
   if (gemm_mode_stats(g.mode) && (!g.st_out || !g.chunk_seq || g.st_stripe_ll <= 0)) return hipErrorInvalidValue;
+  // dual_b names ONE kernel: a caller whose arguments do not describe "hi | lo halves of one weight over one activation operand" gets an error, not another kernel
+  if (g.dual_b && !(gemm_mode_scaled(g.mode) && g.nseg == 2 && g.custom_w && g.A[0] == g.A[1] && g.row_off[0] == g.row_off[1])) return hipErrorInvalidValue;
   int ku = (g.ku == 2 || g.ku == 4) && (g.kseg % (64 * g.ku)) == 0 ? g.ku : 1;
   int grid;
   if (g.tiles) grid = 8 * g.tab_len;
