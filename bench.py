@@ -661,6 +661,9 @@ def main():
                      "achieved": round(achieved, 1), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4),
                      "sustained_shader_clock_MHz": (round(sus_clk) if sus_clk else None), "sustained_clock_source": sus_src,
                      "frac_of_sustained_clock_peak": (round(achieved / (MFMA_F16_DENSE_PEAK_TFLOPS * sus_clk / 2400.0), 4) if sus_clk else None),
+                     "sustained_clock_caveat": "the clock comes from a rocprofv3 PMC pass (GRBM_GUI_ACTIVE / kernel time), and a chip under counter collection clocks "
+                                               "LOWER than in the un-profiled run this line times (1.89-1.95 vs ~2.02 GHz in the guide's DVFS note): this fraction is biased high "
+                                               "by a few per cent; `frac` (against the 2.4 GHz peak) is the figure to quote",
                      "traffic": traffic, "traffic_source": traffic_src, "launches_timed": int(g_n),
                      "launch_sampling": "1 launch in %d of every shape class (hashed decimation of the class's launch counter: no period to resonate with the "
                                         "13 / 16 launches per sampling step) is bracketed by HIP events" % a.prof_stride,

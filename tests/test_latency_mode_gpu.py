@@ -93,3 +93,33 @@ def test_ragged_pair_latency_mode(lat_engine, oracle, small_models):
         print("latency mode, ragged pair cand %d: %s" % (c, check_loop(np.abs(mels[c] - want), "small", 0, "cand %d" % c, problem="test_sampling_loop_matches_oracle[cand %d]" % c)))
         alone = engine.diffusion([l], n_steps=80, noise=[noise[c]])[0]
         assert (alone == mels[c]).all(), "candidate %d differs between the pair and the single run" % c
+
+
+@pytest.mark.parametrize("lens,steps", [((12,), 80), ((20, 9), 80), ((16, 16), 37), ((9,), 200)])
+def test_hoisted_integrator_is_bit_identical(lat_engine, small_models, mid_models, pkg, lens, steps):
+    """Small batches evaluate the conditioning_timestep_integrator layers — which see only (code embedding, timestep), never x_t (main.cpp:3322-3499) — for ALL sampling
+    steps before the loop, many timesteps per batch with per-sequence scale / shift (diffusion.hip: precompute_integrator; option hoist_integrator, default 1). Same
+    arithmetic per sequence: the mel equals the one computed with the layers inside every step, bit for bit — one utterance, a ragged pair, an equal-length pair (the
+    shared unconditioned sequence), 200 steps; explicit noise and device noise. (Under option latency_mode the hoisted layers run on the batch path's GroupNorm
+    kernels while the in-step ones take their statistics from the GEMM epilogues: there the two settings agree to the loop's chaos level, like latency mode and the
+    default do, and only reproducibility is asserted.)"""
+    engine = lat_engine
+    for d in (small_models, mid_models):
+        engine.load(diffusion=d + "/ggml-diffusion-model.bin")
+        lats = [_latents(L, 40 + i) for i, L in enumerate(lens)]
+        rs = np.random.RandomState(11)
+        noise = [rs.randn(steps + 1, 100 * engine.frames(L)).astype(np.float32) for L in lens]
+        for lat_mode in (0, 1):
+            engine.set_option("latency_mode", lat_mode)
+            out = {}
+            for hoist in (0, 1):
+                engine.set_option("hoist_integrator", hoist)
+                engine.seed(5)
+                out[hoist] = (engine.diffusion(lats, n_steps=steps, noise=noise), engine.diffusion(lats, n_steps=steps, noise_mode=pkg.NOISE_DEVICE))
+            engine.set_option("hoist_integrator", 1)
+            for a, b in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
+                assert np.isfinite(a).all() and np.isfinite(b).all()
+                if lat_mode == 0:
+                    assert (a == b).all(), (lens, steps, float(np.abs(a - b).max()))
+                else:
+                    assert np.abs(a - b).max() < 5e-3, (lens, steps, float(np.abs(a - b).max()))

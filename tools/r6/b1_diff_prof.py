@@ -15,13 +15,14 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 B, L = int(sys.argv[2]) if len(sys.argv) > 2 else 1, 200
 lats = [np.random.RandomState(c).randn(L, 1024).astype(np.float32) for c in range(B)]
 FAMS = ["diff_gemm", "diff_gemm_k3r", "diff_gemm_k3", "diff_gemm_qkv", "diff_gemm_k1", "diff_gemm_k1r", "diff_gemm_misc", "diff_attn", "diff_gn_fused", "diff_gn_apply", "diff_gn_stats", "diff_update"]
-for lat in (0, 1):
+for lat, hoist in ((0, 0), (0, 1), (1, 1)):
     eng.set_option("latency_mode", lat)
+    eng.set_option("hoist_integrator", hoist)
     eng.seed(0)
     eng.diffusion(lats, n_steps=2, noise_mode=pkg.NOISE_DEVICE)
     eng.prof_reset(False)
     t0 = time.time(); eng.diffusion(lats, n_steps=80, noise_mode=pkg.NOISE_DEVICE); t1 = time.time()
-    print("latency_mode=%d B=%d: 80 steps, graph replay: %.1f ms (%.3f ms/step)" % (lat, B, 1e3 * (t1 - t0), 1e3 * (t1 - t0) / 80))
+    print("latency_mode=%d hoist_integrator=%d B=%d: 80 steps, graph replay: %.1f ms whole stage call (%.3f ms/step)" % (lat, hoist, B, 1e3 * (t1 - t0), 1e3 * (t1 - t0) / 80))
     eng.set_option("prof_eager_every", 1)
     eng.prof_reset(True)
     t0 = time.time(); eng.diffusion(lats, n_steps=steps, noise_mode=pkg.NOISE_DEVICE); t1 = time.time()

@@ -261,7 +261,7 @@ int main(int argc, char **argv) {
     std::vector<__half> baseqk((size_t)(M + 128) * 2048);
     for (int ku : {1, 2, 4})
       for (int th : {0, 2, 4, 8}) {
-        if (sh_.taps == 3 || sh_.kind == SM_PROJ_DUALB) { if (ku > 1) continue; }
+        if ((sh_.taps == 3 && ku > 1) || (sh_.kind == SM_PROJ_DUALB && ku > 2)) continue;
         GemmArgs bb = b; bb.ku = ku; bb.th = th;
         CK(hipMemsetAsync(dRef, 0xff, (size_t)M * N * 4, s)); CK(hipMemsetAsync(dQK, 0xff, (size_t)(M + 128) * 2048 * 2, s));
         CK(launch_gemm_f16(bb, s)); CK(hipStreamSynchronize(s));

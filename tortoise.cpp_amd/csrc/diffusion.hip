@@ -86,7 +86,8 @@ template <int USE_LDS>
 __global__ __launch_bounds__(256) void gn_fused_kernel(const float *__restrict__ x, const int *__restrict__ seq_start,
                                                        const int *__restrict__ seq_len, int rows_total, int ns, float eps,
                                                        const float *__restrict__ g, const float *__restrict__ b,
-                                                       const float *__restrict__ ss, int do_silu, int lut, __half *__restrict__ y) {
+                                                       const float *__restrict__ ss, int do_silu, int lut, __half *__restrict__ y,
+                                                       const int *__restrict__ seq_step, int ss_step_stride) {
   // one block = one (sequence, group of 32 channels): the [T][32] slab (128 B per row) is read from HBM once,
   // kept in LDS (USE_LDS: T*128 B <= 144 KB) and normalised from there; longer sequences re-read it.
   extern __shared__ __attribute__((aligned(16))) float slab[];
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const float *__restrict__
   const float4 gg = *(const float4 *)(g + c), bb = *(const float4 *)(b + c);
   float sc4[4] = {1.f, 1.f, 1.f, 1.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
   if (ss) {
+    if (seq_step) ss += (size_t)seq_step[s] * ss_step_stride; // this sequence's timestep (the integrator evaluated for many timesteps in one batch)
 #pragma unroll
     for (int i = 0; i < 4; i++) { sc4[i] = ss[c + i] + 1.0f; sh4[i] = ss[C + c + i]; }
   }
@@ -208,6 +210,19 @@ __global__ __launch_bounds__(256) void gather_f16_kernel(const float *__restrict
     o.y = *(unsigned *)&p1;
   }
   *(uint2 *)(y + (size_t)r * C + c) = o;
+}
+
+// f32 row gather: y[r] = x[src_row[r]] (zero where src_row[r] < 0).
+__global__ __launch_bounds__(256) void gather_f32_kernel(const float *__restrict__ x, const int *__restrict__ src_row, float *__restrict__ y) {
+  const int r = blockIdx.x, c = threadIdx.x * 4, sr = src_row[r];
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (sr >= 0) v = *(const float4 *)(x + (size_t)sr * C + c);
+  *(float4 *)(y + (size_t)r * C + c) = v;
+}
+// The current sampling step's slice of a per-step array (the hoisted integrator's code-embedding operand) -> the fixed address the step's kernels read.
+__global__ __launch_bounds__(256) void select_step_slice_kernel(const uint4 *__restrict__ all, size_t n16_per_step, const int *__restrict__ ctr, uint4 *__restrict__ dst) {
+  const uint4 *src = all + (size_t)(*ctr) * n16_per_step;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16_per_step; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
 // Multi-head attention with T5 relative-position bias (AttentionBlock, main.cpp:3232-3275).
@@ -803,6 +818,7 @@ struct Layout {
   std::vector<int> start, len;
   DevBuf d_row_seq, d_row_t, d_start, d_len, d_chunk_seq; // chunk_seq[r / 8]: owning sequence of an aligned 8-row chunk (-1: guard rows only)
   int build(tts_ctx *ctx, const std::vector<int> &lens) {
+    has_seq_step = false; ss_step_stride = 0;
     ns = (int)lens.size();
     len = lens;
     start.resize(ns);
@@ -826,6 +842,18 @@ struct Layout {
     return TTS_OK;
   }
   int max_len() const { return len.empty() ? 0 : *std::max_element(len.begin(), len.end()); }
+  // Sequences of DIFFERENT timesteps in one layout (the hoisted conditioning_timestep_integrator, round 6): seq_step[s] = index of sequence s's timestep; the GroupNorm
+  // kernels then read sequence s's scale / shift at ss + seq_step[s] * ss_step_stride. Empty = one timestep for the whole layout.
+  DevBuf d_seq_step;
+  int ss_step_stride = 0;
+  bool has_seq_step = false;
+  const int *seq_step_ptr() const { return has_seq_step ? d_seq_step.as<int>() : nullptr; }
+  int set_seq_step(tts_ctx *ctx, const std::vector<int> &step_of_seq, int stride_floats) {
+    TTS_HIP(ctx, d_seq_step.reserve(step_of_seq.size() * 4));
+    TTS_HIP(ctx, hipMemcpy(d_seq_step.p, step_of_seq.data(), step_of_seq.size() * 4, hipMemcpyHostToDevice));
+    ss_step_stride = stride_floats; has_seq_step = true;
+    return TTS_OK;
+  }
 };
 
 // Activation workspace for one layout. fp16 GEMM operands carry a 1-row zero halo on both sides (the
@@ -884,6 +912,14 @@ struct DiffState {
   bool share_integ = false;
   DevBuf ce_src, iseq_src;
   DevBuf h0; // in_layers of the first integrator ResBlock applied to the code embedding: the same at every step
+  // Hoisted integrator (round 6, small batches): the conditioning_timestep_integrator layers see only (code embedding, timestep) — never x_t (main.cpp:3322-3499) — so
+  // their output for ALL sampling steps is evaluated before the loop, many timesteps per batch (play: [timestep][sequence] sequences with per-sequence scale / shift),
+  // and a step only selects its slice of ce16_all. Same arithmetic per sequence: bit-identical to evaluating the layers inside every step.
+  bool hoisted = false;
+  Layout play;
+  Work pwk;
+  DevBuf pcode, ph0, pce, psrc, pscatter, ce16_all;
+  std::vector<int> ce_src_host; // share_integ: source row in ilay of every row of lay
   // option latency_mode (small layouts): per sampling step one statistics slot per f32 GEMM output, zeroed at the start of the step; h0's slot persists
   bool lat = false;
   DevBuf gn_stats, gn_stats_h0;
@@ -1178,7 +1214,8 @@ __global__ __launch_bounds__(NT) void gn_reg_kernel(const float *__restrict__ x,
                                                     const int *__restrict__ seq_len, int rows_total, int ns, float eps,
                                                     const float *__restrict__ g, const float *__restrict__ b,
                                                     const float *__restrict__ ss, int do_silu, int lut, __half *__restrict__ y,
-                                                    const char *__restrict__ pf0, int pf0_lines, const char *__restrict__ pf1, int pf1_lines) {
+                                                    const char *__restrict__ pf0, int pf0_lines, const char *__restrict__ pf1, int pf1_lines,
+                                                    const int *__restrict__ seq_step, int ss_step_stride) {
   constexpr int NW = NT / 64, SWEEP = NT / 8;
   __shared__ float sh[2][NW];
   __shared__ unsigned pf_sink[NW][64]; // landing zone of the weight touch below
@@ -1209,6 +1246,7 @@ __global__ __launch_bounds__(NT) void gn_reg_kernel(const float *__restrict__ x,
   const float4 gg = *(const float4 *)(g + c), bb = *(const float4 *)(b + c);
   float sc4[4] = {1.f, 1.f, 1.f, 1.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
   if (ss) {
+    if (seq_step) ss += (size_t)seq_step[s] * ss_step_stride; // this sequence's timestep (the integrator evaluated for many timesteps in one batch)
 #pragma unroll
     for (int i = 0; i < 4; i++) { sc4[i] = ss[c + i] + 1.0f; sh4[i] = ss[C + c + i]; }
   }
@@ -1289,11 +1327,11 @@ static int gn_fused(tts_ctx *ctx, const Layout &lay, const float *x, const float
   if (lay.rows > 4096) { wa_bytes = 0; wb_bytes = 0; }
   const int silu_mode = ctx->ggml_lut ? 1 : ctx->attn_f32 ? 2 : 0; // see silu_dev
 #define GN_ARGS x, lay.d_start.as<int>(), lay.d_len.as<int>(), lay.rows, lay.ns, ctx->gn_eps, g, b, ss, do_silu, silu_mode, y, \
-                (const char *)wa, (int)(wa_bytes >> 7), (const char *)wb, (int)(wb_bytes >> 7)
+                (const char *)wa, (int)(wa_bytes >> 7), (const char *)wb, (int)(wb_bytes >> 7), lay.seq_step_ptr(), lay.ss_step_stride
   if (tmax <= 14 * 64) gn_reg_kernel<512, 14><<<dim3(32, lay.ns), 512, 0, ctx->stream>>>(GN_ARGS);
   else if (tmax <= 18 * 128) gn_reg_kernel<1024, 18><<<dim3(32, lay.ns), 1024, 0, ctx->stream>>>(GN_ARGS);
   else gn_fused_kernel<0><<<dim3(32, lay.ns), 256, 0, ctx->stream>>>(x, lay.d_start.as<int>(), lay.d_len.as<int>(), lay.rows, lay.ns, ctx->gn_eps, g, b, ss,
-                                                                    do_silu, silu_mode, y); // two sweeps over global memory
+                                                                    do_silu, silu_mode, y, lay.seq_step_ptr(), lay.ss_step_stride); // two sweeps over global memory
 #undef GN_ARGS
   TTS_HIP(ctx, hipGetLastError());
   return TTS_OK;
@@ -1308,7 +1346,8 @@ static int gn_fused(tts_ctx *ctx, const Layout &lay, const float *x, const float
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, const int *__restrict__ chunk_seq, const int *__restrict__ seq_start,
                                                        const int *__restrict__ seq_len, const long long *__restrict__ st, int stripe_ll, float eps, const float *__restrict__ g,
                                                        const float *__restrict__ b, const float *__restrict__ ss, int do_silu, int lut, __half *__restrict__ y,
-                                                       const char *__restrict__ pf0, int pf0_lines, const char *__restrict__ pf1, int pf1_lines) {
+                                                       const char *__restrict__ pf0, int pf0_lines, const char *__restrict__ pf1, int pf1_lines,
+                                                       const int *__restrict__ seq_step, int ss_step_stride) {
   __shared__ float2 mr[32];
   __shared__ unsigned pf_sink[4][64];
   const int r0 = blockIdx.x * 4, s = chunk_seq[blockIdx.x >> 1], c = threadIdx.x * 4;
@@ -1345,6 +1384,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__
   const float4 gg = *(const float4 *)(g + c), bb = *(const float4 *)(b + c);
   float sc4[4] = {1.f, 1.f, 1.f, 1.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
   if (ss) {
+    if (seq_step && s >= 0) ss += (size_t)seq_step[s] * ss_step_stride;
 #pragma unroll
     for (int i = 0; i < 4; i++) { sc4[i] = ss[c + i] + 1.0f; sh4[i] = ss[C + c + i]; }
   }
@@ -1389,7 +1429,8 @@ static int gn(tts_ctx *ctx, const DiffState *st, const Layout &lay, const float 
     ProfScope ps(ctx, "diff_gn_apply");
     const int silu_mode = ctx->ggml_lut ? 1 : ctx->attn_f32 ? 2 : 0; // see silu_dev
     gn_apply_kernel<<<lay.rows / 4, 256, 0, ctx->stream>>>(x, lay.d_chunk_seq.as<int>(), lay.d_start.as<int>(), lay.d_len.as<int>(), st_x, (int)st->gn_stripe_ll, ctx->gn_eps, g, b,
-                                                            ss, do_silu, silu_mode, y, (const char *)wa, (int)(wa_bytes >> 7), (const char *)wb, (int)(wb_bytes >> 7));
+                                                            ss, do_silu, silu_mode, y, (const char *)wa, (int)(wa_bytes >> 7), (const char *)wb, (int)(wb_bytes >> 7),
+                                                            lay.seq_step_ptr(), lay.ss_step_stride);
     TTS_HIP(ctx, hipGetLastError());
   }
   return fp16_check(ctx, y, (size_t)lay.rows * C);
@@ -1688,15 +1729,20 @@ static int network_forward(tts_ctx *ctx, DiffState *st, const float *ss) {
   iw.st_x = wk.st_x = iw.st_h = wk.st_h = nullptr;
   if (st->lat) TTS_HIP(ctx, hipMemsetAsync(st->gn_stats.p, 0, (size_t)st->gn_sites_max * st->gn_slot_ll * 8, ctx->stream));
   int j = 0;
-  for (int i = 0; i < st->n_integ; i++, j++) {
-    // first block: reads the code embedding directly, its timestep-independent half (st->h0) comes from setup_batch
-    if (i == 0) CHECK(res_block(ctx, st, il, iw, ce, st->integ_res[0], ss, st->code_emb.as<float>(), st->h0.as<float>(), st->lat ? st->gn_stats_h0.as<long long>() : nullptr));
-    else CHECK(res_block(ctx, st, il, iw, ce, st->integ_res[i], ss + (size_t)j * 2 * C));
-    CHECK(attention_block(ctx, st, il, iw, ce, st->integ_attn[i]));
-  }
   __half *ce16 = st->ce16.as<__half>(), *inp16 = st->inp16.as<__half>();
-  if (st->share_integ) gather_f16_kernel<<<lay.rows, 256, 0, ctx->stream>>>(ce, st->ce_src.as<int>(), ce16);
-  else to_f16_kernel<<<lay.rows, 256, 0, ctx->stream>>>(ce, lay.d_row_seq.as<int>(), ce16);
+  if (st->hoisted) { // the integrator ran before the loop for every step (precompute_integrator): this step's slice
+    j = st->n_integ;
+    select_step_slice_kernel<<<256, 256, 0, ctx->stream>>>(st->ce16_all.as<uint4>(), (size_t)lay.rows * C / 8, st->step_ctr.as<int>(), (uint4 *)ce16);
+  } else {
+    for (int i = 0; i < st->n_integ; i++, j++) {
+      // first block: reads the code embedding directly, its timestep-independent half (st->h0) comes from setup_batch
+      if (i == 0) CHECK(res_block(ctx, st, il, iw, ce, st->integ_res[0], ss, st->code_emb.as<float>(), st->h0.as<float>(), st->lat ? st->gn_stats_h0.as<long long>() : nullptr));
+      else CHECK(res_block(ctx, st, il, iw, ce, st->integ_res[i], ss + (size_t)j * 2 * C));
+      CHECK(attention_block(ctx, st, il, iw, ce, st->integ_attn[i]));
+    }
+    if (st->share_integ) gather_f16_kernel<<<lay.rows, 256, 0, ctx->stream>>>(ce, st->ce_src.as<int>(), ce16);
+    else to_f16_kernel<<<lay.rows, 256, 0, ctx->stream>>>(ce, lay.d_row_seq.as<int>(), ce16);
+  }
   // inp_block: conv k3 100(->128) -> 1024 on x_t, output rounded to fp16 (operand of the next conv)
   GemmArgs gi = gemm_base(lay, st->xt16.as<__half>() + XTC, XTC, 3, XTC, st->inp_w, C, st->inp_bias);
   gi.mode = GEMM_OUT_F16; gi.outH = inp16; gi.ldh = C;
@@ -1724,6 +1770,66 @@ static int network_forward(tts_ctx *ctx, DiffState *st, const float *ss) {
   DBG_SUM("net", st->net.p, (size_t)lay.rows * 256 * 4);
   if (st->lat && st->gn_site > st->gn_sites_max) return fail(ctx, TTS_ERR_STATE, "latency_mode: %d statistics slots used, %d reserved", st->gn_site, st->gn_sites_max);
   return TTS_OK;
+}
+
+// The conditioning_timestep_integrator layers for EVERY sampling step, before the loop (see DiffState::hoisted). Needs setup_batch (code embedding, h0) and
+// precompute_time (ss_all) of this call. Timesteps are processed in chunks of about one benchmark batch of rows (28 672): the regime the GEMMs are tuned for, instead
+// of 22 launches per step at 1 792 rows.
+static int precompute_integrator(tts_ctx *ctx, DiffState *st, int n_steps) {
+  const Layout &lay = st->lay;
+  Layout &il = st->share_integ ? st->ilay : st->lay;
+  const int per = il.ns, nt_max = std::max(1, 28672 / il.rows);
+  const size_t ss_stride = (size_t)st->n_res() * 2 * C;
+  TTS_HIP(ctx, st->ce16_all.reserve((size_t)n_steps * lay.rows * C * 2));
+  // row of il that feeds row r of lay (-1: guard rows), and (sequence, t) of every il row
+  std::vector<int> il_of_lay(lay.rows, -1), il_seq(il.rows, -1), il_t(il.rows, 0);
+  for (int s = 0; s < il.ns; s++)
+    for (int t = 0; t < il.len[s]; t++) { il_seq[il.start[s] + t] = s; il_t[il.start[s] + t] = t; }
+  if (st->share_integ) il_of_lay = st->ce_src_host;
+  else for (int s = 0; s < lay.ns; s++) for (int t = 0; t < lay.len[s]; t++) il_of_lay[lay.start[s] + t] = lay.start[s] + t;
+  const bool lat_saved = st->lat;
+  st->lat = false; // the batch path's GroupNorm kernels (statistics reduced per sequence: per-sequence scale / shift)
+  int rc = TTS_OK;
+  for (int idx0 = 0; idx0 < n_steps && rc == TTS_OK; idx0 += nt_max) {
+    const int nt = std::min(nt_max, n_steps - idx0);
+    std::vector<int> lens, step_of_seq;
+    for (int k = 0; k < nt; k++)
+      for (int s = 0; s < per; s++) { lens.push_back(il.len[s]); step_of_seq.push_back(idx0 + k); }
+    Layout &pl = st->play;
+    if ((rc = pl.build(ctx, lens))) break;
+    if ((rc = pl.set_seq_step(ctx, step_of_seq, (int)ss_stride))) break;
+    Work &pw = st->pwk;
+    if ((rc = pw.reserve(ctx, pl.rows, pl.ns))) break;
+    pw.st_x = pw.st_h = nullptr;
+    std::vector<int> src(pl.rows, -1), scat((size_t)nt * lay.rows, -1);
+    for (int k = 0; k < nt; k++)
+      for (int s = 0; s < per; s++)
+        for (int t = 0; t < il.len[s]; t++) src[pl.start[k * per + s] + t] = il.start[s] + t;
+    for (int k = 0; k < nt; k++)
+      for (int r = 0; r < lay.rows; r++) {
+        const int ir = il_of_lay[r];
+        if (ir >= 0 && il_seq[ir] >= 0) scat[(size_t)k * lay.rows + r] = pl.start[k * per + il_seq[ir]] + il_t[ir];
+      }
+    TTS_HIP(ctx, st->psrc.reserve(src.size() * 4)); TTS_HIP(ctx, st->pscatter.reserve(scat.size() * 4));
+    TTS_HIP(ctx, hipMemcpy(st->psrc.p, src.data(), src.size() * 4, hipMemcpyHostToDevice));
+    TTS_HIP(ctx, hipMemcpy(st->pscatter.p, scat.data(), scat.size() * 4, hipMemcpyHostToDevice));
+    TTS_HIP(ctx, st->pcode.reserve((size_t)pl.rows * C * 4)); TTS_HIP(ctx, st->ph0.reserve((size_t)pl.rows * C * 4)); TTS_HIP(ctx, st->pce.reserve((size_t)pl.rows * C * 4));
+    gather_f32_kernel<<<pl.rows, 256, 0, ctx->stream>>>(st->code_emb.as<float>(), st->psrc.as<int>(), st->pcode.as<float>());
+    gather_f32_kernel<<<pl.rows, 256, 0, ctx->stream>>>(st->h0.as<float>(), st->psrc.as<int>(), st->ph0.as<float>());
+    float *ce = st->pce.as<float>();
+    const float *ssb = st->ss_all.as<float>(); // step 0's block; sequence s reads at + seq_step[s] * ss_stride
+    for (int i = 0; i < st->n_integ && rc == TTS_OK; i++) {
+      if (i == 0) rc = res_block(ctx, st, pl, pw, ce, st->integ_res[0], ssb, st->pcode.as<float>(), st->ph0.as<float>());
+      else rc = res_block(ctx, st, pl, pw, ce, st->integ_res[i], ssb + (size_t)i * 2 * C);
+      if (rc == TTS_OK) rc = attention_block(ctx, st, pl, pw, ce, st->integ_attn[i]);
+    }
+    if (rc) break;
+    gather_f16_kernel<<<nt * lay.rows, 256, 0, ctx->stream>>>(ce, st->pscatter.as<int>(), st->ce16_all.as<__half>() + (size_t)idx0 * lay.rows * C);
+    TTS_HIP(ctx, hipGetLastError());
+    TTS_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the next chunk rebuilds the layout's host-side tables
+  }
+  st->lat = lat_saved;
+  return rc;
 }
 
 // Sets up layouts/buffers for B candidates (cond + optionally uncond copies) and the code embedding.
@@ -1776,6 +1882,7 @@ static int setup_batch(tts_ctx *ctx, DiffState *st, const float *latents, const 
       for (int t = 0; t < lens[s]; t++) cs[lay.start[s] + t] = st->ilay.start[seq_map[s]] + t;
     TTS_HIP(ctx, st->ce_src.reserve((size_t)lay.rows * 4));
     TTS_HIP(ctx, hipMemcpy(st->ce_src.p, cs.data(), (size_t)lay.rows * 4, hipMemcpyHostToDevice));
+    st->ce_src_host = cs;
     TTS_HIP(ctx, st->iseq_src.reserve(st->ilay.ns * 4));
     TTS_HIP(ctx, hipMemcpy(st->iseq_src.p, isrc.data(), st->ilay.ns * 4, hipMemcpyHostToDevice));
   }
@@ -1817,6 +1924,7 @@ int diff_forward(tts_ctx *ctx, const float *latents, int L, const float *x_t, in
   if (!latents || !x_t || !out || L < 1) return fail(ctx, TTS_ERR_ARG, "tts_diffusion_forward: bad argument");
   std::vector<int> Ls{L};
   CHECK(setup_batch(ctx, st, latents, Ls, !cond_free, cond_free));
+  st->hoisted = false;
   const int T = st->lay.len[0];
   CHECK(precompute_time(ctx, st, std::vector<int>{timestep}));
   TTS_HIP(ctx, st->xbuf.reserve((size_t)100 * T * 4));
@@ -1859,6 +1967,9 @@ int diff_sample(tts_ctx *ctx, const float *latents, const int32_t *rows, int B, 
   std::vector<int> ts(n_steps);
   for (int idx = 0; idx < n_steps; idx++) ts[idx] = sched.timestep_map[n_steps - 1 - idx]; // time_embedding_{idx} (5819-5825)
   CHECK(precompute_time(ctx, st, ts));
+  // small batches: the integrator layers of all steps now, in benchmark-sized batches (option hoist_integrator, default 1; results are bit-identical either way)
+  st->hoisted = ctx->hoist_integrator != 0 && st->n_integ > 0 && lay.rows <= LAT_MAX_ROWS && (st->share_integ ? st->ilay.rows : lay.rows) <= LAT_MAX_ROWS;
+  if (st->hoisted) CHECK(precompute_integrator(ctx, st, n_steps));
   // x state [cand][100][T_c]
   std::vector<int64_t> xoff(B);
   int64_t total = 0;

@@ -442,7 +442,7 @@ __device__ __forceinline__ void gemm_vh_body(const GemmArgs &g, int m0, int n0, 
 // K segments through gemm_vh_body: 48 instead of 64 KB of DMA, 24 instead of 32 KB of fragment reads and 2 instead of 4 barriers per 64 MFMAs.
 // g.W = [N][ldw_] with the hi half at column w_off_[0] and the lo half at w_off_[1] (custom_w); g.nseg == 2, g.A[0] == g.A[1], equal row offsets.
 static constexpr int GEMM_DUALB_LDS = 49152;
-template <int MODE, int MI>
+template <int MODE, int MI, int KU = 1>
 __device__ __forceinline__ void gemm_vh_dualb_body(const GemmArgs &g, int m0, int n0, int nblk, int lane, int wave) {
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   char *smem = smem_dyn;
@@ -485,26 +485,30 @@ __device__ __forceinline__ void gemm_vh_dualb_body(const GemmArgs &g, int m0, in
   char *sa = smem, *sb0 = smem + 16384, *sb1 = smem + 32768;
   const __half *aseg = g.A[0] + (ptrdiff_t)g.row_off[0] * g.lda;
   const __half *w0 = g.W + g.w_off_[0], *w1 = g.W + g.w_off_[1];
-  for (int kt = 0; kt < ntiles; kt++) {
-    const __half *abase = aseg + (kt << 6), *b0 = w0 + (kt << 6), *b1 = w1 + (kt << 6);
+  for (int kt = 0; kt < ntiles; kt += KU) { // KU K tiles per barrier pair (see gemm_vh_body): 48 KB of LDS each
 #pragma unroll
-    for (int i = 0; i < 4; i++)
-      if (i < my_pa) __builtin_amdgcn_global_load_lds((gptr_t)(abase + aoff[i]), (lptr_t)(sa + (wave + 4 * i) * 1024), 16, 0, 0);
+    for (int u = 0; u < KU; u++) {
+      const __half *abase = aseg + ((kt + u) << 6), *b0 = w0 + ((kt + u) << 6), *b1 = w1 + ((kt + u) << 6);
 #pragma unroll
-    for (int i = 0; i < 4; i++) __builtin_amdgcn_global_load_lds((gptr_t)(b0 + boff[i]), (lptr_t)(sb0 + (wave * 4 + i) * 1024), 16, 0, 0);
+      for (int i = 0; i < 4; i++)
+        if (i < my_pa) __builtin_amdgcn_global_load_lds((gptr_t)(abase + aoff[i]), (lptr_t)(sa + u * GEMM_DUALB_LDS + (wave + 4 * i) * 1024), 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; i++) __builtin_amdgcn_global_load_lds((gptr_t)(b1 + boff[i]), (lptr_t)(sb1 + (wave * 4 + i) * 1024), 16, 0, 0);
+      for (int i = 0; i < 4; i++) __builtin_amdgcn_global_load_lds((gptr_t)(b0 + boff[i]), (lptr_t)(sb0 + u * GEMM_DUALB_LDS + (wave * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; i++) __builtin_amdgcn_global_load_lds((gptr_t)(b1 + boff[i]), (lptr_t)(sb1 + u * GEMM_DUALB_LDS + (wave * 4 + i) * 1024), 16, 0, 0);
+    }
     __syncthreads();
 #pragma unroll
-    for (int ks = 0; ks < 2; ks++) {
+    for (int ks = 0; ks < 2 * KU; ks++) {
+      const int uo = (ks >> 1) * GEMM_DUALB_LDS, kk = ks & 1;
       half8 af[MA], bf[4], bl[4];
 #pragma unroll
-      for (int i = 0; i < MI; i++) af[i] = *(const half8 *)(sa + lds_off(vh_blk(wm, i) * 16 + fr, ks * 4 + fq));
+      for (int i = 0; i < MI; i++) af[i] = *(const half8 *)(sa + uo + lds_off(vh_blk(wm, i) * 16 + fr, kk * 4 + fq));
       if (MI > 0) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) bf[i] = *(const half8 *)(sb0 + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+        for (int i = 0; i < 4; i++) bf[i] = *(const half8 *)(sb0 + uo + lds_off(wn * 64 + i * 16 + fr, kk * 4 + fq));
 #pragma unroll
-        for (int i = 0; i < 4; i++) bl[i] = *(const half8 *)(sb1 + lds_off(wn * 64 + i * 16 + fr, ks * 4 + fq));
+        for (int i = 0; i < 4; i++) bl[i] = *(const half8 *)(sb1 + uo + lds_off(wn * 64 + i * 16 + fr, kk * 4 + fq));
       }
 #pragma unroll
       for (int i = 0; i < MI; i++)
@@ -557,17 +561,17 @@ static __global__ __launch_bounds__(256, WGS) void gemm_f16_vh_kernel(GemmArgs g
   else gemm_vh_body<MODE, 0, KU>(g, m0, n0, nblk, lane, wave); // 1-block tile: this wave only moves operands
 }
 
-template <int MODE>
-static __global__ __launch_bounds__(256, 3) void gemm_f16_vh_dualb_kernel(GemmArgs g) {
+template <int MODE, int KU = 1>
+static __global__ __launch_bounds__(256, KU == 1 ? 3 : 1) void gemm_f16_vh_dualb_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int m0, n0, nblk;
   if (!gemm_vh_tile(g, m0, n0, nblk)) return;
   const int my_mi = (nblk - (wave >> 1) + 1) >> 1;
-  if (my_mi == 4) gemm_vh_dualb_body<MODE, 4>(g, m0, n0, nblk, lane, wave);
-  else if (my_mi == 3) gemm_vh_dualb_body<MODE, 3>(g, m0, n0, nblk, lane, wave);
-  else if (my_mi == 2) gemm_vh_dualb_body<MODE, 2>(g, m0, n0, nblk, lane, wave);
-  else if (my_mi == 1) gemm_vh_dualb_body<MODE, 1>(g, m0, n0, nblk, lane, wave);
-  else gemm_vh_dualb_body<MODE, 0>(g, m0, n0, nblk, lane, wave);
+  if (my_mi == 4) gemm_vh_dualb_body<MODE, 4, KU>(g, m0, n0, nblk, lane, wave);
+  else if (my_mi == 3) gemm_vh_dualb_body<MODE, 3, KU>(g, m0, n0, nblk, lane, wave);
+  else if (my_mi == 2) gemm_vh_dualb_body<MODE, 2, KU>(g, m0, n0, nblk, lane, wave);
+  else if (my_mi == 1) gemm_vh_dualb_body<MODE, 1, KU>(g, m0, n0, nblk, lane, wave);
+  else gemm_vh_dualb_body<MODE, 0, KU>(g, m0, n0, nblk, lane, wave);
 }
 
 // k = 3 convolution as ONE GEMM with a shared activation slab. The three taps are three row-shifted GEMM
@@ -713,7 +717,7 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
     // One utterance (M = 1 792 rows, N = 1 024: 224 tiles of 64 rows = at most one workgroup per CU): four K tiles per barrier pair at 64-row tiles — a lone
     // workgroup pays its DMA round trip and two barriers per 256 of K instead of per 64 (profiles/r6_small_gemm.txt: k = 1 12.6 -> 11.6 us warm, 22.8 -> 17.9 us
     // with cold weights; the K = 2 048 integrating conv 25.7 / 36.2 -> 20.3 / 27.8). Same products in the same order: bit-identical to every other tiling.
-    if (g.th <= 0 && g.ku == 0 && NT <= 8 && tiles_at(4) <= 256 && (g.kseg % 256) == 0 && !gemm_is_conv3(g) && !g.dual_b) { th = 4; ku = 4; }
+    if (g.th <= 0 && g.ku == 0 && NT <= 8 && tiles_at(4) <= 256 && (g.kseg % 256) == 0 && !gemm_is_conv3(g)) { th = 4; ku = g.dual_b ? 2 : 4; }
     gg.th = th;
     int mt_max = 0;
     for (int x = 0; x < 8; x++) {
@@ -734,8 +738,18 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
     else if (g.mode == GEMM_OUT_F32_STATS) gemm_f16_conv3_vh_kernel<GEMM_OUT_F32_STATS><<<grid, 256, CONV3_VH_LDS, s>>>(gg);
     else gemm_f16_conv3_vh_kernel<GEMM_OUT_F16><<<grid, 256, CONV3_VH_LDS, s>>>(gg);
   } else if (g.dual_b && gemm_mode_scaled(g.mode) && g.nseg == 2 && g.custom_w && g.A[0] == g.A[1] && g.row_off[0] == g.row_off[1]) {
-    if (g.mode == GEMM_OUT_F32_SCALED) gemm_f16_vh_dualb_kernel<GEMM_OUT_F32_SCALED><<<grid, 256, GEMM_DUALB_LDS, s>>>(gg);
-    else gemm_f16_vh_dualb_kernel<GEMM_OUT_F32_SCALED_STATS><<<grid, 256, GEMM_DUALB_LDS, s>>>(gg);
+    // ku: 2 or 3 K tiles per barrier pair for a grid of at most one workgroup per CU (96 / 144 KB of LDS)
+#define TTS_DUALB_LAUNCH(MODE_)                                                                                                                     \
+  do {                                                                                                                                              \
+    if (ku == 2) {                                                                                                                                  \
+      static bool a2 = false;                                                                                                                       \
+      if (!a2) { (void)hipFuncSetAttribute((const void *)gemm_f16_vh_dualb_kernel<MODE_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * GEMM_DUALB_LDS); a2 = true; } \
+      gemm_f16_vh_dualb_kernel<MODE_, 2><<<grid, 256, 2 * GEMM_DUALB_LDS, s>>>(gg);                                                                  \
+    } else gemm_f16_vh_dualb_kernel<MODE_, 1><<<grid, 256, GEMM_DUALB_LDS, s>>>(gg);                                                                \
+  } while (0)
+    if (g.mode == GEMM_OUT_F32_SCALED) TTS_DUALB_LAUNCH(GEMM_OUT_F32_SCALED);
+    else TTS_DUALB_LAUNCH(GEMM_OUT_F32_SCALED_STATS);
+#undef TTS_DUALB_LAUNCH
   } else {
     // KU > 1: 64 / 128 KB of LDS -> 2 / 1 workgroups per CU (the occupancy bound of the launch is a compile-time promise: WGS)
 #define TTS_VH_LAUNCH(MODE_)                                                                                                                      \
