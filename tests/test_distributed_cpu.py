@@ -348,3 +348,18 @@ def test_bench_eight_ranks_gloo_dry_engine():
         assert [r["rank"] for r in out["per_rank"]] == list(range(8)) and all(r["ms_per_step"] > 0 for r in out["per_rank"])
         assert max(r["ms_per_step"] for r in out["per_rank"]) == pytest.approx(out["ms_per_step"], rel=1e-3, abs=0.02)
         assert all(r["numa_node"] == -1 and r["pinned_cpus"] == 0 for r in out["per_rank"])  # host-only contexts: nothing to pin to
+
+
+def test_numa_placement_api_on_a_host_only_context(pkg):
+    """tts_device_numa_node / tts_pin_to_device_numa_node (round 6: each rank of a multi-GPU run keeps its sampler threads on the CPUs next to its GPU): a host-only context has
+    no device — node -1, empty CPU list, nothing pinned, the process's affinity untouched."""
+    eng = pkg.Engine.__new__(pkg.Engine)
+    eng.L = pkg.lib()
+    eng.h = eng.L.tts_create(-1)
+    try:
+        before = os.sched_getaffinity(0)
+        assert eng.numa_node() == (-1, "")
+        assert eng.pin_to_numa_node() == 0
+        assert os.sched_getaffinity(0) == before
+    finally:
+        eng.close()

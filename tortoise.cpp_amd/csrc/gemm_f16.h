@@ -717,7 +717,12 @@ static inline hipError_t launch_gemm_f16(const GemmArgs &g, hipStream_t s) {
     // One utterance (M = 1 792 rows, N = 1 024: 224 tiles of 64 rows = at most one workgroup per CU): four K tiles per barrier pair at 64-row tiles — a lone
     // workgroup pays its DMA round trip and two barriers per 256 of K instead of per 64 (profiles/r6_small_gemm.txt: k = 1 12.6 -> 11.6 us warm, 22.8 -> 17.9 us
     // with cold weights; the K = 2 048 integrating conv 25.7 / 36.2 -> 20.3 / 27.8). Same products in the same order: bit-identical to every other tiling.
-    if (g.th <= 0 && g.ku == 0 && NT <= 8 && tiles_at(4) <= 256 && (g.kseg % 256) == 0 && !gemm_is_conv3(g)) { th = 4; ku = g.dual_b ? 2 : 4; }
+    // (the split-weight proj_out, 48 KB per K tile: two per barrier pair, 21.5 -> 19.1 us warm / 28.3 -> 25.6 cold; the k = 3 kernel has its own pipeline and only takes
+    // the 64-row tiles: 27.3 -> 25.5 / 35.6 -> 32.2)
+    if (g.th <= 0 && g.ku == 0 && NT <= 8 && tiles_at(4) <= 256 && (g.kseg % 256) == 0) {
+      th = 4;
+      if (!gemm_is_conv3(g)) ku = g.dual_b ? 2 : 4;
+    }
     gg.th = th;
     int mt_max = 0;
     for (int x = 0; x < 8; x++) {
