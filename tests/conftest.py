@@ -14,8 +14,20 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 MODELS = os.path.join(ROOT, "models")
 
 
+def _oracle_bg_wanted(config):
+    mexpr = config.getoption("-m") or ""
+    return os.path.exists("/dev/kfd") and not os.environ.get("TTS_NO_ORACLE_BG") and "gpu" in mexpr and "not gpu" not in mexpr
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if _oracle_bg_wanted(config):
+        # The long oracle loops of tests/test_fullsize_gpu.py run in three worker processes beside the GPU tests (oracle_bg below). The host's cores are split so that the
+        # OpenMP teams never oversubscribe them (a first version let every team take all cores: the spinning teams slowed the foreground oracle calls 20 x): 3/8 of the
+        # cores for this process, 5/32 for each worker, passive waiting everywhere. Must be set before liboracle.so (libgomp) is loaded.
+        cores = os.cpu_count() or 8
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(4, cores * 3 // 8)))
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 
 
 @pytest.fixture(scope="session")
@@ -87,8 +99,7 @@ def full_models(pkg):
 def oracle_bg(request):
     """{name: Future}: the long engine-independent oracle computations of tests/test_fullsize_gpu.py (tests/oracle_jobs.py), started in worker processes at the start of
     a GPU session; None when there is no GPU here, when GPU tests are not selected, or with TTS_NO_ORACLE_BG=1 (the tests then compute in-line)."""
-    mexpr = request.config.getoption("-m") or ""
-    if not os.path.exists("/dev/kfd") or os.environ.get("TTS_NO_ORACLE_BG") or "gpu" not in mexpr or "not gpu" in mexpr:
+    if not _oracle_bg_wanted(request.config):
         yield None
         return
     if not any("test_fullsize_gpu" in item.nodeid for item in request.session.items):
@@ -99,7 +110,7 @@ def oracle_bg(request):
     import oracle_jobs
     models = request.getfixturevalue("full_models")
     request.getfixturevalue("oracle")  # liboracle.so is built before the workers look for it
-    threads = max(4, min(64, (os.cpu_count() or 8) // 4))
+    threads = max(2, (os.cpu_count() or 8) * 5 // 32)
     ex = ProcessPoolExecutor(3, mp_context=multiprocessing.get_context("spawn"), initializer=oracle_jobs._init, initargs=(threads,))
     futs = {"bench_length": ex.submit(oracle_jobs.bench_length, models), "config5": ex.submit(oracle_jobs.config5, models),
             "config1": ex.submit(oracle_jobs.config1, models, os.path.join(MODELS, "mol.bin"), [int(t) for t in DEFAULT_TOKENS], 40, 0)}

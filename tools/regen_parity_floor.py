@@ -185,7 +185,7 @@ def finish_mean_gate(f):
 def seed_distribution(kind, L, n_seeds, steps=80):
     """the torch-f32-vs-oracle distance of ONE problem size under n different (latents, noise) seeds — the spread of the statistic the mean
     gate is built on. Recorded under rec[kind]["seed_distribution"]; conftest.loop_gate_mean uses mu + 3 sigma of the per-seed means as the class's floor."""
-    path = ensure_models(kind)
+    path = ensure_trained() if kind == "trained" else ensure_models(kind)
     rec = json.load(open(FLOOR_JSON))
     key = "seed_distribution" if steps == 80 else "seed_distribution_%d" % steps
     dist = rec[kind].setdefault(key, {"L": L, "steps": steps, "rows": []})

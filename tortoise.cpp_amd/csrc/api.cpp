@@ -171,7 +171,7 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
   else if (k == "lc_attn_f32") c->lc_attn_f32 = value != 0;
   else if (k == "latency_mode") c->latency_mode = value != 0;
   else if (k == "fp16_check") c->fp16_check = value != 0;
-  else if (k == "hoist_integrator") c->hoist_integrator = value != 0;
+  else if (k == "hoist_integrator") c->hoist_integrator = value < 0 ? 0 : (int)value; // 0 off, 1 on for small layouts, n > 1: on for layouts of at most n packed rows (A/B)
   else if (k == "attn_f32_drop") c->attn_f32_drop = (int)value & 7;
   else if (k == "ar_weights") {
     if (value != 0 && value != 1 && value != 2) return fail(c, TTS_ERR_ARG, "ar_weights: 0 (f32), 1 (fp16) or 2 (fp8 e4m3)");

@@ -25,6 +25,7 @@ namespace tts {
 
 static constexpr int C = 1024, NHEAD = 16, XTC = 128 /* x_t channels padded 100 -> 128 */;
 static constexpr int LAT_MAX_ROWS = 4096; // option latency_mode applies to packed layouts of at most this many rows (two utterances, both guidance branches)
+static constexpr int HOIST_MAX_ROWS = 8192; // option hoist_integrator: layouts of at most this many rows (four utterances) evaluate the integrator layers before the loop
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -1968,7 +1969,7 @@ int diff_sample(tts_ctx *ctx, const float *latents, const int32_t *rows, int B, 
   for (int idx = 0; idx < n_steps; idx++) ts[idx] = sched.timestep_map[n_steps - 1 - idx]; // time_embedding_{idx} (5819-5825)
   CHECK(precompute_time(ctx, st, ts));
   // small batches: the integrator layers of all steps now, in benchmark-sized batches (option hoist_integrator, default 1; results are bit-identical either way)
-  st->hoisted = ctx->hoist_integrator != 0 && st->n_integ > 0 && lay.rows <= LAT_MAX_ROWS && (st->share_integ ? st->ilay.rows : lay.rows) <= LAT_MAX_ROWS;
+  st->hoisted = ctx->hoist_integrator != 0 && st->n_integ > 0 && lay.rows <= (ctx->hoist_integrator > 1 ? ctx->hoist_integrator : HOIST_MAX_ROWS);
   if (st->hoisted) CHECK(precompute_integrator(ctx, st, n_steps));
   // x state [cand][100][T_c]
   std::vector<int64_t> xoff(B);
