@@ -592,7 +592,7 @@ def main():
     # HBM bytes per GEMM launch from the committed PMC profile (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, calibration in the
     # file's note); null when the profile is absent. bench.py does not run rocprofv3 itself.
     traffic, traffic_src = None, None
-    for prof_name in ("r5_pmc_hbm_traffic.json", "r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):
+    for prof_name in ("r6_pmc_hbm_traffic.json", "r5_pmc_hbm_traffic.json", "r4_pmc_hbm_traffic.json", "r3_pmc_hbm_traffic.json", "r2_pmc_hbm_traffic.json", "r1_pmc_hbm_traffic.json"):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))["kernels"]
             gk = [v for k, v in prof.items() if "gemm_f16" in k]
@@ -604,7 +604,7 @@ def main():
     # second denominator: the fp16 MFMA peak at the shader clock the chip actually sustains under these kernels (PMC pass: GRBM_GUI_ACTIVE
     # over the kernel's duration; 1.95-2.2 GHz under MFMA load against the 2.4 GHz the 2.5 PF figure assumes), launch-weighted over the GEMM kernels
     sus_clk, sus_src = None, None
-    for prof_name in ("r5_pmc_mfma_util.json", "r4_pmc_mfma_util.json"):
+    for prof_name in ("r6_pmc_mfma_util.json", "r5_pmc_mfma_util.json", "r4_pmc_mfma_util.json"):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", prof_name)))["kernels"]
             gk = [v for k, v in prof.items() if "gemm_f16" in k and v.get("dispatches", 0) >= 20]
@@ -614,7 +614,7 @@ def main():
         except Exception:
             pass
     dec_traffic, dec_traffic_src = None, None  # L2-miss bytes fetched per decode step (PMC FETCH_SIZE pass over the decode launches, committed profile)
-    for prof_name, what in (("r5_pmc_decode_traffic.json", "round-5 pass"), ("r4_pmc_decode_traffic.json", "round-4 kernels"), ("r2_pmc_decode_traffic.json", "round-2 pass: the same slabs are streamed")):
+    for prof_name, what in (("r6_pmc_decode_traffic.json", "round-6 pass"), ("r5_pmc_decode_traffic.json", "round-5 pass"), ("r4_pmc_decode_traffic.json", "round-4 kernels"), ("r2_pmc_decode_traffic.json", "round-2 pass: the same slabs are streamed")):
         try:
             dec_traffic = int(json.load(open(os.path.join(ROOT, "profiles", prof_name)))["fetch_bytes_per_step"])
             dec_traffic_src = "profiles/%s (%s)" % (prof_name, what)
