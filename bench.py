@@ -200,6 +200,7 @@ def main():
     ap.add_argument("--no-ab", action="store_true", help="skip the extra pass that measures the other share_uncond setting")
     ap.add_argument("--latency-mode", action="store_true", help="option latency_mode for the headline pass too (it only acts on diffusion batches of <= 4096 packed rows: "
                     "--candidates 1 or 2); the single-utterance A/B below always measures both settings")
+    ap.add_argument("--engine-option", action="append", default=[], metavar="KEY=VALUE", help="tts_set_option on every rank's engine before the run (A/B of an option, e.g. hoist_integrator=0)")
     ap.add_argument("--no-diff-graph", action="store_true", help="A/B: launch every diffusion step eagerly instead of replaying the captured step graph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU plumbing test with --dry-engine)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (and run every collective of the N > 1 path) even for ONE rank: "
@@ -303,6 +304,9 @@ def main():
         eng.set_option("diff_graph", 0)
     if a.latency_mode and not a.dry_engine:
         eng.set_option("latency_mode", 1)
+    for kv in ([] if a.dry_engine else a.engine_option):
+        k_, v_ = kv.split("=", 1)
+        eng.set_option(k_, float(v_))
     if cand_total:
         eng.set_option("rng_shard_offset", cand0)
         eng.set_option("rng_shard_total", cand_total)
