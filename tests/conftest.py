@@ -22,9 +22,9 @@ def _oracle_bg_wanted(config):
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     if _oracle_bg_wanted(config):
-        # The long oracle loops of tests/test_fullsize_gpu.py run in three worker processes beside the GPU tests (oracle_bg below). The host's cores are split so that the
+        # The long oracle loops of tests/test_fullsize_gpu.py run in four worker processes beside the GPU tests (oracle_bg below). The host's cores are split so that the
         # OpenMP teams never oversubscribe them (a first version let every team take all cores: the spinning teams slowed the foreground oracle calls 20 x): 3/8 of the
-        # cores for this process, 5/32 for each worker, passive waiting everywhere. Must be set before liboracle.so (libgomp) is loaded.
+        # cores for this process, 1/8 for each of the four workers, passive waiting everywhere. Must be set before liboracle.so (libgomp) is loaded.
         cores = os.cpu_count() or 8
         os.environ.setdefault("OMP_NUM_THREADS", str(max(4, cores * 3 // 8)))
         os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
@@ -110,12 +110,42 @@ def oracle_bg(request):
     import oracle_jobs
     models = request.getfixturevalue("full_models")
     request.getfixturevalue("oracle")  # liboracle.so is built before the workers look for it
-    threads = max(2, (os.cpu_count() or 8) * 5 // 32)
-    ex = ProcessPoolExecutor(3, mp_context=multiprocessing.get_context("spawn"), initializer=oracle_jobs._init, initargs=(threads,))
-    futs = {"bench_length": ex.submit(oracle_jobs.bench_length, models), "config5": ex.submit(oracle_jobs.config5, models),
-            "config1": ex.submit(oracle_jobs.config1, models, os.path.join(MODELS, "mol.bin"), [int(t) for t in DEFAULT_TOKENS], 40, 0)}
+    small = request.getfixturevalue("small_models")
+    threads = max(2, (os.cpu_count() or 8) // 8)
+    ex = ProcessPoolExecutor(4, mp_context=multiprocessing.get_context("spawn"), initializer=oracle_jobs._init, initargs=(threads,))
+    # four workers: the longest job and the three small-weight loops (tests/test_diffusion_gpu.py asks for them a minute or two into the session) start at once, the
+    # other two full-size jobs (wanted after ~4 minutes) follow on the workers the small ones free
+    futs = {"bench_length": ex.submit(oracle_jobs.bench_length, models)}
+    futs.update({"small_pair0": ex.submit(oracle_jobs.small_pair, small, 0), "small_pair1": ex.submit(oracle_jobs.small_pair, small, 1),
+                 "small_200": ex.submit(oracle_jobs.small_200, small)})
+    futs.update({"loop80:" + d: ex.submit(oracle_jobs.loop80, d) for d in (request.getfixturevalue("mid_models"), small)})
+    futs.update({"config5": ex.submit(oracle_jobs.config5, models),
+                 "config1": ex.submit(oracle_jobs.config1, models, os.path.join(MODELS, "mol.bin"), [int(t) for t in DEFAULT_TOKENS], 40, 0)})
     yield futs
     ex.shutdown(wait=False, cancel_futures=True)
+
+
+@pytest.fixture(scope="session")
+def oracle_sample(oracle, oracle_bg):
+    """run(model_dir, latents, noise, steps, bg=None) -> the oracle's mel of one sampling loop with explicit noise, computed once per session: several GPU tests hold
+    different engine settings (arithmetic modes, latency mode, the ablation ladder) against the oracle on the SAME problem. `bg` names the background job
+    (tests/oracle_jobs.py) that computes this very problem when the pool is on."""
+    import zlib
+    memo, models = {}, {}
+
+    def run(model_dir, lat, noise, steps, bg=None):
+        key = (model_dir, steps, zlib.crc32(np.ascontiguousarray(lat).tobytes()), zlib.crc32(np.ascontiguousarray(noise).tobytes()))
+        if key not in memo:
+            if bg is None and steps == 80 and lat.shape[0] == 12:
+                bg = "loop80:" + model_dir
+            if oracle_bg is not None and bg in oracle_bg:
+                memo[key] = oracle_bg[bg].result()
+            else:
+                if model_dir not in models:
+                    models[model_dir] = oracle.Diffusion(oracle.Model(model_dir + "/ggml-diffusion-model.bin"))
+                memo[key] = models[model_dir].sample(lat, n_steps=steps, noise=noise)
+        return memo[key]
+    return run
 
 
 @pytest.fixture(scope="session")

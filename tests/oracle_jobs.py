@@ -1,5 +1,5 @@
-"""TEST INFRASTRUCTURE: the three long oracle computations of tests/test_fullsize_gpu.py whose inputs do not depend on the engine (the full-depth 80-step loop at the
-benchmark's length: 160 full-size oracle forwards at T = 870; the 200-step loop of configs[4]; the oracle's own end-to-end chain of configs[1]). tests/conftest.py
+"""TEST INFRASTRUCTURE: the long oracle computations of the GPU tests whose inputs do not depend on the engine (the full-depth 80-step loop at the
+benchmark's length: 160 full-size oracle forwards at T = 870; the 200-step loop of configs[4]; the oracle's own end-to-end chain of configs[1]; the 80-step ragged pair and the 200-step loop on the small weights). tests/conftest.py
 (oracle_bg) starts them in worker processes when a GPU session begins, so that they run on the host's idle cores beside the GPU tests instead of in front of them
 (round 6: 790 s -> see profiles/r6_gpu_suite.txt). Each function restates exactly the inputs of the test that uses it; the tests fall back to computing in-line when the
 background pool is off (TTS_NO_ORACLE_BG=1)."""
@@ -61,6 +61,44 @@ def config5(models):
     O = _oracle()
     od = O.Diffusion(O.Model(models + "/ggml-diffusion-model.bin"))
     lat, noise = config5_inputs(od.T_of)
+    return od.sample(lat, n_steps=200, noise=noise)
+
+
+def small_pair_inputs(frames_of):
+    """tests/test_diffusion_gpu.py::test_sampling_loop_matches_oracle and tests/test_latency_mode_gpu.py::test_ragged_pair_latency_mode: two candidates of different length"""
+    lats = [np.random.RandomState(s).randn(L, 1024).astype(np.float32) for L, s in ((20, 1), (9, 2))]
+    rs = np.random.RandomState(3)
+    return lats, [rs.randn(81, 100 * frames_of(len(l))).astype(np.float32) for l in lats]
+
+
+def small_200_inputs(frames_of):
+    """tests/test_diffusion_gpu.py::test_sampling_loop_200_steps_config5"""
+    return np.random.RandomState(3).randn(9, 1024).astype(np.float32), np.random.RandomState(8).randn(201, 100 * frames_of(9)).astype(np.float32)
+
+
+def loop80_inputs(frames_of, L=12):
+    """tests/test_fullsize_gpu.py::test_sampling_loop_80_steps, the latency-mode loop and the ablation ladder of tests/test_diffusion_gpu.py: one problem, small and mid weights"""
+    return np.random.RandomState(L).randn(L, 1024).astype(np.float32), np.random.RandomState(5).randn(81, 100 * frames_of(L)).astype(np.float32)
+
+
+def loop80(models):
+    O = _oracle()
+    od = O.Diffusion(O.Model(models + "/ggml-diffusion-model.bin"))
+    lat, noise = loop80_inputs(od.T_of)
+    return od.sample(lat, n_steps=80, noise=noise)
+
+
+def small_pair(models, c):
+    O = _oracle()
+    od = O.Diffusion(O.Model(models + "/ggml-diffusion-model.bin"))
+    lats, noise = small_pair_inputs(od.T_of)
+    return od.sample(lats[c], n_steps=80, noise=noise[c])
+
+
+def small_200(models):
+    O = _oracle()
+    od = O.Diffusion(O.Model(models + "/ggml-diffusion-model.bin"))
+    lat, noise = small_200_inputs(od.T_of)
     return od.sample(lat, n_steps=200, noise=noise)
 
 

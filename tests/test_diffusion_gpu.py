@@ -72,19 +72,17 @@ def test_numerics_switches(engine, oracle, small_models, gn_eps, lut):
         engine.set_option("ggml_lut", 0)
 
 
-def test_sampling_loop_matches_oracle(engine, oracle, small_models):
+def test_sampling_loop_matches_oracle(engine, oracle, small_models, oracle_sample):
     """diffusion(): the full 80-step schedule, 2 candidates of different length in one batch (ragged layout), explicit noise —
     gates: conftest.loop_gate / loop_gate_mean (the distance two correct f32 evaluations keep, both arithmetic modes; the reference's own gate is max abs
     0.01, main.cpp:6223). (Coarse schedules are a worse test, not a faster one: with 4-6
     respaced steps the first update multiplies the eps error by up to 153 before the +-1 clamp and single bins land 5e-2 apart on two
     correct implementations; over 80 steps the same two implementations agree to ~2e-3.)"""
     engine.load(diffusion=small_models + "/ggml-diffusion-model.bin")
-    od = oracle.Diffusion(oracle.Model(small_models + "/ggml-diffusion-model.bin"))
+    import oracle_jobs
     n_steps = 80
-    lats = [_latents(20, 1), _latents(9, 2)]
-    rs = np.random.RandomState(3)
-    noise = [rs.randn(n_steps + 1, 100 * engine.frames(len(l))).astype(np.float32) for l in lats]
-    wants = [od.sample(l, n_steps=n_steps, noise=noise[c]) for c, l in enumerate(lats)]
+    lats, noise = oracle_jobs.small_pair_inputs(engine.frames)
+    wants = [oracle_sample(small_models, l, noise[c], n_steps, bg="small_pair%d" % c) for c, l in enumerate(lats)]
     try:
         for mode, what in ATTN_MODES:
             engine.set_option("attn_f32", mode)
@@ -97,15 +95,14 @@ def test_sampling_loop_matches_oracle(engine, oracle, small_models):
         engine.set_option("attn_f32", 0)
 
 
-def test_sampling_loop_200_steps_config5(engine, oracle, small_models):
+def test_sampling_loop_200_steps_config5(engine, oracle, small_models, oracle_sample):
     """configs[4] runs 200 diffusion steps (timestep_map = round(i * 3999 / 199), the generalisation the reference hard-codes away for 80): the
     device loop over that schedule against the oracle's, same explicit noise (201 vectors), gate conftest.loop_gate."""
     engine.load(diffusion=small_models + "/ggml-diffusion-model.bin")
-    od = oracle.Diffusion(oracle.Model(small_models + "/ggml-diffusion-model.bin"))
-    lat = _latents(9, 3)
+    import oracle_jobs
+    lat, noise = oracle_jobs.small_200_inputs(engine.frames)
     T = engine.frames(9)
-    noise = np.random.RandomState(8).randn(201, 100 * T).astype(np.float32)
-    want = od.sample(lat, n_steps=200, noise=noise)
+    want = oracle_sample(small_models, lat, noise, 200, bg="small_200")
     try:
         for mode, what in ATTN_MODES:
             engine.set_option("attn_f32", mode)
@@ -117,16 +114,15 @@ def test_sampling_loop_200_steps_config5(engine, oracle, small_models):
         engine.set_option("attn_f32", 0)
 
 
-def test_what_the_default_arithmetic_relies_on(engine, oracle, mid_models):
+def test_what_the_default_arithmetic_relies_on(engine, oracle, mid_models, oracle_sample):
     """The round-5 finding, on the engine itself (mid depth, T = 52, 80 steps, same explicit noise): the two roundings that are the SAME perturbation at every step — the
     proj_out weight (option attn_proj_f16) and anything inside the once-per-utterance latent conditioner (option lc_attn_f32) — each move the mean distance from the oracle,
     the default (neither) sits with the reference-precision mode. CPU emulation of the same ladder: tests/golden/parity_floor.json "ablation"."""
     engine.load(diffusion=mid_models + "/ggml-diffusion-model.bin")
-    od = oracle.Diffusion(oracle.Model(mid_models + "/ggml-diffusion-model.bin"))
     L = 12
     lat = np.random.RandomState(L).randn(L, 1024).astype(np.float32)
     noise = np.random.RandomState(5).randn(81, 100 * engine.frames(L)).astype(np.float32)
-    want = od.sample(lat, n_steps=80, noise=noise)
+    want = oracle_sample(mid_models, lat, noise, 80)  # the problem of tests/test_fullsize_gpu.py::test_sampling_loop_80_steps[mid]
     modes = {"default": (0, 0, 1), "fp16 conditioner": (0, 0, 0), "fp16 proj_out weight": (0, 1, 1), "all fp16 (rounds 1-4)": (0, 1, 0), "attn_f32": (1, 0, 1)}
     mean = {}
     try:

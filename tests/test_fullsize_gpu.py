@@ -95,16 +95,15 @@ def test_vocoder_full(full_engine, oracle, full_models, T):
 
 
 @pytest.mark.parametrize("models,L", [("small", 12), ("mid", 12)])
-def test_sampling_loop_80_steps(engine, oracle, small_models, mid_models, models, L):
+def test_sampling_loop_80_steps(engine, oracle, small_models, mid_models, models, L, oracle_sample):
     """tts_diffusion over the full 80-step schedule against the oracle's diffusion() with the same explicit noise; gate conftest.loop_gate
     (the reference's own: max abs 0.01 on the mel, main.cpp:6223); mean reported."""
     d = small_models if models == "small" else mid_models
     engine.load(diffusion=d + "/ggml-diffusion-model.bin")
-    od = oracle.Diffusion(oracle.Model(d + "/ggml-diffusion-model.bin"))
     lat = np.random.RandomState(L).randn(L, 1024).astype(np.float32)
     T = engine.frames(L)
     noise = np.random.RandomState(5).randn(81, 100 * T).astype(np.float32)
-    want = od.sample(lat, n_steps=80, noise=noise)
+    want = oracle_sample(d, lat, noise, 80)
     try:
         for mode, what in ATTN_MODES:
             engine.set_option("attn_f32", mode)

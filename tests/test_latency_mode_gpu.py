@@ -54,16 +54,15 @@ def test_forward_latency_mode(lat_engine, oracle, small_models, mid_models, mode
 
 
 @pytest.mark.parametrize("kind", ["small", "mid"])
-def test_sampling_loop_80_steps_latency_mode(lat_engine, oracle, small_models, mid_models, kind):
+def test_sampling_loop_80_steps_latency_mode(lat_engine, oracle, small_models, mid_models, kind, oracle_sample):
     """The 80-step loop of tests/test_fullsize_gpu.py::test_sampling_loop_80_steps (same latents, same explicit noise) in latency mode: both arithmetic modes inside the
     ONE pair of gates of the default path."""
     engine = lat_engine
     d = small_models if kind == "small" else mid_models
     engine.load(diffusion=d + "/ggml-diffusion-model.bin")
-    od = oracle.Diffusion(oracle.Model(d + "/ggml-diffusion-model.bin"))
     lat = _latents(12, 12)
     noise = np.random.RandomState(5).randn(81, 100 * engine.frames(12)).astype(np.float32)
-    want = od.sample(lat, n_steps=80, noise=noise)
+    want = oracle_sample(d, lat, noise, 80)
     for mode, what in ATTN_MODES:
         engine.set_option("attn_f32", mode)
         engine.set_option("latency_mode", 0)
@@ -76,20 +75,18 @@ def test_sampling_loop_80_steps_latency_mode(lat_engine, oracle, small_models, m
         assert (mel == again).all(), "latency mode must be reproducible run to run"
 
 
-def test_ragged_pair_latency_mode(lat_engine, oracle, small_models):
+def test_ragged_pair_latency_mode(lat_engine, oracle, small_models, oracle_sample):
     """Two candidates of different length in one latency-mode batch (4 sequences; chunks of 8 rows never straddle two sequences) against the oracle, and each
     candidate against itself run alone in latency mode: the statistics are exact sums of per-chunk partials, so a candidate's result does not depend on its
     neighbours here either."""
     engine = lat_engine
     engine.load(diffusion=small_models + "/ggml-diffusion-model.bin")
-    od = oracle.Diffusion(oracle.Model(small_models + "/ggml-diffusion-model.bin"))
-    lats = [_latents(20, 1), _latents(9, 2)]
-    rs = np.random.RandomState(3)
-    noise = [rs.randn(81, 100 * engine.frames(len(l))).astype(np.float32) for l in lats]
+    import oracle_jobs
+    lats, noise = oracle_jobs.small_pair_inputs(engine.frames)
     engine.set_option("latency_mode", 1)
     mels = engine.diffusion(lats, n_steps=80, noise=noise)
     for c, l in enumerate(lats):
-        want = od.sample(l, n_steps=80, noise=noise[c])
+        want = oracle_sample(small_models, l, noise[c], 80, bg="small_pair%d" % c)
         print("latency mode, ragged pair cand %d: %s" % (c, check_loop(np.abs(mels[c] - want), "small", 0, "cand %d" % c, problem="test_sampling_loop_matches_oracle[cand %d]" % c)))
         alone = engine.diffusion([l], n_steps=80, noise=[noise[c]])[0]
         assert (alone == mels[c]).all(), "candidate %d differs between the pair and the single run" % c
