@@ -120,3 +120,24 @@ def test_hoisted_integrator_is_bit_identical(lat_engine, small_models, mid_model
                     assert (a == b).all(), (lens, steps, float(np.abs(a - b).max()))
                 else:
                     assert np.abs(a - b).max() < 5e-3, (lens, steps, float(np.abs(a - b).max()))
+
+
+@pytest.mark.parametrize("models,L", [("small", 1), ("small", 12), ("mid", 43), ("small", 100), ("small", 200), ("small", 250)])
+def test_attention_64_query_workgroups_are_bit_identical(lat_engine, small_models, mid_models, models, L):
+    """Option attn_q64 (the diffusion attention kernel with 64 instead of 128 queries per workgroup: twice as many, half as long workgroups for grids that leave the CUs
+    with at most one; measured without gain and off by default, profiles/r6_small_batch.txt). Every query's arithmetic is the same in the same key order (main.cpp:3232-3275): the forward
+    with the option forced on equals the forward with it off bit for bit, conditioned and conditioning-free, for lengths on and off the 64 / 128 boundaries."""
+    engine = lat_engine
+    d = small_models if models == "small" else mid_models
+    engine.load(diffusion=d + "/ggml-diffusion-model.bin")
+    lat = _latents(L, L)
+    x_t = np.random.RandomState(7).randn(100, engine.frames(L)).astype(np.float32)
+    try:
+        for cond_free in (False, True):
+            out = {}
+            for q64 in (0, 1):
+                engine.set_option("attn_q64", q64)
+                out[q64] = engine.diffusion_forward(lat, x_t, 1234, cond_free)
+            assert np.isfinite(out[0]).all() and (out[0] == out[1]).all(), (L, cond_free, float(np.abs(out[0] - out[1]).max()))
+    finally:
+        engine.set_option("attn_q64", 0)

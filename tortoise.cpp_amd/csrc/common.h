@@ -109,6 +109,7 @@ struct tts_ctx {
   int fp16_check = 0;      // option "fp16_check": scan every fp16 operand the diffusion stage writes for non-finite / saturated values (tts_diffusion_fp16_check)
   int64_t fp16_bad_weights[2] = {0, 0}; // the same two counts over the split-precision weights packed by the last tts_load_diffusion
   void *fp16_counts = nullptr;           // device: int64[2]
+  int attn_q64 = 0; // option "attn_q64": diffusion attention with 64-query workgroups: 0 never (default: measured, no gain), 1 always, 2 = when the 128-query grid has at most 256 workgroups (bit-identical)
   int hoist_integrator = 1; // option "hoist_integrator": small diffusion batches evaluate the conditioning_timestep_integrator layers (which never see x_t) for all sampling steps before the loop, in benchmark-sized batches (bit-identical; 0 = inside every step)
   int latency_mode = 0;    // option "latency_mode": small diffusion batches (<= 4096 packed rows) take the GroupNorm statistics from the producing GEMM's epilogue (diffusion.hip: gn_apply_kernel); not bit-identical to the batch path
   bool capturing = false;  // a hipGraph is being captured on the stream: ProfScope records nothing (event records would become graph nodes)

@@ -272,7 +272,12 @@ __device__ __forceinline__ float rows4_sum(float x) {
 // far path did not) and the PMC pass says the kernel is bound by VALU issue, not by the matrix pipe (profiles/r4_pmc_attention.json:
 // VALU pipe 66 % busy, matrix pipe 35 %, 6.6 VALU instructions per MFMA). Same arithmetic in the same order: bit-identical output.
 enum { ATT_FAR = 0, ATT_NEAR = 1, ATT_TAIL = 2 };
-template <int NR> // K/V ring depth: 3 = two tiles in flight, 3 workgroups per CU; 2 = one tile in flight, 4 workgroups per CU
+// NI: 16-query blocks per wave. 2 = 128 queries per workgroup (the batch shape). 1 = 64 queries per workgroup (round 6): for grids that would otherwise put at most one
+// workgroup on a CU (one utterance: 2 sequences x 16 heads x 7 query blocks = 224) twice as many, half as long workgroups give every SIMD a second wave. Every query's
+// arithmetic is the same in the same key order: bit-identical (tests/test_latency_mode_gpu.py). MEASURED, NO GAIN: one utterance's diffusion stage 138.1 / 136.0 ms with 128-query
+// workgroups, 136.2 / 135.9 with 64; two utterances 212.1 / 210.1 against 213.6 / 213.3 (profiles/r6_small_batch.txt) — the kernel's tile loop is a dependent chain per
+// wave (scores -> max -> exp -> PV) that a second wave per SIMD does not shorten at this size. Kept behind option attn_q64 (default 0) for A/B.
+template <int NR, int NI = 2> // NR: K/V ring depth: 3 = two tiles in flight, 3 workgroups per CU; 2 = one tile in flight, 4 workgroups per CU
 __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const __half *__restrict__ qk, const __half *__restrict__ vt, int ldvt,
                                                         const int *__restrict__ seq_start, const int *__restrict__ seq_len,
                                                         const float *__restrict__ bias_tab, __half *__restrict__ out, int nq) {
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
   // get ids congruent mod 8 and reuse that pair's K/V tiles from one L2 (16 heads => pairs % 8 == 0).
   const int xcd = blockIdx.x & 7, tt = blockIdx.x >> 3;
   const int pair = (tt / nq) * 8 + xcd, h = pair & 15, s = pair >> 4;
-  const int T = seq_len[s], r0 = seq_start[s], q0 = (tt % nq) * 128;
+  const int T = seq_len[s], r0 = seq_start[s], q0 = (tt % nq) * (64 * NI);
   if (q0 >= T) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), fr = lane & 15, fq = lane >> 4;
   const float L2E = 1.44269504088896f;
@@ -297,22 +302,24 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
     const int d = j - ATT_TAB / 2, ad = d < 0 ? -d : d;
     tab[j] = bias_tab[h * 128 + (d > 0 ? 64 : 0) + (ad < 63 ? ad : 63)] * (L2E / SC);
   }
-  const int qw = q0 + wave * 32;
-  half8 qf[2][2]; // Q[query = qw + i*16 + fr][d = ks*32 + fq*8 ..+7]
+  constexpr int QW = 16 * NI; // queries per wave
+  const int qw = q0 + wave * QW;
+  half8 qf[NI][2]; // Q[query = qw + i*16 + fr][d = ks*32 + fq*8 ..+7]
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < NI; i++)
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
       qf[i][ks] = *(const half8 *)(qk + (size_t)(r0 + qw + i * 16 + fr) * 2048 + h * 128 + ks * 32 + fq * 8);
   // Retire the Q loads HERE (a use makes hipcc place its vmcnt(0) now): vmcnt is an in-order counter, so a Q
   // load still pending at the loop would force vmcnt(0) in front of the first MFMA of every tile and drain the
   // K/V prefetch (seen in the ISA as `s_waitcnt vmcnt(0) lgkmcnt(0)` after the ds_reads).
-  asm volatile("" ::"v"(qf[0][0]), "v"(qf[0][1]), "v"(qf[1][0]), "v"(qf[1][1]));
-  floatx4 o[2][4]; // O^T[d = dt*16 + fq*4 + r][query = qw + i*16 + fr]
-  floatx4 lacc[2]; // row sums of P from the matrix pipe: (all-ones A tile) . P^T, every register = l[query fr]
-  float mrow[2];
+  if constexpr (NI == 2) asm volatile("" ::"v"(qf[0][0]), "v"(qf[0][1]), "v"(qf[1][0]), "v"(qf[1][1]));
+  else asm volatile("" ::"v"(qf[0][0]), "v"(qf[0][1]));
+  floatx4 o[NI][4]; // O^T[d = dt*16 + fq*4 + r][query = qw + i*16 + fr]
+  floatx4 lacc[NI]; // row sums of P from the matrix pipe: (all-ones A tile) . P^T, every register = l[query fr]
+  float mrow[NI];
 #pragma unroll
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < NI; i++) {
 #pragma unroll
     for (int j = 0; j < 4; j++) o[i][j] = (floatx4){0.f, 0.f, 0.f, 0.f};
     lacc[i] = (floatx4){0.f, 0.f, 0.f, 0.f};
@@ -348,13 +355,13 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
     __builtin_amdgcn_global_load_lds((gptr_t)(vsrc + voff[1]), (lptr_t)(vs_ + 1024), 16, 0, 0);
   };
   // S^T of one key tile: sc[i][jt][r] = S[query i*16+fr][key SIG(jt, fq*4 + r)]
-  auto scores = [&](const char *Ks, floatx4 (&sc)[2][4]) {
+  auto scores = [&](const char *Ks, floatx4 (&sc)[NI][4]) {
 #pragma unroll
     for (int jt = 0; jt < 4; jt++) {
       const half8 kf0 = *(const half8 *)(Ks + attn_off(jt * 16 + fr, fq));
       const half8 kf1 = *(const half8 *)(Ks + attn_off(jt * 16 + fr, 4 + fq));
 #pragma unroll
-      for (int i = 0; i < 2; i++) {
+      for (int i = 0; i < NI; i++) {
         floatx4 a = (floatx4){0.f, 0.f, 0.f, 0.f};
         a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf0, qf[i][0], a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf1, qf[i][1], a, 0, 0, 0);
@@ -384,13 +391,13 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
     stage(kb + NR - 1, (kb + NR - 1) % NR);
     const char *Ks = smem + (kb % NR) * 16384, *Vs = Ks + 8192;
     ATT_T(3);
-    floatx4 sc[2][4];
+    floatx4 sc[NI][4];
     scores(Ks, sc);
     ATT_T(4);
     const int kmin = kb * 64;
-    half8 pf[2][2]; // P^T in B-operand layout: slot e of step ks2 = key 32 ks2 + 8 fq + e
+    half8 pf[NI][2]; // P^T in B-operand layout: slot e of step ks2 = key 32 ks2 + 8 fq + e
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < NI; i++) {
       const int qi = qw + i * 16 + fr;
       float mx = -INFINITY, boff = 0.f; // v = sc*SC + bias; far tiles: bias is one constant (folded below)
       if (MODE == ATT_FAR) {
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
         mx *= SC;
       } else { // last tile of the sequence: keys >= T are masked
         const int left = T - kmin - fq * 8; // keys of this lane with off < left exist
-        const bool far_hi = kmin - (qw + 31) >= 63, far = far_hi || qw - (kmin + 63) >= 63; // then the bias is one constant (and the table base would be out of range)
+        const bool far_hi = kmin - (qw + QW - 1) >= 63, far = far_hi || qw - (kmin + 63) >= 63; // then the bias is one constant (and the table base would be out of range)
         const float cb = far_hi ? tab[ATT_TAB / 2 + 63] : tab[ATT_TAB / 2 - 63];
         const float *tp = tab + (far ? 0 : kmin + fq * 8 - qi + ATT_TAB / 2);
         float bv[4][4]; // all table reads first, unconditionally (a load under a per-element select is branched around)
@@ -463,17 +470,17 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
       for (int dt = 0; dt < 4; dt++) {
         const half8 vf = *(const half8 *)(Vs + attn_off(dt * 16 + fr, 4 * ks2 + fq));
 #pragma unroll
-        for (int i = 0; i < 2; i++) o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[i][ks2], o[i][dt], 0, 0, 0);
+        for (int i = 0; i < NI; i++) o[i][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[i][ks2], o[i][dt], 0, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < 2; i++) lacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[i][ks2], lacc[i], 0, 0, 0);
+      for (int i = 0; i < NI; i++) lacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[i][ks2], lacc[i], 0, 0, 0);
     }
     ATT_T(6);
   };
   {
-    // tiles [0, a): every key at least 63 before every query of the wave (qw - (kmin + 63) >= 63); [b, ..): at least 63 after (kmin - (qw + 31) >= 63)
+    // tiles [0, a): every key at least 63 before every query of the wave (qw - (kmin + 63) >= 63); [b, ..): at least 63 after (kmin - (qw + QW - 1) >= 63)
     const int last = (T & 63) ? nkb - 1 : nkb; // the masked tile, if any, is handled on its own
-    const int a = min(max((qw - 126) >= 0 ? (qw - 126) / 64 + 1 : 0, 0), last), b = min((qw + 94 + 63) / 64, last);
+    const int a = min(max((qw - 126) >= 0 ? (qw - 126) / 64 + 1 : 0, 0), last), b = min((qw + QW + 62 + 63) / 64, last);
     int kb = 0;
     for (; kb < a; kb++) tile(kb, std::integral_constant<int, ATT_FAR>{}, ATT_TAB / 2 - 63);
     for (; kb < b; kb++) tile(kb, std::integral_constant<int, ATT_NEAR>{}, 0);
@@ -482,12 +489,11 @@ __global__ __launch_bounds__(256, NR == 2 ? 4 : 3) void diff_attn_kernel(const _
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // trailing (clamped) DMA pieces must land before the LDS is released
   ATT_CLK(1);
-  float lrow[2] = {lacc[0][0], lacc[1][0]};
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
+  #pragma unroll
+  for (int i = 0; i < NI; i++) {
     const int qi = qw + i * 16 + fr;
     if (qi < T) {
-      const float inv = 1.0f / lrow[i];
+      const float inv = 1.0f / lacc[i][0];
 #pragma unroll
       for (int dt = 0; dt < 4; dt++) {
         __half2 p0 = __floats2half2_rn(o[i][dt][0] * inv, o[i][dt][1] * inv), p1 = __floats2half2_rn(o[i][dt][2] * inv, o[i][dt][3] * inv);
@@ -1491,8 +1497,15 @@ static int attention_block(tts_ctx *ctx, DiffState *st, const Layout &lay, Work 
     } else {
       // one K/V tile in flight at 4 workgroups per CU (162.5-163.0 us per launch) beat two tiles in flight at 3 per CU (168.2-168.9 us; round 2). Round 6: the deeper ring
       // does not help one utterance either (224 workgroups, at most one per CU: 20.6 us with one tile in flight, 21.1 with two — profiles/r6_small_batch.txt)
-      diff_attn_kernel<2><<<nq * NHEAD * lay.ns, 256, att_lds<2>(), ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128,
-                                                                               lay.d_start.as<int>(), lay.d_len.as<int>(), w.bias_tab, wk.ATT16(), nq);
+      // 64-query workgroups (option attn_q64: 0 never = default, 1 always, 2 = when the 128-query grid would leave CUs with at most one workgroup): bit-identical, no gain
+      const bool q64 = ctx->attn_q64 == 1 || (ctx->attn_q64 == 2 && nq * NHEAD * lay.ns <= 256);
+      if (q64) {
+        const int nq64 = (lay.max_len() + 63) / 64;
+        diff_attn_kernel<2, 1><<<nq64 * NHEAD * lay.ns, 256, att_lds<2>(), ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128,
+                                                                                      lay.d_start.as<int>(), lay.d_len.as<int>(), w.bias_tab, wk.ATT16(), nq64);
+      } else
+        diff_attn_kernel<2, 2><<<nq * NHEAD * lay.ns, 256, att_lds<2>(), ctx->stream>>>(wk.qk16.as<__half>(), wk.vt16.as<__half>(), wk.rows + 128,
+                                                                                    lay.d_start.as<int>(), lay.d_len.as<int>(), w.bias_tab, wk.ATT16(), nq);
     }
     TTS_HIP(ctx, hipGetLastError());
   }
