@@ -198,8 +198,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-share-uncond", action="store_true", help="headline pass with the unconditioned integrator layers evaluated per candidate")
     ap.add_argument("--no-ab", action="store_true", help="skip the extra pass that measures the other share_uncond setting")
-    ap.add_argument("--latency-mode", action="store_true", help="option latency_mode for the headline pass too (it only acts on diffusion batches of <= 4096 packed rows: "
-                    "--candidates 1 or 2); the single-utterance A/B below always measures both settings")
+    ap.add_argument("--latency-mode", action="store_true", help="option latency_mode for the headline pass too (it only acts on diffusion batches of <= 2 048 packed rows: "
+                    "--candidates 1); the single-utterance A/B below always measures both settings")
     ap.add_argument("--engine-option", action="append", default=[], metavar="KEY=VALUE", help="tts_set_option on every rank's engine before the run (A/B of an option, e.g. hoist_integrator=0)")
     ap.add_argument("--no-diff-graph", action="store_true", help="A/B: launch every diffusion step eagerly instead of replaying the captured step graph")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU plumbing test with --dry-engine)")

@@ -104,11 +104,12 @@ const char *tts_last_error(const tts_ctx *ctx);
  * the [B][8194] logits to the host as the reference does (main.cpp:4766-4768). Sampled ids are identical either way.
  * "dec_f32_mfma" (0 default; set BEFORE tts_load_ar): the decode step's LayerNorm-GEMV kernels multiply on v_mfma_f32_16x16x4_f32 (exact f32 products)
  * instead of split-precision fp16 pairs.
- * "latency_mode" (0 default; round 6): small diffusion batches only (at most 4096 packed rows: one or two utterances with both guidance branches — the reference's own
+ * "latency_mode" (0 default; round 6): small diffusion batches only (at most 2 048 packed rows: one utterance with both guidance branches — the reference's own
  * workload is ONE, main.cpp:6570). The GroupNorm statistics of every f32 tensor of the sampling step are accumulated by the epilogue of the GEMM that produces it
  * (exact fixed-point sums per sequence and 32-channel group) and the 45 GroupNorms of a step become elementwise launches. Results are reproducible run to run and
  * independent of the other candidates of the (small) batch, held to the same oracle gates as the default, but NOT bit-identical to the default path, which is why it is
- * opt-in. Measured gain: 1 % of the single-utterance diffusion stage (profiles/r6_small_batch.txt: the launches are bound by their fixed costs, not by the reduction).
+ * opt-in. Measured gain: 2-5 % of the single-utterance diffusion stage (138.7 -> 135.7 ms in the bench line, profiles/r6_small_batch.txt); it loses above one utterance.
+ * "hoist_integrator" (1 default), "attn_q64" (0 default): INTEGRATION.md; both bit-identical to the setting they replace.
  * "fp16_check" (0 default): see tts_diffusion_fp16_check. */
 int tts_set_option(tts_ctx *ctx, const char *key, double value);
 

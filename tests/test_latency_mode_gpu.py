@@ -1,4 +1,4 @@
-"""Option latency_mode (round 6): small diffusion batches — one or two utterances, at most 4096 packed rows — take the GroupNorm statistics
+"""Option latency_mode (round 6): small diffusion batches — one utterance, at most 2 048 packed rows — take the GroupNorm statistics
 from the epilogue of the GEMM that produced the tensor (fixed-point sums, gemm_f16.h: GEMM_OUT_*_STATS) and normalise with gn_apply_kernel instead of the reducing
 GroupNorm kernels (one 512-thread workgroup per (sequence, group): 64 workgroups, 8.7 us per launch, 43 launches per sampling step). The arithmetic differs from the
 batch path only in how the variance is formed (exact sums, E[x^2] - E[x]^2 in f64, against two-pass f32), so it is held to the SAME oracle gates as the default

@@ -111,7 +111,7 @@ struct tts_ctx {
   void *fp16_counts = nullptr;           // device: int64[2]
   int attn_q64 = 0; // option "attn_q64": diffusion attention with 64-query workgroups: 0 never (default: measured, no gain), 1 always, 2 = when the 128-query grid has at most 256 workgroups (bit-identical)
   int hoist_integrator = 1; // option "hoist_integrator": small diffusion batches evaluate the conditioning_timestep_integrator layers (which never see x_t) for all sampling steps before the loop, in benchmark-sized batches (bit-identical; 0 = inside every step)
-  int latency_mode = 0;    // option "latency_mode": small diffusion batches (<= 4096 packed rows) take the GroupNorm statistics from the producing GEMM's epilogue (diffusion.hip: gn_apply_kernel); not bit-identical to the batch path
+  int latency_mode = 0;    // option "latency_mode": small diffusion batches (<= 2 048 packed rows) take the GroupNorm statistics from the producing GEMM's epilogue (diffusion.hip: gn_apply_kernel); not bit-identical to the batch path
   bool capturing = false;  // a hipGraph is being captured on the stream: ProfScope records nothing (event records would become graph nodes)
   int diff_graph = 1;      // option "diff_graph": the diffusion step is captured once per call and replayed (0: every step launched eagerly)
   int prof_eager_every = 8; // while a diff_* family is profiled, every Nth diffusion step runs eagerly with its event pairs; the others replay the graph
