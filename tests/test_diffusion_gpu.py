@@ -153,6 +153,26 @@ def test_reference_noise_stream(engine, oracle, small_models):
     assert engine.rng_uniform() == rng.uniform()
 
 
+def test_reference_noise_pipeline_changes_nothing(engine, small_models):
+    """Round 6: with ONE candidate in the reference's draw order the host draws block k + 1 of the noise while the device runs the earlier steps (option noise_pipeline,
+    default 1; diffusion.hip: diff_sample). Same draws in the same order (main.cpp:5638, 6020-6021): the mel and the RNG state after the call equal the ones of the
+    draw-everything-first path bit for bit, for 80 and 200 steps; two candidates (candidate-major draw order) take the old path under either setting."""
+    engine.load(diffusion=small_models + "/ggml-diffusion-model.bin")
+    try:
+        for lats, steps in (([_latents(10, 4)], 80), ([_latents(23, 6)], 200), ([_latents(9, 1), _latents(14, 2)], 80)):
+            out = {}
+            for pipe in (0, 1):
+                engine.set_option("noise_pipeline", pipe)
+                engine.seed(4321)
+                mels = engine.diffusion(lats, n_steps=steps)
+                out[pipe] = (mels, engine.rng_uniform())
+            assert out[0][1] == out[1][1], "RNG state after the call differs"
+            for a, b in zip(out[0][0], out[1][0]):
+                assert np.isfinite(a).all() and (a == b).all()
+    finally:
+        engine.set_option("noise_pipeline", 1)
+
+
 def test_device_noise_is_deterministic_and_normal(engine, small_models, pkg):
     engine.load(diffusion=small_models + "/ggml-diffusion-model.bin")
     lat = _latents(30, 5)

@@ -171,6 +171,8 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
   else if (k == "lc_attn_f32") c->lc_attn_f32 = value != 0;
   else if (k == "latency_mode") c->latency_mode = value != 0;
   else if (k == "fp16_check") c->fp16_check = value != 0;
+  else if (k == "noise_pipeline") c->noise_pipeline = value != 0;
+  else if (k == "load_threads") c->load_threads = value < 0 ? 0 : value > 64 ? 64 : (int)value;
   else if (k == "attn_q64") c->attn_q64 = value < 0 ? 0 : value > 2 ? 2 : (int)value; // 0 never, 1 always, 2 auto (grids of at most one 128-query workgroup per CU)
   else if (k == "hoist_integrator") c->hoist_integrator = value < 0 ? 0 : (int)value; // 0 off, 1 on for small layouts, n > 1: on for layouts of at most n packed rows (A/B)
   else if (k == "attn_f32_drop") c->attn_f32_drop = (int)value & 7;

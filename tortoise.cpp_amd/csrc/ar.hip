@@ -1232,11 +1232,18 @@ struct ArState {
 
 void ar_free(ArState *s) { delete s; }
 
+static PinnedPool *ar_pin = nullptr; // pinned staging of the running ar_load (one load at a time per process: the loaders are not re-entrant across contexts)
+static hipError_t ar_h2d(void *dst, const void *src, size_t bytes) { return ar_pin ? ar_pin->upload(dst, src, bytes) : hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); }
+static std::mutex ar_own_mu; // ar_load builds the layers on several threads (common.h: run_parallel)
+static void ar_own(ArState *st, void *p) {
+  std::lock_guard<std::mutex> lk(ar_own_mu);
+  st->owned.push_back(p);
+}
 static int upload_h(tts_ctx *ctx, ArState *st, const std::vector<__half> &src, __half **dst) {
   void *p = nullptr;
   TTS_HIP(ctx, hipMalloc(&p, src.size() * sizeof(__half)));
-  st->owned.push_back(p);
-  TTS_HIP(ctx, hipMemcpy(p, src.data(), src.size() * sizeof(__half), hipMemcpyHostToDevice));
+  ar_own(st, p);
+  TTS_HIP(ctx, ar_h2d(p, src.data(), src.size() * sizeof(__half)));
   *dst = (__half *)p;
   return TTS_OK;
 }
@@ -1244,8 +1251,8 @@ static int upload_h(tts_ctx *ctx, ArState *st, const std::vector<__half> &src, _
 static int upload(tts_ctx *ctx, ArState *st, const std::vector<float> &src, float **dst) {
   void *p = nullptr;
   TTS_HIP(ctx, hipMalloc(&p, src.size() * sizeof(float)));
-  st->owned.push_back(p);
-  TTS_HIP(ctx, hipMemcpy(p, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
+  ar_own(st, p);
+  TTS_HIP(ctx, ar_h2d(p, src.data(), src.size() * sizeof(float)));
   *dst = (float *)p;
   return TTS_OK;
 }
@@ -1414,11 +1421,19 @@ static int fetch(tts_ctx *ctx, ArState *st, const WeightFile &wf, const std::str
 }
 
 int ar_load(tts_ctx *ctx, const char *path) {
+  static const bool timing = getenv("TTS_TIMING") != nullptr; // host-side breakdown on stderr
+  const auto t0 = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
   WeightFile wf;
   std::string err;
   int rc = read_weight_file(path, wf, err);
+  const double t_read = since(t0);
   if (rc != TTS_OK) return fail(ctx, rc, "autoregressive_model_load: %s", err.c_str());
+  static std::mutex load_mu; // one tts_load_ar at a time per process (ar_pin is shared)
+  std::lock_guard<std::mutex> load_lk(load_mu);
   std::unique_ptr<ArState> st(new ArState());
+  PinnedPool pin;
+  struct PinScope { PinnedPool *&slot; PinScope(PinnedPool *&s, PinnedPool *p) : slot(s) { slot = p; } ~PinScope() { slot = nullptr; } } pin_scope(ar_pin, ctx->load_threads == 1 ? nullptr : &pin);
   st->f32_mfma = ctx->dec_f32_mfma != 0;
   const std::string hp = "inference_model.transformer.h.";
   while (wf.has(hp + std::to_string(st->n_layers) + ".ln_1.weight")) st->n_layers++;
@@ -1432,16 +1447,21 @@ int ar_load(tts_ctx *ctx, const char *path) {
   }
 #define FETCH(name, a, b, dst) do { int _r = fetch(ctx, st.get(), wf, name, a, b, dst); if (_r) return _r; } while (0)
 #define FETCHT(name, a, b, dst) do { int _r = fetch(ctx, st.get(), wf, name, a, b, dst, true); if (_r) return _r; } while (0)
-  FETCH("text_embedding.weight", D, 256, &st->text_emb);
-  FETCH("text_pos_embedding.emb.weight", D, 404, &st->text_pos);
-  FETCH("mel_embedding.weight", D, V, &st->mel_emb);
-  FETCH("mel_pos_embedding.emb.weight", D, 608, &st->mel_pos);
-  FETCH("inference_model.transformer.ln_f.weight", D, 1, &st->lnf_g);
-  FETCH("inference_model.transformer.ln_f.bias", D, 1, &st->lnf_b);
-  FETCH("inference_model.lm_head.0.weight", D, 1, &st->lmh_g);
-  FETCH("inference_model.lm_head.0.bias", D, 1, &st->lmh_b);
+  auto build_globals = [&]() -> int {
+    FETCH("text_embedding.weight", D, 256, &st->text_emb);
+    FETCH("text_pos_embedding.emb.weight", D, 404, &st->text_pos);
+    FETCH("mel_embedding.weight", D, V, &st->mel_emb);
+    FETCH("mel_pos_embedding.emb.weight", D, 608, &st->mel_pos);
+    FETCH("inference_model.transformer.ln_f.weight", D, 1, &st->lnf_g);
+    FETCH("inference_model.transformer.ln_f.bias", D, 1, &st->lnf_b);
+    FETCH("inference_model.lm_head.0.weight", D, 1, &st->lmh_g);
+    FETCH("inference_model.lm_head.0.bias", D, 1, &st->lmh_b);
+    return TTS_OK;
+  };
   st->L.resize(st->n_layers);
-  for (int i = 0; i < st->n_layers; i++) {
+  // One layer = 50 MB of f32 weights re-tiled into the decode slabs, the strip-major copies and the split-fp16 MFMA layouts on the host (~0.2 s of one core) + their
+  // uploads: layers are independent, built on several threads (round 6: tts_load_ar 5.9 s -> see DESIGN.md section 5; option load_threads = 1 restores the serial loader).
+  auto build_layer = [&](int i) -> int {
     std::string p = hp + std::to_string(i);
     ArLayerDev &l = st->L[i];
     FETCH(p + ".ln_1.weight", D, 1, &l.ln1_g); FETCH(p + ".ln_1.bias", D, 1, &l.ln1_b);
@@ -1480,8 +1500,8 @@ int ar_load(tts_ctx *ctx, const char *path) {
       auto up8 = [&](const std::vector<uint8_t> &src, uint8_t **dst) {
         void *q = nullptr;
         TTS_HIP(ctx, hipMalloc(&q, src.size()));
-        st->owned.push_back(q);
-        TTS_HIP(ctx, hipMemcpy(q, src.data(), src.size(), hipMemcpyHostToDevice));
+        ar_own(st.get(), q);
+        TTS_HIP(ctx, ar_h2d(q, src.data(), src.size()));
         *dst = (uint8_t *)q;
         return (int)TTS_OK;
       };
@@ -1510,23 +1530,10 @@ int ar_load(tts_ctx *ctx, const char *path) {
       if ((r = upload_h(ctx, st.get(), to_half(pack_cols4(wf.t.at(p + ".attn.c_proj.weight").data.data(), D, D)), &l.q_proj))) return r;
       if ((r = upload_h(ctx, st.get(), to_half(pack_cols4(wf.t.at(p + ".mlp.c_proj.weight").data.data(), FF, D)), &l.q_fc2))) return r;
     }
-  }
-#undef FETCH
-#undef FETCHT
-  for (int i = 0; i < st->n_layers; i++) { // split-precision copies for the multi-row MFMA path
-    ArLayerDev &l = st->L[i];
-    struct { const float *w; int K, N; __half **dst; } jobs[4] = {
-        {l.w_attn, D, 3 * D, &l.s_attn}, {l.w_proj, D, D, &l.s_proj}, {l.w_fc, D, FF, &l.s_fc}, {l.w_fc2, FF, D, &l.s_fc2}};
-    for (auto &j : jobs) {
-      void *p = nullptr;
-      TTS_HIP(ctx, hipMalloc(&p, (size_t)j.N * 2 * j.K * sizeof(__half)));
-      st->owned.push_back(p);
-      split_weight_kernel<<<dim3(j.N / 32, j.K / 32), 256, 0, ctx->stream>>>(j.w, j.K, j.N, (__half *)p);
-      *j.dst = (__half *)p;
-    }
-  }
-  TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  { // lm_head.1: nn.Linear [8194][1024] -> [1024][VPAD] so that it streams like the Conv1D weights
+    return TTS_OK;
+  };
+  // lm_head.1: nn.Linear [8194][1024] -> [1024][VPAD] so that it streams like the Conv1D weights (one more job beside the layers)
+  auto build_head = [&]() -> int {
     auto it = wf.t.find("inference_model.lm_head.1.weight");
     auto ib = wf.t.find("inference_model.lm_head.1.bias");
     if (it == wf.t.end() || ib == wf.t.end()) return fail(ctx, TTS_ERR_FORMAT, "lm_head.1 missing from model file");
@@ -1551,17 +1558,38 @@ int ar_load(tts_ctx *ctx, const char *path) {
         void *q = nullptr;
         TTS_HIP(ctx, hipMalloc(&q, o.size()));
         st->owned.push_back(q);
-        TTS_HIP(ctx, hipMemcpy(q, o.data(), o.size(), hipMemcpyHostToDevice));
+        TTS_HIP(ctx, ar_h2d(q, o.data(), o.size()));
         st->o_lm = (uint8_t *)q;
         r = upload(ctx, st.get(), sc, &st->os_lm); if (r) return r;
       }
       r = upload(ctx, st.get(), cfold, &st->d_lmb); if (r) return r;
     }
     r = upload(ctx, st.get(), bt, &st->lm_b); if (r) return r;
+    return TTS_OK;
+  };
+  const auto t1 = std::chrono::steady_clock::now();
+  const int nl = st->n_layers;
+  if (int r = run_parallel(ctx, nl + 2, [&](int i) { return i == 0 ? build_head() : i == 1 ? build_globals() : build_layer(i - 2); })) return r; // the head (0.2 s) first
+  const double t_layers = since(t1);
+#undef FETCH
+#undef FETCHT
+  for (int i = 0; i < st->n_layers; i++) { // split-precision copies for the multi-row MFMA path
+    ArLayerDev &l = st->L[i];
+    struct { const float *w; int K, N; __half **dst; } jobs[4] = {
+        {l.w_attn, D, 3 * D, &l.s_attn}, {l.w_proj, D, D, &l.s_proj}, {l.w_fc, D, FF, &l.s_fc}, {l.w_fc2, FF, D, &l.s_fc2}};
+    for (auto &j : jobs) {
+      void *p = nullptr;
+      TTS_HIP(ctx, hipMalloc(&p, (size_t)j.N * 2 * j.K * sizeof(__half)));
+      st->owned.push_back(p);
+      split_weight_kernel<<<dim3(j.N / 32, j.K / 32), 256, 0, ctx->stream>>>(j.w, j.K, j.N, (__half *)p);
+      *j.dst = (__half *)p;
+    }
   }
+  TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
   st->loaded_wmode = ctx->ar_weights;
   if (ctx->ar) ar_free(ctx->ar);
   ctx->ar = st.release();
+  if (timing) fprintf(stderr, "[tts timing] AR load: file %.1f ms, %d layers %.1f, total %.1f\n", t_read, ctx->ar->n_layers, t_layers, since(t0));
   return TTS_OK;
 }
 

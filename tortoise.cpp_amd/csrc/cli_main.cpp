@@ -54,6 +54,7 @@ int main(int argc, char **argv) {
   int seed = 0, candidates = 1, steps = 80, device = 0, fixed_codes = 0, devices = 1, shard = -1, nshards = 1;
   std::string device_map, clvpPath, exchange = "files", rccl_id, diffLatentPath;
   bool dry = false, allow_shared = false;
+  bool timing = false;
   int test_fail_shard = -1, test_slow_shard = -1;
   std::vector<std::pair<std::string, double>> engine_options; // --option key=value (repeatable): tts_set_option before the models are loaded
   for (int i = 1; i < argc - 1; ++i) {
@@ -73,6 +74,7 @@ int main(int argc, char **argv) {
     else if (a == "--clvp") clvpPath = argv[i + 1];
     else if (a == "--exchange") exchange = argv[i + 1];
     else if (a == "--dry-run") dry = argv[i + 1][0] != '0'; // plumbing check without a device, see below
+    else if (a == "--timing") timing = argv[i + 1][0] != '0'; // wall clock of every phase of this process on stderr
     else if (a == "--test-fail-shard") test_fail_shard = std::stoi(argv[i + 1]); // test hooks (tests/test_distributed_cpu.py): worker r exits with status 3 after the
     else if (a == "--test-slow-shard") test_slow_shard = std::stoi(argv[i + 1]); // conditioning broadcast / sleeps 2 s before the final exchange
     else if (a == "--option") { // engine option, e.g. --option attn_f32=1 (include/tortoise_mi355x.h: tts_set_option)
@@ -191,7 +193,18 @@ int main(int argc, char **argv) {
   }
   const int total_candidates = candidates;
   if (shard >= 0) candidates = total_candidates / nshards;
+  using clk = std::chrono::steady_clock;
+  const clk::time_point t_start = clk::now();
+  clk::time_point t_last = t_start;
   tts_ctx *ctx = tts_create(dry ? -1 : device); // --dry-run: a host-only context (tokenizer, RNG, sampler; every stage call would fail)
+  auto mark = [&](const char *what) { // --timing 1
+    if (!timing) return;
+    const clk::time_point t = clk::now();
+    fprintf(stderr, "[timing] %-22s %8.1f ms (at %8.1f)\n", what, std::chrono::duration<double, std::milli>(t - t_last).count(),
+            std::chrono::duration<double, std::milli>(t - t_start).count());
+    t_last = t;
+  };
+  mark("tts_create");
   if (!ctx) {
     fprintf(stderr, "tts_create(%d) failed: no HIP device (this engine has no CPU path)\n", device);
     return 1;
@@ -265,7 +278,9 @@ int main(int argc, char **argv) {
       for (int c = 0; c < B_ar; c++) { audio.insert(audio.end(), seqs[c].begin(), seqs[c].end()); nsamp.push_back(seqs[c].size()); }
     }
   } else {
+  mark("tokenizer, voice");
   if (tts_load_ar(ctx, (modelsDir + "/ggml-model.bin").c_str())) return die(ctx, "autoregressive_model_load");
+  mark("load autoregressive");
   std::vector<int32_t> codes((size_t)B_ar * 502), rows(B_ar);
   std::vector<float> latents((size_t)B_ar * 500 * 1024);
   int32_t nsteps = 0;
@@ -275,6 +290,7 @@ int main(int argc, char **argv) {
   if (tts_autoregressive(ctx, tokens.data(), n, voice.data(), B_ar, fixed_codes > 0 ? fixed_codes : 500, ar_flags,
                          codes.data(), rows.data(), latents.data(), &nsteps))
     return die(ctx, "autoregressive");
+  mark("autoregressive");
   printf("tokens sampled: %d\n", nsteps);
   if (fixed_codes <= 0) {
     std::vector<int32_t> stopped(B_ar);
@@ -311,6 +327,7 @@ int main(int argc, char **argv) {
   }
 
   if (tts_load_diffusion(ctx, (modelsDir + "/ggml-diffusion-model.bin").c_str())) return die(ctx, "diffusion_model_load");
+  mark("load diffusion");
   if (!diffLatentPath.empty()) {
     std::vector<float> dl(2048);
     std::ifstream f(diffLatentPath, std::ios::binary);
@@ -329,10 +346,13 @@ int main(int argc, char **argv) {
   // B == 1: the reference's exact RNG order (AR uniforms, x_T, per-step noise, vocoder noise)
   const int noise_mode = (total_candidates == 1) ? TTS_NOISE_REFERENCE : TTS_NOISE_DEVICE;
   if (tts_diffusion(ctx, lat_in, rows.data(), B, steps, nullptr, noise_mode, mel.data())) return die(ctx, "diffusion");
+  mark("diffusion");
   if (tts_diffusion_time_mlp_retries(ctx) > 0) // only ever seen while another process shares the GPU (include/tortoise_mi355x.h)
     fprintf(stderr, "[tortoise] the timestep MLP was re-evaluated %d times before two evaluations agreed\n", tts_diffusion_time_mlp_retries(ctx));
   if (tts_load_vocoder(ctx, (modelsDir + "/ggml-vocoder-model.bin").c_str())) return die(ctx, "vocoder_model_load");
+  mark("load vocoder");
   if (tts_vocoder(ctx, mel.data(), frames.data(), B, nullptr, noise_mode, audio.data())) return die(ctx, "vocoder");
+  mark("vocoder");
   for (int c = 0; c < B; c++) nsamp.push_back((size_t)tts_vocoder_samples(frames[c]));
   } // !dry
   auto write_one = [&](const float *samples, int64_t ns, int gc, bool is_output) {
@@ -393,6 +413,8 @@ int main(int argc, char **argv) {
       f << kept_gc << " " << std::setprecision(17) << kept_score << "\n";
     }
   }
+  mark("write");
   tts_destroy(ctx);
+  mark("tts_destroy");
   return 0;
 }

@@ -11,7 +11,13 @@
 #include <map>
 #include <memory>
 #include <random>
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace tts {
@@ -42,6 +48,24 @@ struct DevBuf {
     if (p) (void)hipFree(p);
     p = nullptr; cap = 0;
     hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  template <class T> T *as() const { return (T *)p; }
+};
+
+struct PinnedBuf { // page-locked host memory that lives with its owner (asynchronous copies need it)
+  void *p = nullptr;
+  size_t cap = 0;
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf &) = delete;
+  PinnedBuf &operator=(const PinnedBuf &) = delete;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
     if (e == hipSuccess) cap = bytes;
     return e;
   }
@@ -109,6 +133,8 @@ struct tts_ctx {
   int fp16_check = 0;      // option "fp16_check": scan every fp16 operand the diffusion stage writes for non-finite / saturated values (tts_diffusion_fp16_check)
   int64_t fp16_bad_weights[2] = {0, 0}; // the same two counts over the split-precision weights packed by the last tts_load_diffusion
   void *fp16_counts = nullptr;           // device: int64[2]
+  int noise_pipeline = 1;  // option "noise_pipeline": TTS_NOISE_REFERENCE with one candidate draws a step's noise on the host while the device runs the previous steps (same draws in the same order)
+  int load_threads = 0;    // option "load_threads": host threads of the tts_load_* calls (0 = min(16, hardware threads); 1 = single-threaded)
   int attn_q64 = 0; // option "attn_q64": diffusion attention with 64-query workgroups: 0 never (default: measured, no gain), 1 always, 2 = when the 128-query grid has at most 256 workgroups (bit-identical)
   int hoist_integrator = 1; // option "hoist_integrator": small diffusion batches evaluate the conditioning_timestep_integrator layers (which never see x_t) for all sampling steps before the loop, in benchmark-sized batches (bit-identical; 0 = inside every step)
   int latency_mode = 0;    // option "latency_mode": small diffusion batches (<= 2 048 packed rows) take the GroupNorm statistics from the producing GEMM's epilogue (diffusion.hip: gn_apply_kernel); not bit-identical to the batch path
@@ -123,6 +149,83 @@ struct tts_ctx {
 namespace tts {
 
 int fail(tts_ctx *ctx, int code, const char *fmt, ...);
+
+// Host staging for the loaders' uploads: a pageable hipMemcpy goes through the runtime's own bounce buffer at ~5 GB/s, and tts_load_ar moves 4.6 GB (every matrix in two
+// or three layouts); from pinned memory the same copies run at PCIe speed. A few pinned buffers, taken and given back by the load workers, freed when the load returns.
+struct PinnedPool {
+  // at most `max_bufs` buffers of at least `min_cap` bytes exist at any time (pinning costs ~0.4 ms per MB, and so does the release): a worker that finds none idle waits
+  // for one — an upload holds its buffer for a host memcpy + a DMA, a few ms against the ~20 ms of packing between two uploads
+  explicit PinnedPool(size_t min_cap_ = (size_t)18 << 20, int max_bufs_ = 4) : min_cap(min_cap_), max_bufs(max_bufs_) {}
+  size_t min_cap;
+  int max_bufs, made = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<std::pair<void *, size_t>> idle;
+  ~PinnedPool() { for (auto &b : idle) (void)hipHostFree(b.first); }
+  std::pair<void *, size_t> take(size_t n) {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      for (size_t i = 0; i < idle.size(); i++)
+        if (idle[i].second >= n) { auto b = idle[i]; idle.erase(idle.begin() + (long)i); return b; }
+      if (made < max_bufs) { made++; break; }                                                  // room for one more
+      if (!idle.empty()) { (void)hipHostFree(idle.back().first); idle.pop_back(); break; }     // all too small: replace one
+      cv.wait(lk);
+    }
+    lk.unlock();
+    const size_t cap = std::max(n, min_cap);
+    void *p = nullptr;
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {
+      lk.lock(); made--; lk.unlock(); cv.notify_one();
+      return {nullptr, 0};
+    }
+    return {p, cap};
+  }
+  void give(std::pair<void *, size_t> b) {
+    if (!b.first) return;
+    { std::lock_guard<std::mutex> lk(mu); idle.push_back(b); }
+    cv.notify_one();
+  }
+  // dst (device) <- src (pageable host); falls back to the plain copy when no pinned memory can be had
+  hipError_t upload(void *dst, const void *src, size_t bytes) {
+    auto b = take(bytes);
+    if (!b.first) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    memcpy(b.first, src, bytes);
+    const hipError_t e = hipMemcpy(dst, b.first, bytes, hipMemcpyHostToDevice);
+    give(b);
+    return e;
+  }
+};
+
+// Load-time host work (layout transforms and uploads of independent tensors: the reference's loaders are one pass over the file, main.cpp:811-888; here every layer's
+// decode slabs / fp16 copies are built on the host) spread over a few threads: body(i) for i in [0, n), first non-zero status wins, no exception leaves a worker.
+// Option "load_threads": 0 = min(16, hardware threads), 1 = the single-threaded loaders of rounds 1-5. Everything body() shares must be guarded by the caller
+// (fail() serialises the error text itself).
+inline int run_parallel(tts_ctx *ctx, int n, const std::function<int(int)> &body) {
+  int nt = ctx->load_threads > 0 ? ctx->load_threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  nt = std::min(nt, n);
+  std::atomic<int> next{0}, rc{0};
+  auto work = [&]() {
+    if (ctx->device >= 0) (void)hipSetDevice(ctx->device); // the current device is per thread
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n || rc.load()) break;
+      int r;
+      try {
+        r = body(i);
+      } catch (const std::bad_alloc &) {
+        r = fail(ctx, TTS_ERR_LIMIT, "out of host memory");
+      } catch (...) {
+        r = fail(ctx, TTS_ERR_STATE, "internal error in a load worker");
+      }
+      if (r) { int z = 0; rc.compare_exchange_strong(z, r); }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; t++) th.emplace_back(work);
+  work();
+  for (auto &t : th) t.join();
+  return rc.load();
+}
 
 // Global id of this context's candidate 0: the ONE place that interprets rng_shard_offset / rng_shard_total, used by the
 // sampler's stream partition and by the device noise streams of the diffusion and vocoder stages alike. total == 0 = unsharded:

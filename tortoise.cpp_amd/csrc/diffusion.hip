@@ -942,6 +942,7 @@ struct DiffState {
     step_exec = nullptr; step_graph = nullptr;
   }
   DevBuf code_emb, ce, ce16, xt16, inp16, net, temb, e1, emb, ss_all, ss_chk, xbuf, xoff, noise, seq_src, lat_in16, out_ct;
+  PinnedBuf noise_host; // reference-order noise drawn step by step beside the device loop (diff_sample)
   ~DiffState() { drop_step_graph(); for (void *p : owned) (void)hipFree(p); }
   int n_res() const { return n_integ + n_main + n_tail; }
 };
@@ -959,8 +960,8 @@ int diff_set_cond_latent(tts_ctx *ctx, const float *latent2048) {
 }
 
 namespace {
-struct Loader {
-  tts_ctx *ctx; DiffState *st; const WeightFile &wf; std::map<std::string, bool> used;
+struct Loader { // its jobs run on several threads (common.h: run_parallel): `used`, `owned` and the bad-weight counters are touched under `mu`
+  tts_ctx *ctx; DiffState *st; const WeightFile &wf; std::map<std::string, bool> used; std::mutex mu; PinnedPool pin{(size_t)9 << 20, 4};
   const HostTensor *get(const std::string &name, int64_t nelem) {
     auto it = wf.t.find(name);
     if (it == wf.t.end()) { fail(ctx, TTS_ERR_FORMAT, "tensor '%s' missing from diffusion model file", name.c_str()); return nullptr; }
@@ -969,14 +970,14 @@ struct Loader {
            (long long)it->second.nelem(), (long long)nelem);
       return nullptr;
     }
-    used[name] = true;
+    { std::lock_guard<std::mutex> lk(mu); used[name] = true; }
     return &it->second;
   }
   template <class T> int put(const std::vector<T> &h, T **dst) {
     void *p = nullptr;
     TTS_HIP(ctx, hipMalloc(&p, h.size() * sizeof(T)));
-    st->owned.push_back(p);
-    TTS_HIP(ctx, hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    { std::lock_guard<std::mutex> lk(mu); st->owned.push_back(p); }
+    TTS_HIP(ctx, pin.upload(p, h.data(), h.size() * sizeof(T)));
     *dst = (T *)p;
     return TTS_OK;
   }
@@ -1023,11 +1024,13 @@ struct Loader {
           sp[(size_t)n * 2 * C + k] = hi;
           sp[(size_t)n * 2 * C + C + k] = __float2half_rn(w - __half2float(hi));
         }
+      long long bad[2] = {0, 0};
       for (const __half &h : sp) {
         const float v = std::fabs(__half2float(h));
-        if (!(v <= 65504.0f)) ctx->fp16_bad_weights[0]++;
-        else if (v > 60000.0f) ctx->fp16_bad_weights[1]++;
+        if (!(v <= 65504.0f)) bad[0]++;
+        else if (v > 60000.0f) bad[1]++;
       }
+      if (bad[0] | bad[1]) { std::lock_guard<std::mutex> lk(mu); ctx->fp16_bad_weights[0] += bad[0]; ctx->fp16_bad_weights[1] += bad[1]; }
       if ((r = put(sp, &a.proj_w_split))) return r;
     }
     if ((r = f32(p + ".proj_out.bias", C, &a.proj_b))) return r;
@@ -1069,49 +1072,51 @@ int diff_load(tts_ctx *ctx, const char *path) {
   if (rc != TTS_OK) return fail(ctx, rc, "diffusion_model_load: %s", err.c_str());
   std::unique_ptr<DiffState> st(new DiffState());
   Loader ld{ctx, st.get(), wf, {}};
-#define R(x) do { int _r = (x); if (_r) return _r; } while (0)
   while (wf.has("latent_conditioner." + std::to_string(st->n_lc + 1) + ".norm.weight")) st->n_lc++;
   while (wf.has("conditioning_timestep_integrator." + std::to_string(st->n_integ) + ".resblk.in_layers.0.weight")) st->n_integ++;
   while (wf.has("layers." + std::to_string(st->n_main) + ".resblk.in_layers.0.weight")) st->n_main++;
   while (wf.has("layers." + std::to_string(st->n_main + st->n_tail) + ".in_layers.0.weight")) st->n_tail++;
-  R(ld.f32("diffusion_conditioning_latent", 2 * C, &st->cond_latent));
-  R(ld.f32("unconditioned_embedding", C, &st->uncond_emb));
-  R(ld.conv16("latent_conditioner.0.weight", C, C, 3, C, C, &st->lc_w));
-  R(ld.f32("latent_conditioner.0.bias", C, &st->lc_bias));
   st->lc_attn.resize(st->n_lc);
-  for (int i = 0; i < st->n_lc; i++) R(ld.attn("latent_conditioner." + std::to_string(i + 1), st->lc_attn[i]));
-  R(ld.f32("code_norm.weight", C, &st->code_g));
-  R(ld.f32("code_norm.bias", C, &st->code_b));
-  R(ld.f32("time_embed.0.weight", C * C, &st->te0_w)); R(ld.f32("time_embed.0.bias", C, &st->te0_b));
-  R(ld.f32("time_embed.2.weight", C * C, &st->te2_w)); R(ld.f32("time_embed.2.bias", C, &st->te2_b));
   st->integ_res.resize(st->n_integ); st->integ_attn.resize(st->n_integ);
-  for (int i = 0; i < st->n_integ; i++) {
-    std::string p = "conditioning_timestep_integrator." + std::to_string(i);
-    R(ld.res(p + ".resblk", st->integ_res[i]));
-    R(ld.attn(p + ".attn", st->integ_attn[i]));
-  }
-  R(ld.conv16("inp_block.weight", C, 100, 3, C, XTC, &st->inp_w));
-  R(ld.f32("inp_block.bias", C, &st->inp_bias));
-  R(ld.conv16("integrating_conv.weight", C, 2 * C, 1, C, 2 * C, &st->integ_w));
-  R(ld.f32("integrating_conv.bias", C, &st->integ_bias));
   st->main_res.resize(st->n_main); st->main_attn.resize(st->n_main);
-  for (int i = 0; i < st->n_main; i++) {
-    std::string p = "layers." + std::to_string(i);
-    R(ld.res(p + ".resblk", st->main_res[i]));
-    R(ld.attn(p + ".attn", st->main_attn[i]));
-  }
   st->tail_res.resize(st->n_tail);
-  for (int i = 0; i < st->n_tail; i++) R(ld.res("layers." + std::to_string(st->n_main + i), st->tail_res[i]));
-  R(ld.f32("out.0.weight", C, &st->outn_g)); R(ld.f32("out.0.bias", C, &st->outn_b));
-  R(ld.conv16("out.2.weight", 200, C, 3, 256, C, &st->out_w));
-  {
+  // Every block's fp16 re-layout + upload is one job (round 6: the jobs run on several threads, tts_load_diffusion 1.2 s -> see DESIGN.md section 5)
+  std::vector<std::function<int()>> jobs;
+  DiffState *S = st.get();
+#define J(x) jobs.emplace_back([&ld, S]() -> int { (void)S; return (x); })
+  J(ld.f32("diffusion_conditioning_latent", 2 * C, &S->cond_latent));
+  J(ld.f32("unconditioned_embedding", C, &S->uncond_emb));
+  J(ld.conv16("latent_conditioner.0.weight", C, C, 3, C, C, &S->lc_w));
+  J(ld.f32("latent_conditioner.0.bias", C, &S->lc_bias));
+  for (int i = 0; i < st->n_lc; i++) jobs.emplace_back([&ld, S, i]() { return ld.attn("latent_conditioner." + std::to_string(i + 1), S->lc_attn[i]); });
+  J(ld.f32("code_norm.weight", C, &S->code_g));
+  J(ld.f32("code_norm.bias", C, &S->code_b));
+  J(ld.f32("time_embed.0.weight", C * C, &S->te0_w)); J(ld.f32("time_embed.0.bias", C, &S->te0_b));
+  J(ld.f32("time_embed.2.weight", C * C, &S->te2_w)); J(ld.f32("time_embed.2.bias", C, &S->te2_b));
+  for (int i = 0; i < st->n_integ; i++) {
+    jobs.emplace_back([&ld, S, i]() { return ld.res("conditioning_timestep_integrator." + std::to_string(i) + ".resblk", S->integ_res[i]); });
+    jobs.emplace_back([&ld, S, i]() { return ld.attn("conditioning_timestep_integrator." + std::to_string(i) + ".attn", S->integ_attn[i]); });
+  }
+  J(ld.conv16("inp_block.weight", C, 100, 3, C, XTC, &S->inp_w));
+  J(ld.f32("inp_block.bias", C, &S->inp_bias));
+  J(ld.conv16("integrating_conv.weight", C, 2 * C, 1, C, 2 * C, &S->integ_w));
+  J(ld.f32("integrating_conv.bias", C, &S->integ_bias));
+  for (int i = 0; i < st->n_main; i++) {
+    jobs.emplace_back([&ld, S, i]() { return ld.res("layers." + std::to_string(i) + ".resblk", S->main_res[i]); });
+    jobs.emplace_back([&ld, S, i]() { return ld.attn("layers." + std::to_string(i) + ".attn", S->main_attn[i]); });
+  }
+  for (int i = 0; i < st->n_tail; i++) jobs.emplace_back([&ld, S, i]() { return ld.res("layers." + std::to_string(S->n_main + i), S->tail_res[i]); });
+  J(ld.f32("out.0.weight", C, &S->outn_g)); J(ld.f32("out.0.bias", C, &S->outn_b));
+  J(ld.conv16("out.2.weight", 200, C, 3, 256, C, &S->out_w));
+  jobs.emplace_back([&ld, S]() -> int {
     const HostTensor *t = ld.get("out.2.bias", 200);
     if (!t) return TTS_ERR_FORMAT;
     std::vector<float> b(256, 0.f);
     std::copy(t->data.begin(), t->data.end(), b.begin());
-    R(ld.put(b, &st->out_bias));
-  }
-#undef R
+    return ld.put(b, &S->out_bias);
+  });
+#undef J
+  if (int r = run_parallel(ctx, (int)jobs.size(), [&](int i) { return jobs[i](); })) return r;
   for (auto &kv : wf.t)
     if (!ld.used.count(kv.first)) return fail(ctx, TTS_ERR_FORMAT, "unknown tensor '%s' in model file", kv.first.c_str());
   TTS_HIP(ctx, hipFuncSetAttribute((const void *)diff_attn_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT32_LDS)); // > 64 KB of dynamic LDS
@@ -1992,8 +1997,23 @@ int diff_sample(tts_ctx *ctx, const float *latents, const int32_t *rows, int B, 
   TTS_HIP(ctx, st->xoff.reserve(B * 8));
   TTS_HIP(ctx, hipMemcpy(st->xoff.p, xoff.data(), B * 8, hipMemcpyHostToDevice));
   const bool host_noise = noise != nullptr || noise_mode == TTS_NOISE_REFERENCE;
+  // One candidate in the reference's draw order (what ./tortoise runs): 81 x 100 T normal draws from the libstdc++ objects take longer on the host (~3 ms per step at
+  // T = 870) than the device takes for the step. Round 6: block k + 1 is drawn and sent while the device still works on steps <= k - 1 — the same draws in the same
+  // order (x_T, then step after step), the stream orders copy k + 1 in front of step k's update kernel. More candidates draw candidate after candidate
+  // (main.cpp:5638, 6020-6021): their order does not allow it.
+  bool pipe_noise = host_noise && !noise && B == 1 && ctx->noise_pipeline != 0;
+  if (pipe_noise && st->noise_host.reserve((size_t)total * (n_steps + 1) * 4) != hipSuccess) { (void)hipGetLastError(); pipe_noise = false; }
+  auto draw_block = [&](int k) { // block k of the one candidate into the pinned buffer, then on its way to the device
+    float *dst = st->noise_host.as<float>() + (size_t)k * total;
+    for (int64_t i = 0; i < total; i++) dst[i] = ctx->normal_distribution(ctx->generator);
+    return hipMemcpyAsync(st->noise.as<float>() + (size_t)k * total, dst, (size_t)total * 4, hipMemcpyHostToDevice, ctx->stream);
+  };
   std::vector<float> hn;
-  if (host_noise) {
+  if (pipe_noise) {
+    TTS_HIP(ctx, st->noise.reserve((size_t)total * (n_steps + 1) * 4));
+    TTS_HIP(ctx, draw_block(0));
+    TTS_HIP(ctx, hipMemcpyAsync(st->xbuf.p, st->noise.p, total * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  } else if (host_noise) {
     // per step a [cand][100][T] block in the layout of x: block 0 = x_T, block 1+idx = step idx
     hn.resize((size_t)total * (n_steps + 1));
     if (noise) { // caller layout: per candidate (n_steps+1) consecutive vectors
@@ -2081,6 +2101,7 @@ int diff_sample(tts_ctx *ctx, const float *latents, const int32_t *rows, int B, 
   }
   for (int idx = 0; idx < n_steps; idx++) {
     const bool eager = !use_graph || (prof_diff && idx % ctx->prof_eager_every == 0);
+    if (pipe_noise) TTS_HIP(ctx, draw_block(idx + 1)); // read by this step's update kernel
     if (eager) CHECK(enqueue_step());
     else TTS_HIP(ctx, hipGraphLaunch(st->step_exec, ctx->stream));
   }

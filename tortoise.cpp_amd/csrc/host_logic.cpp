@@ -2,6 +2,7 @@
 // sequence bookkeeping, WAV writer. Reference behaviour is cited per function (file:line in
 // /root/reference); tests/test_host_parity.py checks each against the real reference code.
 #include "common.h"
+#include <unistd.h>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -23,7 +24,11 @@ int fail(tts_ctx *ctx, int code, const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
-  if (ctx) ctx->err = buf;
+  if (ctx) {
+    static std::mutex mu; // load workers may fail at the same time (common.h: run_parallel)
+    std::lock_guard<std::mutex> lk(mu);
+    ctx->err = buf;
+  }
   return code;
 }
 
@@ -33,17 +38,21 @@ int fail(tts_ctx *ctx, int code, const char *fmt, ...) {
 // data} until EOF. Only F32 (ttype 0) occurs in the published files.
 // ---------------------------------------------------------------------------------------------
 int read_weight_file(const char *path, WeightFile &out, std::string &err) {
+  // Two passes (round 6): the record headers are walked with seeks, then the tensor payloads (1.6 GB for the AR model) are read by a few threads with pread() —
+  // the single fread() pass of rounds 1-5 spent as long zero-filling and copying as the page cache took to deliver.
   FILE *f = fopen(path, "rb");
   if (!f) { err = std::string("failed to open '") + path + "'"; return TTS_ERR_IO; }
-  fseek(f, 0, SEEK_END);
-  const long long file_size = ftell(f);
-  fseek(f, 0, SEEK_SET);
+  fseeko(f, 0, SEEK_END);
+  const long long file_size = ftello(f);
+  fseeko(f, 0, SEEK_SET);
   uint32_t magic = 0;
   if (fread(&magic, 4, 1, f) != 1 || magic != 0x67676d6cu) {
     fclose(f);
     err = std::string("invalid model file '") + path + "' (bad magic)";
     return TTS_ERR_FORMAT;
   }
+  struct Pending { HostTensor *t; long long off; std::string name; };
+  std::vector<Pending> pend;
   for (;;) {
     int32_t hdr[3];
     size_t got = fread(hdr, 4, 3, f);
@@ -69,16 +78,42 @@ int read_weight_file(const char *path, WeightFile &out, std::string &err) {
       want *= (unsigned long long)t.ne[i];
       if (want > (unsigned long long)file_size) break;
     }
-    if (want > (unsigned long long)(file_size - ftell(f))) { fclose(f); err = "tensor '" + name + "' truncated"; return TTS_ERR_IO; }
-    t.data.resize((size_t)t.nelem());
-    if (fread(t.data.data(), sizeof(float), t.data.size(), f) != t.data.size()) {
-      fclose(f);
-      err = "tensor '" + name + "' truncated";
-      return TTS_ERR_IO;
-    }
-    out.t.emplace(std::move(name), std::move(t));
+    const long long off = ftello(f);
+    if (want > (unsigned long long)(file_size - off)) { fclose(f); err = "tensor '" + name + "' truncated"; return TTS_ERR_IO; }
+    if (fseeko(f, (off_t)want, SEEK_CUR) != 0) { fclose(f); err = "tensor '" + name + "' truncated"; return TTS_ERR_IO; }
+    auto ins = out.t.emplace(name, std::move(t)); // a repeated name keeps its first record, as the single-pass reader did
+    if (ins.second) pend.push_back(Pending{&ins.first->second, off, std::move(name)});
   }
+  const int fd = fileno(f);
+  const int n = (int)pend.size();
+  int nt = (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+  nt = std::min(nt, std::max(1, n));
+  std::atomic<int> next{0}, bad{-1}, oom{0};
+  auto work = [&]() {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n || bad.load() >= 0 || oom.load()) break;
+      Pending &p = pend[i];
+      try {
+        p.t->data.resize((size_t)p.t->nelem());
+      } catch (...) { oom.store(1); break; }
+      char *dst = (char *)p.t->data.data();
+      size_t left = p.t->data.size() * sizeof(float);
+      long long off = p.off;
+      while (left > 0) {
+        const ssize_t g = pread(fd, dst, left, (off_t)off);
+        if (g <= 0) { int z = -1; bad.compare_exchange_strong(z, i); break; }
+        dst += g; off += g; left -= (size_t)g;
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; t++) th.emplace_back(work);
+  work();
+  for (auto &t : th) t.join();
   fclose(f);
+  if (oom.load()) { err = "out of host memory"; return TTS_ERR_LIMIT; }
+  if (bad.load() >= 0) { err = "tensor '" + pend[bad.load()].name + "' truncated"; return TTS_ERR_IO; }
   return TTS_OK;
 }
 
