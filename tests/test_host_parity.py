@@ -296,3 +296,31 @@ int main(void) {
     assert int(a[0]) == 870 and int(a[1]) == 880 * 256 - 6
     assert int(a[3]) == pkg.host_trimmed_rows(np.full(502, 83, np.int32)) if hasattr(pkg, "host_trimmed_rows") else True
     assert out[1].startswith("-") and "no HIP device" in out[1]
+
+
+def test_bulk_normal_draws_equal_single_draws(pkg, host, oracle):
+    """Round 6: counts of 4096 and more take a two-phase form of libstdc++'s normal_distribution (host_logic.cpp: rng_normal_fill — the generator calls and the accept test on
+    the calling thread, log / sqrt / divide of the accepted pairs on a few threads). Every float must equal the one a single operator() call returns, and generator and
+    distribution must be left in the state single draws leave them in: odd and even counts in sequence (the cached second value crosses calls and crosses the two forms),
+    uniforms in between, against a context with option rng_fast_normal = 0 — and against the reference's compiled sample_normal_noise (oracle/_ref)."""
+    L = pkg.lib()
+    slow = pkg.Engine.__new__(pkg.Engine); slow.L = L; slow.h = L.tts_create(-1)
+    slow.set_option("rng_fast_normal", 0)
+    counts = (5000, 4097, 3, 100001, 1, 8192, 65537, 7, 87000, 87001, 4096, 2)
+    for seed in (0, 1, 245645656):
+        host.seed(seed); slow.seed(seed)
+        for n in counts:
+            x, y = host.rng_normal(n), slow.rng_normal(n)
+            assert (x.view(np.uint32) == y.view(np.uint32)).all(), (seed, n)
+            assert host.rng_uniform() == slow.rng_uniform(), (seed, n)
+    slow.close()
+    R = oracle.ref()
+    if R is None:
+        pytest.skip("oracle/_ref/libref.so not built (no /root/reference): the comparison with the single-draw form above has run")
+    host.seed(77)
+    R.ref_seed(77)
+    for n in (87000, 4097, 5, 20000):
+        want = np.empty(n, np.float32)
+        R.ref_normal_fill(want, n)
+        assert (host.rng_normal(n).view(np.uint32) == want.view(np.uint32)).all(), n
+    assert host.rng_uniform() == R.ref_uniform()

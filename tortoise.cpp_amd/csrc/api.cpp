@@ -171,6 +171,7 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
   else if (k == "lc_attn_f32") c->lc_attn_f32 = value != 0;
   else if (k == "latency_mode") c->latency_mode = value != 0;
   else if (k == "fp16_check") c->fp16_check = value != 0;
+  else if (k == "rng_fast_normal") c->rng_fast_normal = value != 0;
   else if (k == "noise_pipeline") c->noise_pipeline = value != 0;
   else if (k == "load_threads") c->load_threads = value < 0 ? 0 : value > 64 ? 64 : (int)value;
   else if (k == "attn_q64") c->attn_q64 = value < 0 ? 0 : value > 2 ? 2 : (int)value; // 0 never, 1 always, 2 auto (grids of at most one 128-query workgroup per CU)
@@ -273,8 +274,8 @@ int tts_rng_save_state(tts_ctx *c, const char *path) {
 }
 float tts_rng_uniform(tts_ctx *c) { return c ? c->distribution(c->generator) : 0.f; }
 void tts_rng_normal(tts_ctx *c, float *out, int64_t n) { // sample_normal_noise, main.cpp:4695-4701
-  if (!c || !out) return;
-  for (int64_t i = 0; i < n; i++) out[i] = c->normal_distribution(c->generator);
+  if (!c || !out || n <= 0) return;
+  rng_normal_fill(c, out, n);
 }
 
 int tts_tokenizer_load(tts_ctx *c, const char *path) {

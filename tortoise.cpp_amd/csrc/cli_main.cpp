@@ -39,6 +39,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 #include <chrono>
+#include <thread>
 
 static int die(tts_ctx *c, const char *what) {
   fprintf(stderr, "%s: %s\n", what, tts_last_error(c));
@@ -279,6 +280,18 @@ int main(int argc, char **argv) {
     }
   } else {
   mark("tokenizer, voice");
+  // The diffusion and vocoder models do not depend on anything the autoregressive stage produces: they are read, re-laid out and uploaded on a second thread while this
+  // one loads and runs the autoregressive model (round 6; the reference loads each model in front of its stage, main.cpp:5089, 5634, 6069). Their status is looked at where
+  // the reference would have loaded them, so a bad file is reported at the same point of the run with the same message.
+  int rc_diff = 0, rc_voc = 0;
+  std::string err_diff, err_voc;
+  struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } bg;
+  bg.t = std::thread([&]() {
+    rc_diff = tts_load_diffusion(ctx, (modelsDir + "/ggml-diffusion-model.bin").c_str());
+    if (rc_diff) { err_diff = tts_last_error(ctx); return; }
+    rc_voc = tts_load_vocoder(ctx, (modelsDir + "/ggml-vocoder-model.bin").c_str());
+    if (rc_voc) err_voc = tts_last_error(ctx);
+  });
   if (tts_load_ar(ctx, (modelsDir + "/ggml-model.bin").c_str())) return die(ctx, "autoregressive_model_load");
   mark("load autoregressive");
   std::vector<int32_t> codes((size_t)B_ar * 502), rows(B_ar);
@@ -326,8 +339,9 @@ int main(int argc, char **argv) {
     if (shard < 0) printf("clvp: candidate %d kept (score %.5f)\n", kept_gc, kept_score);
   }
 
-  if (tts_load_diffusion(ctx, (modelsDir + "/ggml-diffusion-model.bin").c_str())) return die(ctx, "diffusion_model_load");
-  mark("load diffusion");
+  bg.t.join();
+  if (rc_diff) { fprintf(stderr, "diffusion_model_load: %s\n", err_diff.c_str()); return 1; }
+  mark("wait for the diffusion + vocoder loads");
   if (!diffLatentPath.empty()) {
     std::vector<float> dl(2048);
     std::ifstream f(diffLatentPath, std::ios::binary);
@@ -349,8 +363,7 @@ int main(int argc, char **argv) {
   mark("diffusion");
   if (tts_diffusion_time_mlp_retries(ctx) > 0) // only ever seen while another process shares the GPU (include/tortoise_mi355x.h)
     fprintf(stderr, "[tortoise] the timestep MLP was re-evaluated %d times before two evaluations agreed\n", tts_diffusion_time_mlp_retries(ctx));
-  if (tts_load_vocoder(ctx, (modelsDir + "/ggml-vocoder-model.bin").c_str())) return die(ctx, "vocoder_model_load");
-  mark("load vocoder");
+  if (rc_voc) { fprintf(stderr, "vocoder_model_load: %s\n", err_voc.c_str()); return 1; }
   if (tts_vocoder(ctx, mel.data(), frames.data(), B, nullptr, noise_mode, audio.data())) return die(ctx, "vocoder");
   mark("vocoder");
   for (int c = 0; c < B; c++) nsamp.push_back((size_t)tts_vocoder_samples(frames[c]));

@@ -133,6 +133,7 @@ struct tts_ctx {
   int fp16_check = 0;      // option "fp16_check": scan every fp16 operand the diffusion stage writes for non-finite / saturated values (tts_diffusion_fp16_check)
   int64_t fp16_bad_weights[2] = {0, 0}; // the same two counts over the split-precision weights packed by the last tts_load_diffusion
   void *fp16_counts = nullptr;           // device: int64[2]
+  int rng_fast_normal = 1; // option "rng_fast_normal": 0 = every normal draw through std::normal_distribution::operator() (A/B and the tests' reference for the fast form)
   int noise_pipeline = 1;  // option "noise_pipeline": TTS_NOISE_REFERENCE with one candidate draws a step's noise on the host while the device runs the previous steps (same draws in the same order)
   int load_threads = 0;    // option "load_threads": host threads of the tts_load_* calls (0 = min(16, hardware threads); 1 = single-threaded)
   int attn_q64 = 0; // option "attn_q64": diffusion attention with 64-query workgroups: 0 never (default: measured, no gain), 1 always, 2 = when the 128-query grid has at most 256 workgroups (bit-identical)
@@ -149,6 +150,10 @@ struct tts_ctx {
 namespace tts {
 
 int fail(tts_ctx *ctx, int code, const char *fmt, ...);
+
+// n draws of the context's normal distribution (sample_normal_noise, main.cpp:4695-4701: std::normal_distribution<double> over std::mt19937, values narrowed to float) into
+// dst, leaving generator and distribution in exactly the state n single draws leave them in. Large counts take a two-phase form of the same algorithm (host_logic.cpp).
+void rng_normal_fill(tts_ctx *ctx, float *dst, int64_t n);
 
 // Host staging for the loaders' uploads: a pageable hipMemcpy goes through the runtime's own bounce buffer at ~5 GB/s, and tts_load_ar moves 4.6 GB (every matrix in two
 // or three layouts); from pinned memory the same copies run at PCIe speed. A few pinned buffers, taken and given back by the load workers, freed when the load returns.

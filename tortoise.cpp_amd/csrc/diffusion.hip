@@ -2005,7 +2005,7 @@ int diff_sample(tts_ctx *ctx, const float *latents, const int32_t *rows, int B, 
   if (pipe_noise && st->noise_host.reserve((size_t)total * (n_steps + 1) * 4) != hipSuccess) { (void)hipGetLastError(); pipe_noise = false; }
   auto draw_block = [&](int k) { // block k of the one candidate into the pinned buffer, then on its way to the device
     float *dst = st->noise_host.as<float>() + (size_t)k * total;
-    for (int64_t i = 0; i < total; i++) dst[i] = ctx->normal_distribution(ctx->generator);
+    rng_normal_fill(ctx, dst, total);
     return hipMemcpyAsync(st->noise.as<float>() + (size_t)k * total, dst, (size_t)total * 4, hipMemcpyHostToDevice, ctx->stream);
   };
   std::vector<float> hn;
@@ -2027,7 +2027,7 @@ int diff_sample(tts_ctx *ctx, const float *latents, const int32_t *rows, int B, 
       for (int c = 0; c < B; c++)
         for (int k = 0; k <= n_steps; k++) {
           float *dst = hn.data() + (size_t)k * total + xoff[c];
-          for (int64_t i = 0; i < (int64_t)100 * lay.len[c]; i++) dst[i] = ctx->normal_distribution(ctx->generator);
+          rng_normal_fill(ctx, dst, (int64_t)100 * lay.len[c]);
         }
     }
     TTS_HIP(ctx, st->noise.reserve(hn.size() * 4));

@@ -3,6 +3,9 @@
 // /root/reference); tests/test_host_parity.py checks each against the real reference code.
 #include "common.h"
 #include <unistd.h>
+#include <iomanip>
+#include <random>
+#include <sstream>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -30,6 +33,105 @@ int fail(tts_ctx *ctx, int code, const char *fmt, ...) {
     ctx->err = buf;
   }
   return code;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reference-order normal noise in bulk. The reference draws every noise value with ONE call of std::normal_distribution<double>::operator()(std::mt19937 &)
+// (main.cpp:4695-4701; 81 x 100 T values per utterance in diffusion(), 64 (T + 10) in vocoder()), ~38 ns each on the GPU box's host: 0.27 s for one utterance, more than
+// the device needs for the whole sampling loop. libstdc++'s algorithm (bits/random.tcc; restated in oracle/orc_math.cpp and pinned there against the reference's compiled
+// lines) is Marsaglia's polar method over generate_canonical<double, 53>:
+//     u = (g() + g() * 2^32) / 2^64  (clamped below 1);   x = 2 u1 - 1, y = 2 u2 - 1, r2 = x x + y y, repeat while r2 > 1 or r2 == 0;
+//     m = sqrt(-2 log(r2) / r2);   return y m now, x m at the next call;   every returned value v goes through v * stddev + mean.
+// Only the generator calls and the accept test are sequential; log / sqrt / divide depend on one accepted pair each. rng_normal_fill runs the sequential part on the
+// calling thread (the generator object itself: it ends in the state single draws leave it in) and the per-pair arithmetic on a few threads — the same operations in the
+// same order per value, so every float equals the one operator() returns (tests/test_host_parity.py compares the two forms draw for draw, and the fast form against
+// the reference's compiled lines). The distribution object's cached second value is read and written through its stream operators (the library's own state interface).
+// ---------------------------------------------------------------------------------------------
+namespace {
+// (the reference's build has no fused multiply-add: contraction is switched off in every function below that multiplies and adds)
+inline double canonical53(std::mt19937 &g) {
+#pragma clang fp contract(off)
+  const double lo = (double)g();
+  const double hi = (double)g();
+  double ret = (lo + hi * 4294967296.0) / 18446744073709551616.0;
+  if (ret >= 1.0) ret = std::nextafter(1.0, 0.0);
+  return ret;
+}
+struct PolarPair { double x, y, r2; };
+inline void polar_finish(const PolarPair &p, double &first, double &second) {
+#pragma clang fp contract(off)
+  const double m = std::sqrt(-2 * std::log(p.r2) / p.r2);
+  first = p.y * m;
+  second = p.x * m;
+}
+inline float as_returned(double v) {
+#pragma clang fp contract(off)
+  return (float)(v * 1.0 + 0.0);
+} // operator() ends with ret * stddev + mean (turns -0 into +0, like the original)
+bool normal_saved(const std::normal_distribution<double> &d, double &saved) {
+  std::ostringstream os;
+  os << d; // "mean stddev saved_available [saved]" at max_digits10
+  std::istringstream is(os.str());
+  double mean = 0, sd = 0;
+  int avail = 0;
+  is >> mean >> sd >> avail;
+  if (avail) is >> saved;
+  return avail != 0;
+}
+void normal_set_saved(std::normal_distribution<double> &d, bool avail, double saved) {
+  if (!avail) { d.reset(); return; }
+  std::ostringstream os;
+  os.precision(std::numeric_limits<double>::max_digits10);
+  os << std::scientific << d.mean() << ' ' << d.stddev() << ' ' << 1 << ' ' << saved;
+  std::istringstream is(os.str());
+  is >> d;
+}
+} // namespace
+
+void rng_normal_fill(tts_ctx *ctx, float *dst, int64_t n) {
+#pragma clang fp contract(off)
+  if (n <= 0) return;
+  std::normal_distribution<double> &nd = ctx->normal_distribution;
+  if (!ctx->rng_fast_normal || n < 4096 || nd.mean() != 0.0 || nd.stddev() != 1.0) {
+    for (int64_t i = 0; i < n; i++) dst[i] = nd(ctx->generator);
+    return;
+  }
+  int64_t at = 0;
+  double saved = 0;
+  if (normal_saved(nd, saved)) dst[at++] = as_returned(saved); // the cached second value of an earlier pair comes first
+  const int64_t left = n - at, pairs = (left + 1) / 2;
+  std::vector<PolarPair> pp((size_t)pairs);
+  std::mt19937 &g = ctx->generator;
+  for (int64_t i = 0; i < pairs; i++) { // the sequential part: generator calls and the accept test
+    double x, y, r2;
+    do {
+      x = 2.0 * canonical53(g) - 1.0;
+      y = 2.0 * canonical53(g) - 1.0;
+      r2 = x * x + y * y;
+    } while (r2 > 1.0 || r2 == 0.0);
+    pp[(size_t)i] = PolarPair{x, y, r2};
+  }
+  float *out = dst + at;
+  double last_second = 0;
+  auto finish = [&](int64_t a, int64_t b) {
+#pragma clang loop vectorize(disable) // scalar libm log / sqrt, as in the original
+    for (int64_t i = a; i < b; i++) {
+      double v0, v1;
+      polar_finish(pp[(size_t)i], v0, v1);
+      out[2 * i] = as_returned(v0);
+      if (2 * i + 1 < left) out[2 * i + 1] = as_returned(v1);
+      else last_second = v1; // only the last pair of an odd count gets here (one thread)
+    }
+  };
+  const int nt = (int)std::min<int64_t>(std::min(8u, std::max(1u, std::thread::hardware_concurrency())), pairs / 8192);
+  if (nt <= 1) finish(0, pairs);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(finish, pairs * t / nt, pairs * (t + 1) / nt);
+    finish(0, pairs / nt);
+    for (auto &t : th) t.join();
+  }
+  normal_set_saved(nd, (left & 1) != 0, last_second);
 }
 
 // ---------------------------------------------------------------------------------------------

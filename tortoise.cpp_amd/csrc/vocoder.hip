@@ -574,7 +574,7 @@ int voc_run(tts_ctx *ctx, const float *mel, const int32_t *frames, int B, const 
     TTS_HIP(ctx, hipMemcpyAsync(st->nzsrc.p, noise, nz_total * 4, hipMemcpyHostToDevice, ctx->stream));
   } else if (noise_mode == TTS_NOISE_REFERENCE) {
     hn.resize(nz_total);
-    for (int64_t i = 0; i < nz_total; i++) hn[i] = ctx->normal_distribution(ctx->generator);
+    rng_normal_fill(ctx, hn.data(), nz_total);
     TTS_HIP(ctx, hipMemcpyAsync(st->nzsrc.p, hn.data(), nz_total * 4, hipMemcpyHostToDevice, ctx->stream));
   } else {
     for (int c = 0; c < B; c++) {
