@@ -285,6 +285,7 @@ def main():
         voice = tv.cpu().numpy()
         prompts = {p: tt[p].cpu().numpy() for p in range(8)}
 
+    load_ms = {}
     placement = {"node": -1, "cpulist": "", "cpus": 0}  # NUMA node of this rank's GPU / CPUs the rank was pinned to (0: not pinned)
     if a.dry_engine:
         eng = pkg.Engine.__new__(pkg.Engine)
@@ -299,7 +300,11 @@ def main():
             ncpu = placement["cpus"] or (os.cpu_count() or 8) // world
             eng.set_option("sampler_threads", max(0, min(7, ncpu - 2)))
         placement["node"], placement["cpulist"] = eng.numa_node()
-        eng.load(model_dir)
+        # model loads, timed (not part of the metric: weights are resident when the timed region starts; round 6 parallelised the loaders, profiles/r6_cli_wall.txt)
+        for _k, _f in (("ar", "ggml-model.bin"), ("diffusion", "ggml-diffusion-model.bin"), ("vocoder", "ggml-vocoder-model.bin")):
+            _t0 = time.perf_counter()
+            eng.load(**{_k: os.path.join(model_dir, _f)})
+            load_ms[_k] = round(1e3 * (time.perf_counter() - _t0), 1)
     if a.no_diff_graph and not a.dry_engine:
         eng.set_option("diff_graph", 0)
     if a.latency_mode and not a.dry_engine:
@@ -657,7 +662,7 @@ def main():
         "ar_weights_f16_option": f16,
         "ar_weights_fp8_option": fp8,
         "reference_precision_option": ref_prec,
-        "ragged_batch": ragged, "single_utterance_ms": single_ms, "single_utterance_latency_mode": single_lat, "first_audio_ms": first_audio, "clvp_ms": clvp,
+        "ragged_batch": ragged, "single_utterance_ms": single_ms, "single_utterance_latency_mode": single_lat, "first_audio_ms": first_audio, "clvp_ms": clvp, "load_ms": load_ms,
         # the collective backend has seen this many ranks (all_reduce of ones) and rank 0 has gathered this many audio samples in the last pass
         "per_rank": (per_rank if per_rank else [{"rank": 0, "ms_per_step": None, "numa_node": placement["node"], "pinned_cpus": placement["cpus"]}]),
         "collective_ranks": collective_ranks, "collective_backend": (a.backend if dist else None), "gathered_samples": shape.get("gathered_samples"),

@@ -110,7 +110,10 @@ const char *tts_last_error(const tts_ctx *ctx);
  * independent of the other candidates of the (small) batch, held to the same oracle gates as the default, but NOT bit-identical to the default path, which is why it is
  * opt-in. Measured gain: 2-5 % of the single-utterance diffusion stage (138.7 -> 135.7 ms in the bench line, profiles/r6_small_batch.txt); it loses above one utterance.
  * "hoist_integrator" (1 default), "attn_q64" (0 default): INTEGRATION.md; both bit-identical to the setting they replace.
- * "fp16_check" (0 default): see tts_diffusion_fp16_check. */
+ * "fp16_check" (0 default): see tts_diffusion_fp16_check.
+ * "load_threads" (0 default = min(16, hardware threads); set BEFORE tts_load_*): host threads that build and upload the device layouts; 1 = serial.
+ * "noise_pipeline", "rng_fast_normal" (1 default): production of TTS_NOISE_REFERENCE draws (beside the device loop; two-phase normal distribution). Results and the RNG
+ * state afterwards are those of single std::normal_distribution draws either way (tests/test_host_parity.py); 0 = the single-draw forms. */
 int tts_set_option(tts_ctx *ctx, const char *key, double value);
 
 /* ---- weight files (drop-in format: magic 0x67676d6c + name-keyed F32 records) ------------- */
