@@ -1,4 +1,6 @@
 """GPU parity of the autoregressive stage against the oracle (CPU restatement), through the C ABI."""
+import time
+
 import numpy as np
 import pytest
 
@@ -27,6 +29,42 @@ def test_prefill_and_steps_logits(engine, oracle, small_models, voice, B):
         prev = rs.randint(0, 8192, B).astype(np.int32)
         lg, lo = engine.ar_step(prev, i), ar.step(prev, i)
         assert rel_err(lg, lo) < 1e-4, i
+
+
+@pytest.mark.parametrize("models", ["small", "full"])
+def test_loader_paths_give_the_same_bits(engine, small_models, full_models, voice, models):
+    """tts_load_ar builds its device layouts three ways: on one host thread (load_threads = 1: rounds 1-5), on several host threads (load_device_pack = 0), and — the
+    default since round 6 — with kernels from the uploaded file tensors (ar.hip: pk_*_kernel). The layouts are index permutations plus one rounding per element, so the
+    three loads must give bit-identical logits in the prompt pass, the decode steps (16 candidates: every decode slab layout and the head) and the latent pass (the
+    split-precision copies). Full size: every layer shape the benchmark runs."""
+    d = small_models if models == "small" else full_models
+    toks, B = DEFAULT_TOKENS, 16
+    rs = np.random.RandomState(5)
+    prevs = [rs.randint(0, 8192, B).astype(np.int32) for _ in range(3)]
+    codes = rs.randint(0, 8192, (B, 12)).astype(np.int32)
+    out = {}
+    try:
+        for name, opts in (("serial host", {"load_threads": 1}), ("host threads", {"load_threads": 0, "load_device_pack": 0}), ("device", {"load_threads": 0, "load_device_pack": 1})):
+            for k, v in opts.items():
+                engine.set_option(k, v)
+            t0 = time.time()
+            engine.load(ar=d + "/ggml-model.bin")
+            print("tts_load_ar, %s weights, %s: %.2f s" % (models, name, time.time() - t0))
+            engine.ar_begin(toks, voice, B, 8)
+            got = [engine.ar_prefill().copy()]
+            for i, prev in enumerate(prevs):
+                got.append(engine.ar_step(prev, i).copy())
+            engine.seed(9)
+            c, rows, lats, steps = engine.autoregressive(toks, voice, 2, 12, mask_stop=True)
+            got += [np.asarray(c).copy()] + [np.asarray(l).copy() for l in lats]
+            out[name] = got
+    finally:
+        engine.set_option("load_threads", 0)
+        engine.set_option("load_device_pack", 1)
+    for name in ("host threads", "device"):
+        assert len(out[name]) == len(out["serial host"])
+        for a_, b_ in zip(out["serial host"], out[name]):
+            assert a_.shape == b_.shape and (a_.view(np.uint32) == b_.view(np.uint32)).all(), name
 
 
 def test_long_context_crosses_attention_chunk(engine, oracle, small_models, voice):

@@ -62,7 +62,7 @@ tts_ctx *tts_create(int device) {
   if (hipSetDevice(device) != hipSuccess) return nullptr;
   tts_ctx *c = new tts_ctx();
   c->device = device;
-  if (hipStreamCreate(&c->stream) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+  if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreateWithFlags(&c->load_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
       hipEventCreate(&c->ev1) != hipSuccess) {
     delete c;
     return nullptr;
@@ -140,6 +140,7 @@ void tts_destroy(tts_ctx *c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->load_stream) (void)hipStreamDestroy(c->load_stream);
   delete c;
 }
 
@@ -173,6 +174,7 @@ int tts_set_option(tts_ctx *c, const char *key, double value) {
   else if (k == "fp16_check") c->fp16_check = value != 0;
   else if (k == "rng_fast_normal") c->rng_fast_normal = value != 0;
   else if (k == "noise_pipeline") c->noise_pipeline = value != 0;
+  else if (k == "load_device_pack") c->load_device_pack = value != 0;
   else if (k == "load_threads") c->load_threads = value < 0 ? 0 : value > 64 ? 64 : (int)value;
   else if (k == "attn_q64") c->attn_q64 = value < 0 ? 0 : value > 2 ? 2 : (int)value; // 0 never, 1 always, 2 auto (grids of at most one 128-query workgroup per CU)
   else if (k == "hoist_integrator") c->hoist_integrator = value < 0 ? 0 : (int)value; // 0 off, 1 on for small layouts, n > 1: on for layouts of at most n packed rows (A/B)

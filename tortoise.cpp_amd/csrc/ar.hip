@@ -189,6 +189,70 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float *__restri
     out[(size_t)(n0 + r) * 2 * K + K + k0 + tx] = lo;
   }
 }
+
+// ---- load-time re-layouts on the device (round 6) -------------------------------------------------
+// The host packers above (strip_major, fold_layernorm, pack_mfma16h, pack_cols4) are index permutations plus one rounding each; tts_load_ar spent 5.9 s in them on one
+// core and still 0.5 s on sixteen. The same permutations as kernels: a worker uploads a tensor as it lies in the file and the layouts are produced from that copy.
+// Same arithmetic per element (f32 multiply by the LayerNorm gain, exact scaling by 64, round-to-nearest-even fp16 hi / lo, the double-precision column sums of the
+// folded bias in ascending k): the buffers equal the host packers' byte for byte (tests/test_ar_gpu.py compares the logits of the two loads bit for bit).
+__global__ __launch_bounds__(256) void pk_strip_major_kernel(const float *__restrict__ w, int K, int N, float *__restrict__ t) {
+  const size_t total = (size_t)K * N;
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+    const size_t s0 = o / ((size_t)K * 64), rem = o % ((size_t)K * 64);
+    t[o] = w[(rem / 64) * N + s0 * 64 + (rem % 64)];
+  }
+}
+__global__ __launch_bounds__(256) void pk_fold_kernel(const float *__restrict__ w, int K, int N, const float *__restrict__ g, float *__restrict__ wf) {
+  const size_t total = (size_t)K * N;
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) wf[o] = g[o / N] * w[o];
+}
+// cf[n] = float(double(c[n]) + sum_k double(b[k]) double(w[k][n])), k ascending (a product of two floats is exact in double: fused or not, the same sum)
+__global__ __launch_bounds__(256) void pk_fold_bias_kernel(const float *__restrict__ w, int K, int N, const float *__restrict__ b, const float *__restrict__ c,
+                                                           float *__restrict__ cf) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  double acc = 0.0;
+  for (int k = 0; k < K; k++) acc += (double)b[k] * (double)w[(size_t)k * N + n];
+  cf[n] = (float)((double)c[n] + acc);
+}
+// pack_mfma16h: one thread per weight (K = 1024)
+__global__ __launch_bounds__(256) void pk_mfma16h_kernel(const float *__restrict__ w, int N, __half *__restrict__ t) {
+  const size_t total = (size_t)1024 * N;
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+    const int e = (int)(o & 7), lane = (int)((o >> 3) & 63), s2 = (int)((o >> 9) & 7), wv = (int)((o >> 12) & 3);
+    const size_t cb = o >> 14;
+    const float v = W16_SCALE * w[(size_t)(wv * 256 + s2 * 32 + 8 * (lane >> 4) + e) * N + cb * 16 + (lane & 15)];
+    const __half hi = __float2half_rn(v);
+    const size_t base = ((((cb * 4 + wv) * 8 + s2) * 64 + lane) * 16);
+    t[base + e] = hi;
+    t[base + 8 + e] = __float2half_rn(v - __half2float(hi));
+  }
+}
+__global__ __launch_bounds__(256) void pk_cols4_kernel(const float *__restrict__ w, int K, int N, float *__restrict__ t) {
+  const size_t total = (size_t)K * N;
+  const int KG = K / 1024;
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+    const int c = (int)(o & 3), tid = (int)((o >> 2) & 255), kk = (int)((o >> 10) & 3);
+    const size_t q = o >> 12; // cb * KG + i
+    const size_t cb = q / KG, i = q % KG;
+    t[o] = w[(i * 1024 + 4 * tid + kk) * N + cb * 4 + c];
+  }
+}
+// nn.Linear [V][D] -> [D][VPAD], zero padded
+__global__ __launch_bounds__(256) void pk_transpose_pad_kernel(const float *__restrict__ w, int rowsV, int colsD, int vpad, float *__restrict__ wt) {
+  const size_t total = (size_t)colsD * vpad;
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (size_t)gridDim.x * 256) {
+    const size_t k = o / vpad, n = o % vpad;
+    wt[o] = n < (size_t)rowsV ? w[n * colsD + k] : 0.f;
+  }
+}
+// max |w| into *out (bits of a non-negative float order like unsigned integers; a NaN ends up above every number and fails the range check loudly)
+__global__ __launch_bounds__(256) void pk_absmax_kernel(const float *__restrict__ w, size_t n, unsigned *__restrict__ out) {
+  unsigned m = 0;
+  for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (size_t)gridDim.x * 256) m = max(m, __float_as_uint(fabsf(w[o])));
+  for (int off = 32; off; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
 // x f32 [rows][K] -> hi, lo fp16 [rows_pad][K] (pad rows zero)
 __global__ __launch_bounds__(256) void split_act_kernel(const float *__restrict__ x, int rows, int K, __half *__restrict__ hi,
                                                         __half *__restrict__ lo) {
@@ -1233,7 +1297,22 @@ struct ArState {
 void ar_free(ArState *s) { delete s; }
 
 static PinnedPool *ar_pin = nullptr; // pinned staging of the running ar_load (one load at a time per process: the loaders are not re-entrant across contexts)
-static hipError_t ar_h2d(void *dst, const void *src, size_t bytes) { return ar_pin ? ar_pin->upload(dst, src, bytes) : hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice); }
+static hipStream_t ar_load_stream = nullptr;
+static hipError_t ar_h2d(void *dst, const void *src, size_t bytes) { return ar_pin ? ar_pin->upload(dst, src, bytes, ar_load_stream) : PinnedPool::copy_now(dst, src, bytes, ar_load_stream); }
+// a tensor that read_weight_file left in the file: pread() into pinned staging, DMA to dst
+static int ar_file_to_device(tts_ctx *ctx, const WeightFile &wf, const HostTensor &t, const std::string &name, void *dst) {
+  const size_t bytes = (size_t)t.nelem() * 4;
+  std::pair<void *, size_t> b = ar_pin ? ar_pin->take(bytes) : std::pair<void *, size_t>{nullptr, 0};
+  std::vector<float> tmp;
+  void *host = b.first;
+  if (!host) { tmp.resize((size_t)t.nelem()); host = tmp.data(); }
+  const bool ok = wf.read_payload(t, host);
+  const hipError_t e = ok ? PinnedPool::copy_now(dst, host, bytes, ar_load_stream) : hipSuccess;
+  if (ar_pin) ar_pin->give(b);
+  if (!ok) return fail(ctx, TTS_ERR_IO, "autoregressive_model_load: tensor '%s' truncated", name.c_str());
+  TTS_HIP(ctx, e);
+  return TTS_OK;
+}
 static std::mutex ar_own_mu; // ar_load builds the layers on several threads (common.h: run_parallel)
 static void ar_own(ArState *st, void *p) {
   std::lock_guard<std::mutex> lk(ar_own_mu);
@@ -1416,6 +1495,16 @@ static int fetch(tts_ctx *ctx, ArState *st, const WeightFile &wf, const std::str
   if (t.ne[0] != ne0 || t.ne[1] != ne1 || t.nelem() != ne0 * ne1)
     return fail(ctx, TTS_ERR_FORMAT, "tensor '%s' has wrong shape in model file: got [%d, %d], expected [%d, %d]",
                 name.c_str(), (int)t.ne[0], (int)t.ne[1], (int)ne0, (int)ne1);
+  if (t.data.empty() && t.file_off >= 0) { // left in the file (device-packing load): file -> pinned staging -> device
+    if (tile) return fail(ctx, TTS_ERR_STATE, "internal: strip-major re-layout of a tensor that was not read ('%s')", name.c_str());
+    void *p = nullptr;
+    TTS_HIP(ctx, hipMalloc(&p, (size_t)t.nelem() * 4));
+    ar_own(st, p);
+    const int r = ar_file_to_device(ctx, wf, t, name, p);
+    if (r) return r;
+    *dst = (float *)p;
+    return TTS_OK;
+  }
   if (tile) return upload(ctx, st, strip_major(t.data.data(), (int)ne1, (int)ne0), dst);
   return upload(ctx, st, t.data, dst);
 }
@@ -1424,16 +1513,19 @@ int ar_load(tts_ctx *ctx, const char *path) {
   static const bool timing = getenv("TTS_TIMING") != nullptr; // host-side breakdown on stderr
   const auto t0 = std::chrono::steady_clock::now();
   auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+  // (decided before the file is read: with device-side packing the large tensors stay in the file until a worker wants them)
+  const bool dev_pack = ctx->load_device_pack != 0 && ctx->load_threads != 1 && ctx->dec_f32_mfma == 0 && ctx->ar_weights == 0;
   WeightFile wf;
   std::string err;
-  int rc = read_weight_file(path, wf, err);
+  int rc = read_weight_file(path, wf, err, dev_pack ? (size_t)256 << 10 : (size_t)-1);
   const double t_read = since(t0);
   if (rc != TTS_OK) return fail(ctx, rc, "autoregressive_model_load: %s", err.c_str());
   static std::mutex load_mu; // one tts_load_ar at a time per process (ar_pin is shared)
   std::lock_guard<std::mutex> load_lk(load_mu);
   std::unique_ptr<ArState> st(new ArState());
-  PinnedPool pin;
+  PinnedPool pin{(size_t)18 << 20, 6};
   struct PinScope { PinnedPool *&slot; PinScope(PinnedPool *&s, PinnedPool *p) : slot(s) { slot = p; } ~PinScope() { slot = nullptr; } } pin_scope(ar_pin, ctx->load_threads == 1 ? nullptr : &pin);
+  ar_load_stream = ctx->load_stream;
   st->f32_mfma = ctx->dec_f32_mfma != 0;
   const std::string hp = "inference_model.transformer.h.";
   while (wf.has(hp + std::to_string(st->n_layers) + ".ln_1.weight")) st->n_layers++;
@@ -1447,6 +1539,54 @@ int ar_load(tts_ctx *ctx, const char *path) {
   }
 #define FETCH(name, a, b, dst) do { int _r = fetch(ctx, st.get(), wf, name, a, b, dst); if (_r) return _r; } while (0)
 #define FETCHT(name, a, b, dst) do { int _r = fetch(ctx, st.get(), wf, name, a, b, dst, true); if (_r) return _r; } while (0)
+  // Device-side re-layouts (option load_device_pack, default 1) for the default decode arithmetic; the reduced-precision slab options and the f32-MFMA variant keep the
+  // host packers (they are A/B options), and so does load_threads = 1 (the serial loader of rounds 1-5, kept as the reference for the equality test).
+  std::mutex tmp_mu;
+  std::vector<void *> temps; // file-order copies and folded matrices: freed once the packing kernels have run
+  // temporaries come out of ONE device allocation (a few hundred hipMalloc / hipFree pairs cost 0.1 s): the file's tensors once more + the gain-folded matrices + the head
+  char *arena = nullptr;
+  size_t arena_cap = 0;
+  std::atomic<size_t> arena_at{0};
+  if (dev_pack) {
+    size_t need = (size_t)st->n_layers * ((size_t)D * 3 * D + (size_t)D * FF) * 4 + (size_t)3 * D * VPAD * 4 + ((size_t)8 << 20);
+    for (auto &kv : wf.t) need += (size_t)kv.second.nelem() * 4 + 256;
+    if (hipMalloc((void **)&arena, need) == hipSuccess) arena_cap = need;
+    else (void)hipGetLastError(); // fall back to one allocation per temporary
+  }
+  struct ArenaFree { char *&p; ~ArenaFree() { if (p) (void)hipFree(p); } } arena_free{arena};
+  auto dalloc = [&](size_t bytes, bool temp) -> void * {
+    if (temp && arena) {
+      const size_t sz = (bytes + 255) & ~(size_t)255, at = arena_at.fetch_add(sz);
+      if (at + sz <= arena_cap) return arena + at;
+    }
+    void *q = nullptr;
+    if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); fail(ctx, TTS_ERR_HIP, "hipMalloc of %zu bytes failed while loading the AR model", bytes); return nullptr; }
+    if (temp) { std::lock_guard<std::mutex> lk(tmp_mu); temps.push_back(q); }
+    else ar_own(st.get(), q);
+    return q;
+  };
+  struct TempFree { std::vector<void *> &v; ~TempFree() { for (void *q : v) (void)hipFree(q); } } temp_free{temps};
+  auto pgrid = [](size_t n) { return (int)std::min<size_t>((n + 255) / 256, 8192); };
+  // the tensor as it lies in the file, shape-checked like fetch(), into a temporary device buffer
+  auto raw_up = [&](const std::string &name, int64_t ne0, int64_t ne1, float **dst) -> int {
+    auto it = wf.t.find(name);
+    if (it == wf.t.end()) return fail(ctx, TTS_ERR_FORMAT, "tensor '%s' missing from AR model file", name.c_str());
+    const HostTensor &t = it->second;
+    if (t.ne[0] != ne0 || t.ne[1] != ne1 || t.nelem() != ne0 * ne1)
+      return fail(ctx, TTS_ERR_FORMAT, "tensor '%s' has wrong shape in model file: got [%d, %d], expected [%d, %d]", name.c_str(), (int)t.ne[0], (int)t.ne[1], (int)ne0, (int)ne1);
+    void *q = dalloc((size_t)t.nelem() * 4, true);
+    if (!q) return TTS_ERR_HIP;
+    if (t.data.empty() && t.file_off >= 0) { const int r = ar_file_to_device(ctx, wf, t, name, q); if (r) return r; }
+    else TTS_HIP(ctx, ar_h2d(q, t.data.data(), (size_t)t.nelem() * 4));
+    *dst = (float *)q;
+    return TTS_OK;
+  };
+  unsigned *d_max = nullptr; // max |w| bits: per layer the four matrices, then the two gain-folded ones
+  if (dev_pack) {
+    d_max = (unsigned *)dalloc((size_t)st->n_layers * 6 * 4, true);
+    if (!d_max) return TTS_ERR_HIP;
+    TTS_HIP(ctx, hipMemsetAsync(d_max, 0, (size_t)st->n_layers * 6 * 4, ctx->stream));
+  }
   auto build_globals = [&]() -> int {
     FETCH("text_embedding.weight", D, 256, &st->text_emb);
     FETCH("text_pos_embedding.emb.weight", D, 404, &st->text_pos);
@@ -1466,11 +1606,42 @@ int ar_load(tts_ctx *ctx, const char *path) {
     ArLayerDev &l = st->L[i];
     FETCH(p + ".ln_1.weight", D, 1, &l.ln1_g); FETCH(p + ".ln_1.bias", D, 1, &l.ln1_b);
     FETCH(p + ".ln_2.weight", D, 1, &l.ln2_g); FETCH(p + ".ln_2.bias", D, 1, &l.ln2_b);
-    FETCHT(p + ".attn.c_attn.weight", 3 * D, D, &l.w_attn); FETCH(p + ".attn.c_attn.bias", 3 * D, 1, &l.b_attn);
-    FETCHT(p + ".attn.c_proj.weight", D, D, &l.w_proj); FETCH(p + ".attn.c_proj.bias", D, 1, &l.b_proj);
-    FETCHT(p + ".mlp.c_fc.weight", FF, D, &l.w_fc); FETCH(p + ".mlp.c_fc.bias", FF, 1, &l.b_fc);
-    FETCHT(p + ".mlp.c_proj.weight", D, FF, &l.w_fc2); FETCH(p + ".mlp.c_proj.bias", D, 1, &l.b_fc2);
+    FETCH(p + ".attn.c_attn.bias", 3 * D, 1, &l.b_attn); FETCH(p + ".attn.c_proj.bias", D, 1, &l.b_proj);
+    FETCH(p + ".mlp.c_fc.bias", FF, 1, &l.b_fc); FETCH(p + ".mlp.c_proj.bias", D, 1, &l.b_fc2);
     int r;
+    if (dev_pack) {
+      struct M { const char *name; int K, N; float **strip; float *raw; } m[4] = {
+          {".attn.c_attn.weight", D, 3 * D, &l.w_attn, nullptr}, {".attn.c_proj.weight", D, D, &l.w_proj, nullptr},
+          {".mlp.c_fc.weight", D, FF, &l.w_fc, nullptr}, {".mlp.c_proj.weight", FF, D, &l.w_fc2, nullptr}};
+      for (int j = 0; j < 4; j++) {
+        if ((r = raw_up(p + m[j].name, m[j].N, m[j].K, &m[j].raw))) return r;
+        const size_t n = (size_t)m[j].K * m[j].N;
+        if (!(*m[j].strip = (float *)dalloc(n * 4, false))) return TTS_ERR_HIP;
+        pk_strip_major_kernel<<<pgrid(n), 256, 0, ctx->stream>>>(m[j].raw, m[j].K, m[j].N, *m[j].strip);
+        pk_absmax_kernel<<<pgrid(n), 256, 0, ctx->stream>>>(m[j].raw, n, d_max + (size_t)i * 6 + j);
+      }
+      struct F { int j; const float *g, *b, *c; __half **dh; float **db; } f[2] = {{0, l.ln1_g, l.ln1_b, l.b_attn, &l.dh_attn, &l.db_attn},
+                                                                                   {2, l.ln2_g, l.ln2_b, l.b_fc, &l.dh_fc, &l.db_fc}};
+      for (int q = 0; q < 2; q++) { // LayerNorm gain folded into the matrix the normalised rows feed, then the split-fp16 decode slabs; beta . W + c as the new bias
+        const int N = m[f[q].j].N;
+        const size_t n = (size_t)D * N;
+        float *fold = (float *)dalloc(n * 4, true);
+        if (!fold || !(*f[q].dh = (__half *)dalloc(n * 2 * sizeof(__half), false)) || !(*f[q].db = (float *)dalloc((size_t)N * 4, false))) return TTS_ERR_HIP;
+        pk_fold_kernel<<<pgrid(n), 256, 0, ctx->stream>>>(m[f[q].j].raw, D, N, f[q].g, fold);
+        pk_absmax_kernel<<<pgrid(n), 256, 0, ctx->stream>>>(fold, n, d_max + (size_t)i * 6 + 4 + q);
+        pk_mfma16h_kernel<<<pgrid(n), 256, 0, ctx->stream>>>(fold, N, *f[q].dh);
+        pk_fold_bias_kernel<<<(N + 255) / 256, 256, 0, ctx->stream>>>(m[f[q].j].raw, D, N, f[q].b, f[q].c, *f[q].db);
+      }
+      if (!(l.d_proj = (float *)dalloc((size_t)D * D * 4, false)) || !(l.d_fc2 = (float *)dalloc((size_t)FF * D * 4, false))) return TTS_ERR_HIP;
+      pk_cols4_kernel<<<pgrid((size_t)D * D), 256, 0, ctx->stream>>>(m[1].raw, D, D, l.d_proj);
+      pk_cols4_kernel<<<pgrid((size_t)FF * D), 256, 0, ctx->stream>>>(m[3].raw, FF, D, l.d_fc2);
+      TTS_HIP(ctx, hipGetLastError());
+      return TTS_OK;
+    }
+    FETCHT(p + ".attn.c_attn.weight", 3 * D, D, &l.w_attn);
+    FETCHT(p + ".attn.c_proj.weight", D, D, &l.w_proj);
+    FETCHT(p + ".mlp.c_fc.weight", FF, D, &l.w_fc);
+    FETCHT(p + ".mlp.c_proj.weight", D, FF, &l.w_fc2);
     // The split-precision layouts hold 64 W as fp16 hi | lo (W16_SCALE): a trained GPT-2 never comes near |W| = 937, but a file that does must fail loudly instead of
     // turning into an fp16 infinity inside the MFMA operands (round 6; the diffusion stage's proj_out pair picks its scale per tensor instead)
     auto split_range = [&](const std::string &name, const float *w, size_t n) -> int {
@@ -1539,6 +1710,25 @@ int ar_load(tts_ctx *ctx, const char *path) {
     if (it == wf.t.end() || ib == wf.t.end()) return fail(ctx, TTS_ERR_FORMAT, "lm_head.1 missing from model file");
     if (it->second.ne[0] != D || it->second.ne[1] != V || ib->second.nelem() != V)
       return fail(ctx, TTS_ERR_FORMAT, "tensor 'inference_model.lm_head.1.weight' has wrong shape in model file");
+    if (dev_pack) {
+      std::vector<float> bt(VPAD, 0.f);
+      std::copy(ib->second.data.begin(), ib->second.data.end(), bt.begin());
+      int r = upload(ctx, st.get(), bt, &st->lm_b); if (r) return r;
+      float *rw = nullptr, *g0 = nullptr, *b0 = nullptr;
+      if ((r = raw_up("inference_model.lm_head.1.weight", D, V, &rw)) || (r = raw_up("inference_model.lm_head.0.weight", D, 1, &g0)) ||
+          (r = raw_up("inference_model.lm_head.0.bias", D, 1, &b0))) return r;
+      const size_t n = (size_t)D * VPAD;
+      float *wt = (float *)dalloc(n * 4, true), *fold = (float *)dalloc(n * 4, true);
+      if (!wt || !fold || !(st->lm_w = (float *)dalloc(n * 4, false)) || !(st->dh_lm = (__half *)dalloc(n * 2 * sizeof(__half), false)) ||
+          !(st->d_lmb = (float *)dalloc((size_t)VPAD * 4, false))) return TTS_ERR_HIP;
+      pk_transpose_pad_kernel<<<pgrid(n), 256, 0, ctx->stream>>>(rw, V, D, VPAD, wt);
+      pk_strip_major_kernel<<<pgrid(n), 256, 0, ctx->stream>>>(wt, D, VPAD, st->lm_w);
+      pk_fold_kernel<<<pgrid(n), 256, 0, ctx->stream>>>(wt, D, VPAD, g0, fold);
+      pk_mfma16h_kernel<<<pgrid(n), 256, 0, ctx->stream>>>(fold, VPAD, st->dh_lm);
+      pk_fold_bias_kernel<<<(VPAD + 255) / 256, 256, 0, ctx->stream>>>(wt, D, VPAD, b0, st->lm_b, st->d_lmb);
+      TTS_HIP(ctx, hipGetLastError());
+      return TTS_OK;
+    }
     std::vector<float> wt((size_t)D * VPAD, 0.f), bt(VPAD, 0.f);
     const float *w = it->second.data.data();
     for (int n = 0; n < V; n++)
@@ -1570,6 +1760,21 @@ int ar_load(tts_ctx *ctx, const char *path) {
   const auto t1 = std::chrono::steady_clock::now();
   const int nl = st->n_layers;
   if (int r = run_parallel(ctx, nl + 2, [&](int i) { return i == 0 ? build_head() : i == 1 ? build_globals() : build_layer(i - 2); })) return r; // the head (0.2 s) first
+  if (dev_pack) { // the range guard of the split-precision layouts, from the device's max |w| values, in the host path's order and words
+    TTS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<unsigned> mx((size_t)nl * 6);
+    TTS_HIP(ctx, hipMemcpy(mx.data(), d_max, mx.size() * 4, hipMemcpyDeviceToHost));
+    static const char *wn[6] = {".attn.c_attn.weight", ".attn.c_proj.weight", ".mlp.c_fc.weight", ".mlp.c_proj.weight", ".attn.c_attn.weight (LayerNorm gain folded in)",
+                                ".mlp.c_fc.weight (LayerNorm gain folded in)"};
+    static const int order[6] = {0, 1, 2, 3, 4, 5};
+    for (int i = 0; i < nl; i++)
+      for (int j : order) {
+        float m;
+        memcpy(&m, &mx[(size_t)i * 6 + j], 4);
+        if (!(m * W16_SCALE < 60000.0f))
+          return fail(ctx, TTS_ERR_FORMAT, "tensor '%s': max |w| = %g does not fit the split-precision fp16 layout (|w| < %g)", (hp + std::to_string(i) + wn[j]).c_str(), m, 60000.0 / W16_SCALE);
+      }
+  }
   const double t_layers = since(t1);
 #undef FETCH
 #undef FETCHT

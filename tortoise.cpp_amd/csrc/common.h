@@ -23,17 +23,27 @@
 namespace tts {
 
 struct HostTensor {
-  std::vector<float> data;
+  std::vector<float> data;  // empty for a tensor left in the file (file_off >= 0): see read_weight_file's lazy_from
   int64_t ne[4] = {1, 1, 1, 1};
   int n_dims = 0;
+  int64_t file_off = -1;    // byte offset of the payload in the file
   int64_t nelem() const { return ne[0] * ne[1] * ne[2] * ne[3]; }
 };
 // Name-keyed legacy-ggml container (format: main.cpp:811-888).
 struct WeightFile {
   std::map<std::string, HostTensor> t;
+  int fd = -1; // open while tensors are left in the file
+  WeightFile() = default;
+  WeightFile(const WeightFile &) = delete;
+  WeightFile &operator=(const WeightFile &) = delete;
+  ~WeightFile();
   bool has(const std::string &n) const { return t.count(n) != 0; }
+  // payload of a tensor that was left in the file, straight into dst (e.g. pinned staging memory); false on a short read
+  bool read_payload(const HostTensor &ht, void *dst) const;
 };
-int read_weight_file(const char *path, WeightFile &out, std::string &err);
+// lazy_from: payloads of at least this many bytes are NOT read (HostTensor::data stays empty, file_off says where they are; WeightFile::fd stays open) — the AR loader
+// reads them straight into pinned staging memory on its worker threads instead of through 1.6 GB of freshly faulted-in host vectors.
+int read_weight_file(const char *path, WeightFile &out, std::string &err, size_t lazy_from = (size_t)-1);
 
 // Grow-only device buffer.
 struct DevBuf {
@@ -89,6 +99,7 @@ void sampler_pool_free(SamplerPool *p);
 struct tts_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t load_stream = nullptr; // non-blocking: the loaders' uploads (a legacy-stream copy on a second thread is an error while `stream` captures a graph: the CLI loads the diffusion and vocoder models beside the AR stage)
   int stream_cus = 0; // option stream_cus: CUs per XCD this context's stream is confined to (> 0) / excluded from (< 0); 0 = whole chip
   std::string err;
   // options
@@ -135,6 +146,7 @@ struct tts_ctx {
   void *fp16_counts = nullptr;           // device: int64[2]
   int rng_fast_normal = 1; // option "rng_fast_normal": 0 = every normal draw through std::normal_distribution::operator() (A/B and the tests' reference for the fast form)
   int noise_pipeline = 1;  // option "noise_pipeline": TTS_NOISE_REFERENCE with one candidate draws a step's noise on the host while the device runs the previous steps (same draws in the same order)
+  int load_device_pack = 1; // option "load_device_pack": tts_load_ar builds its decode layouts with kernels from the uploaded file tensors (0: on the host threads)
   int load_threads = 0;    // option "load_threads": host threads of the tts_load_* calls (0 = min(16, hardware threads); 1 = single-threaded)
   int attn_q64 = 0; // option "attn_q64": diffusion attention with 64-query workgroups: 0 never (default: measured, no gain), 1 always, 2 = when the 128-query grid has at most 256 workgroups (bit-identical)
   int hoist_integrator = 1; // option "hoist_integrator": small diffusion batches evaluate the conditioning_timestep_integrator layers (which never see x_t) for all sampling steps before the loop, in benchmark-sized batches (bit-identical; 0 = inside every step)
@@ -190,12 +202,18 @@ struct PinnedPool {
     { std::lock_guard<std::mutex> lk(mu); idle.push_back(b); }
     cv.notify_one();
   }
-  // dst (device) <- src (pageable host); falls back to the plain copy when no pinned memory can be had
-  hipError_t upload(void *dst, const void *src, size_t bytes) {
+  // dst (device) <- src (pageable host), complete on return; on stream s when given (never the legacy stream then); falls back to the plain copy when no pinned
+  // memory can be had
+  static hipError_t copy_now(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    if (!s) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s);
+    return e != hipSuccess ? e : hipStreamSynchronize(s);
+  }
+  hipError_t upload(void *dst, const void *src, size_t bytes, hipStream_t s = nullptr) {
     auto b = take(bytes);
-    if (!b.first) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    if (!b.first) return copy_now(dst, src, bytes, s);
     memcpy(b.first, src, bytes);
-    const hipError_t e = hipMemcpy(dst, b.first, bytes, hipMemcpyHostToDevice);
+    const hipError_t e = copy_now(dst, b.first, bytes, s);
     give(b);
     return e;
   }

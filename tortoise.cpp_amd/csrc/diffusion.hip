@@ -977,7 +977,7 @@ struct Loader { // its jobs run on several threads (common.h: run_parallel): `us
     void *p = nullptr;
     TTS_HIP(ctx, hipMalloc(&p, h.size() * sizeof(T)));
     { std::lock_guard<std::mutex> lk(mu); st->owned.push_back(p); }
-    TTS_HIP(ctx, pin.upload(p, h.data(), h.size() * sizeof(T)));
+    TTS_HIP(ctx, pin.upload(p, h.data(), h.size() * sizeof(T), ctx->load_stream));
     *dst = (T *)p;
     return TTS_OK;
   }

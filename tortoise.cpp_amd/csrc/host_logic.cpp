@@ -139,7 +139,21 @@ void rng_normal_fill(tts_ctx *ctx, float *dst, int64_t n) {
 // (vocoder): u32 magic 'ggml', then {i32 n_dims, i32 name_len, i32 ttype, i32 ne[n_dims], name,
 // data} until EOF. Only F32 (ttype 0) occurs in the published files.
 // ---------------------------------------------------------------------------------------------
-int read_weight_file(const char *path, WeightFile &out, std::string &err) {
+WeightFile::~WeightFile() { if (fd >= 0) close(fd); }
+bool WeightFile::read_payload(const HostTensor &ht, void *dst) const {
+  if (fd < 0 || ht.file_off < 0) return false;
+  char *p = (char *)dst;
+  size_t left = (size_t)ht.nelem() * sizeof(float);
+  long long off = ht.file_off;
+  while (left > 0) {
+    const ssize_t g = pread(fd, p, left, (off_t)off);
+    if (g <= 0) return false;
+    p += g; off += g; left -= (size_t)g;
+  }
+  return true;
+}
+
+int read_weight_file(const char *path, WeightFile &out, std::string &err, size_t lazy_from) {
   // Two passes (round 6): the record headers are walked with seeks, then the tensor payloads (1.6 GB for the AR model) are read by a few threads with pread() —
   // the single fread() pass of rounds 1-5 spent as long zero-filling and copying as the page cache took to deliver.
   FILE *f = fopen(path, "rb");
@@ -183,8 +197,10 @@ int read_weight_file(const char *path, WeightFile &out, std::string &err) {
     const long long off = ftello(f);
     if (want > (unsigned long long)(file_size - off)) { fclose(f); err = "tensor '" + name + "' truncated"; return TTS_ERR_IO; }
     if (fseeko(f, (off_t)want, SEEK_CUR) != 0) { fclose(f); err = "tensor '" + name + "' truncated"; return TTS_ERR_IO; }
+    t.file_off = off;
     auto ins = out.t.emplace(name, std::move(t)); // a repeated name keeps its first record, as the single-pass reader did
-    if (ins.second) pend.push_back(Pending{&ins.first->second, off, std::move(name)});
+    if (ins.second && want < (unsigned long long)lazy_from) pend.push_back(Pending{&ins.first->second, off, std::move(name)});
+    else if (ins.second && out.fd < 0) out.fd = dup(fileno(f));
   }
   const int fd = fileno(f);
   const int n = (int)pend.size();

@@ -374,7 +374,7 @@ struct VLoader {
     void *p = nullptr;
     TTS_HIP(ctx, hipMalloc(&p, h.size() * sizeof(T)));
     st->owned.push_back(p);
-    TTS_HIP(ctx, hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    TTS_HIP(ctx, PinnedPool::copy_now(p, h.data(), h.size() * sizeof(T), ctx->load_stream)); // not the legacy stream: this load may run beside a capturing AR stage
     *dst = (T *)p;
     return TTS_OK;
   }
