@@ -111,7 +111,8 @@ const char *tts_last_error(const tts_ctx *ctx);
  * opt-in. Measured gain: 2-5 % of the single-utterance diffusion stage (138.7 -> 135.7 ms in the bench line, profiles/r6_small_batch.txt); it loses above one utterance.
  * "hoist_integrator" (1 default), "attn_q64" (0 default): INTEGRATION.md; both bit-identical to the setting they replace.
  * "fp16_check" (0 default): see tts_diffusion_fp16_check.
- * "load_threads" (0 default = min(16, hardware threads); set BEFORE tts_load_*): host threads that build and upload the device layouts; 1 = serial.
+ * "load_threads" (0 default = min(16, hardware threads); set BEFORE tts_load_*): host threads that read, upload and (diffusion) re-lay-out the tensors; 1 = serial.
+ * "load_device_pack" (1 default; set BEFORE tts_load_ar): decode layouts built by kernels from the uploaded file tensors (0: by the host threads). Same bits.
  * "noise_pipeline", "rng_fast_normal" (1 default): production of TTS_NOISE_REFERENCE draws (beside the device loop; two-phase normal distribution). Results and the RNG
  * state afterwards are those of single std::normal_distribution draws either way (tests/test_host_parity.py); 0 = the single-draw forms. */
 int tts_set_option(tts_ctx *ctx, const char *key, double value);
