@@ -1554,10 +1554,25 @@ int ar_load(tts_ctx *ctx, const char *path) {
     else (void)hipGetLastError(); // fall back to one allocation per temporary
   }
   struct ArenaFree { char *&p; ~ArenaFree() { if (p) (void)hipFree(p); } } arena_free{arena};
+  // ... and so do the layouts that stay (4.4 GB in ~400 pieces: one hipMalloc now, one hipFree in tts_destroy)
+  char *keep = nullptr;
+  size_t keep_cap = 0;
+  std::atomic<size_t> keep_at{0};
+  if (dev_pack) {
+    const size_t per_layer = ((size_t)12 * D * D) * 4 /* strip-major f32 */ + ((size_t)7 * D * D) * 4 /* split-fp16 decode slabs */ + ((size_t)5 * D * D) * 4 /* 4-column slabs */ +
+                             ((size_t)12 * D * D) * 4 /* hi | lo copies for the multi-row passes */ + (size_t)(3 * D + FF) * 4 + 64 * 256;
+    const size_t need = (size_t)st->n_layers * per_layer + (size_t)D * VPAD * 8 + (size_t)VPAD * 4 + ((size_t)1 << 20);
+    if (hipMalloc((void **)&keep, need) == hipSuccess) { keep_cap = need; ar_own(st.get(), keep); }
+    else (void)hipGetLastError();
+  }
   auto dalloc = [&](size_t bytes, bool temp) -> void * {
     if (temp && arena) {
       const size_t sz = (bytes + 255) & ~(size_t)255, at = arena_at.fetch_add(sz);
       if (at + sz <= arena_cap) return arena + at;
+    }
+    if (!temp && keep) {
+      const size_t sz = (bytes + 255) & ~(size_t)255, at = keep_at.fetch_add(sz);
+      if (at + sz <= keep_cap) return keep + at;
     }
     void *q = nullptr;
     if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); fail(ctx, TTS_ERR_HIP, "hipMalloc of %zu bytes failed while loading the AR model", bytes); return nullptr; }
@@ -1783,9 +1798,8 @@ int ar_load(tts_ctx *ctx, const char *path) {
     struct { const float *w; int K, N; __half **dst; } jobs[4] = {
         {l.w_attn, D, 3 * D, &l.s_attn}, {l.w_proj, D, D, &l.s_proj}, {l.w_fc, D, FF, &l.s_fc}, {l.w_fc2, FF, D, &l.s_fc2}};
     for (auto &j : jobs) {
-      void *p = nullptr;
-      TTS_HIP(ctx, hipMalloc(&p, (size_t)j.N * 2 * j.K * sizeof(__half)));
-      st->owned.push_back(p);
+      void *p = dalloc((size_t)j.N * 2 * j.K * sizeof(__half), false);
+      if (!p) return TTS_ERR_HIP;
       split_weight_kernel<<<dim3(j.N / 32, j.K / 32), 256, 0, ctx->stream>>>(j.w, j.K, j.N, (__half *)p);
       *j.dst = (__half *)p;
     }

@@ -96,11 +96,18 @@ void rng_normal_fill(tts_ctx *ctx, float *dst, int64_t n) {
     for (int64_t i = 0; i < n; i++) dst[i] = nd(ctx->generator);
     return;
   }
+  // (nothing has touched the generator yet: if the pair buffer cannot be had, the single-draw form does the whole job)
+  std::vector<PolarPair> pp;
+  try {
+    pp.resize((size_t)(n + 1) / 2);
+  } catch (...) {
+    for (int64_t i = 0; i < n; i++) dst[i] = nd(ctx->generator);
+    return;
+  }
   int64_t at = 0;
   double saved = 0;
   if (normal_saved(nd, saved)) dst[at++] = as_returned(saved); // the cached second value of an earlier pair comes first
   const int64_t left = n - at, pairs = (left + 1) / 2;
-  std::vector<PolarPair> pp((size_t)pairs);
   std::mt19937 &g = ctx->generator;
   for (int64_t i = 0; i < pairs; i++) { // the sequential part: generator calls and the accept test
     double x, y, r2;
@@ -127,8 +134,14 @@ void rng_normal_fill(tts_ctx *ctx, float *dst, int64_t n) {
   if (nt <= 1) finish(0, pairs);
   else {
     std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back(finish, pairs * t / nt, pairs * (t + 1) / nt);
+    int started = 1; // ranges [pairs t / nt, pairs (t + 1) / nt): range 0 is this thread's; a thread that cannot be created leaves its range (and the rest) to this one
+    try {
+      th.reserve((size_t)nt);
+      for (; started < nt; started++) th.emplace_back(finish, pairs * started / nt, pairs * (started + 1) / nt);
+    } catch (...) {
+    }
     finish(0, pairs / nt);
+    if (started < nt) finish(pairs * started / nt, pairs);
     for (auto &t : th) t.join();
   }
   normal_set_saved(nd, (left & 1) != 0, last_second);
