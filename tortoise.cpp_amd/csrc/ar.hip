@@ -212,7 +212,14 @@ __global__ __launch_bounds__(256) void pk_fold_bias_kernel(const float *__restri
   const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= N) return;
   double acc = 0.0;
-  for (int k = 0; k < K; k++) acc += (double)b[k] * (double)w[(size_t)k * N + n];
+  for (int k0 = 0; k0 < K; k0 += 16) { // 16 independent loads in flight, then the 16 additions in ascending k (a first version waited for every load: 280 us per launch)
+    float wv[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) wv[j] = k0 + j < K ? w[(size_t)(k0 + j) * N + n] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+      if (k0 + j < K) acc += (double)b[k0 + j] * (double)wv[j];
+  }
   cf[n] = (float)((double)c[n] + acc);
 }
 // pack_mfma16h: one thread per weight (K = 1024)
@@ -248,10 +255,16 @@ __global__ __launch_bounds__(256) void pk_transpose_pad_kernel(const float *__re
 }
 // max |w| into *out (bits of a non-negative float order like unsigned integers; a NaN ends up above every number and fails the range check loudly)
 __global__ __launch_bounds__(256) void pk_absmax_kernel(const float *__restrict__ w, size_t n, unsigned *__restrict__ out) {
+  __shared__ unsigned wm[4];
   unsigned m = 0;
   for (size_t o = (size_t)blockIdx.x * 256 + threadIdx.x; o < n; o += (size_t)gridDim.x * 256) m = max(m, __float_as_uint(fabsf(w[o])));
   for (int off = 32; off; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) { // one atomic per workgroup (32 K waves hitting one address took 340 us per launch)
+    m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+    if (m) atomicMax(out, m);
+  }
 }
 // x f32 [rows][K] -> hi, lo fp16 [rows_pad][K] (pad rows zero)
 __global__ __launch_bounds__(256) void split_act_kernel(const float *__restrict__ x, int rows, int K, __half *__restrict__ hi,
@@ -1633,7 +1646,7 @@ int ar_load(tts_ctx *ctx, const char *path) {
         const size_t n = (size_t)m[j].K * m[j].N;
         if (!(*m[j].strip = (float *)dalloc(n * 4, false))) return TTS_ERR_HIP;
         pk_strip_major_kernel<<<pgrid(n), 256, 0, ctx->stream>>>(m[j].raw, m[j].K, m[j].N, *m[j].strip);
-        pk_absmax_kernel<<<pgrid(n), 256, 0, ctx->stream>>>(m[j].raw, n, d_max + (size_t)i * 6 + j);
+        pk_absmax_kernel<<<std::min(pgrid(n), 1024), 256, 0, ctx->stream>>>(m[j].raw, n, d_max + (size_t)i * 6 + j);
       }
       struct F { int j; const float *g, *b, *c; __half **dh; float **db; } f[2] = {{0, l.ln1_g, l.ln1_b, l.b_attn, &l.dh_attn, &l.db_attn},
                                                                                    {2, l.ln2_g, l.ln2_b, l.b_fc, &l.dh_fc, &l.db_fc}};
@@ -1643,7 +1656,7 @@ int ar_load(tts_ctx *ctx, const char *path) {
         float *fold = (float *)dalloc(n * 4, true);
         if (!fold || !(*f[q].dh = (__half *)dalloc(n * 2 * sizeof(__half), false)) || !(*f[q].db = (float *)dalloc((size_t)N * 4, false))) return TTS_ERR_HIP;
         pk_fold_kernel<<<pgrid(n), 256, 0, ctx->stream>>>(m[f[q].j].raw, D, N, f[q].g, fold);
-        pk_absmax_kernel<<<pgrid(n), 256, 0, ctx->stream>>>(fold, n, d_max + (size_t)i * 6 + 4 + q);
+        pk_absmax_kernel<<<std::min(pgrid(n), 1024), 256, 0, ctx->stream>>>(fold, n, d_max + (size_t)i * 6 + 4 + q);
         pk_mfma16h_kernel<<<pgrid(n), 256, 0, ctx->stream>>>(fold, N, *f[q].dh);
         pk_fold_bias_kernel<<<(N + 255) / 256, 256, 0, ctx->stream>>>(m[f[q].j].raw, D, N, f[q].b, f[q].c, *f[q].db);
       }
