@@ -151,6 +151,37 @@ def test_cli_devices_shards_reproduce_the_single_process_batch(small_models, tmp
         assert a.shape == b.shape and np.abs(a - b).max() <= 1e-4 * max(1e-6, np.abs(a).max()), (c, errs["two"][-600:])
 
 
+@pytest.mark.parametrize("models", ["small", "full"])
+def test_cli_round6_load_and_noise_paths_write_the_same_file(small_models, full_models, tmp_path, models):
+    """One utterance through the CLI (one candidate: the reference's RNG order) with the round-6 defaults — AR layouts built by kernels from pinned uploads on worker
+    threads, the diffusion and vocoder models loaded on a second thread while the AR stage loads and runs, the noise of step k + 1 drawn beside step k in the two-phase
+    form of the normal distribution — and with all of that switched off (the loaders and draws of rounds 1-5): the two WAV files are equal byte for byte, three times
+    in a row for the default (the second thread races the AR stage's graph capture; profiles/r6_cli_wall.txt)."""
+    import shutil
+    exe = os.path.join(ROOT, "tortoise.cpp_amd", "tortoise")
+    if not os.path.exists(exe):
+        pytest.skip("CLI binary not built")
+    src = small_models if models == "small" else full_models
+    d = tmp_path / "models"
+    d.mkdir()
+    for f in ("ggml-model.bin", "ggml-diffusion-model.bin", "ggml-vocoder-model.bin"):
+        os.symlink(os.path.join(src, f), d / f)
+    shutil.copy(os.path.join(ROOT, "models", "tokenizer.json"), d / "tokenizer.json")
+    base = [exe, "--models", str(d), "--message", "this is a test message.", "--voice", os.path.join(ROOT, "models", "mol.bin"), "--seed", "3", "--codes", "48", "--timing", "1"]
+    old = ["--option", "load_threads=1", "--option", "load_device_pack=0", "--option", "noise_pipeline=0", "--option", "rng_fast_normal=0"]
+    got = {}
+    for tag, extra in (("old", old), ("new1", []), ("new2", []), ("new3", [])):
+        out = tmp_path / (tag + ".wav")
+        r = subprocess.run(base + ["--output", str(out)] + extra, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and out.exists(), r.stdout + r.stderr
+        got[tag] = out.read_bytes()
+        if tag in ("old", "new1"):
+            print("%s weights, %s: %s" % (models, tag, " | ".join(l.split("]")[1].strip() for l in r.stderr.splitlines() if l.startswith("[timing]") and ("load" in l or "wait" in l))))
+    assert len(got["old"]) > 44 + 4 * 1000
+    for tag in ("new1", "new2", "new3"):
+        assert got[tag] == got["old"], tag
+
+
 def test_cli_clvp_reranking_single_process_and_shards(small_models, tmp_path):
     """`tortoise --clvp <file>` (extension): the candidates are scored with CLVP, only the best one is carried through diffusion +
     vocoder and written to --output. A single process and two --devices workers (both on device 0) must keep the SAME candidate (the codes of

@@ -362,18 +362,18 @@ int voc_halo_frames() { return TTS_VOC_CHUNK_HALO; }
 
 namespace {
 struct VLoader {
-  tts_ctx *ctx; VocState *st; const WeightFile &wf; std::map<std::string, bool> used;
+  tts_ctx *ctx; VocState *st; const WeightFile &wf; std::map<std::string, bool> used; std::mutex mu; // the three res stacks load on their own threads
   const HostTensor *get(const std::string &name, int64_t nelem) {
     auto it = wf.t.find(name);
     if (it == wf.t.end()) { fail(ctx, TTS_ERR_FORMAT, "tensor '%s' missing from vocoder model file", name.c_str()); return nullptr; }
     if (it->second.nelem() != nelem) { fail(ctx, TTS_ERR_FORMAT, "tensor '%s' has wrong size in model file", name.c_str()); return nullptr; }
-    used[name] = true;
+    { std::lock_guard<std::mutex> lk(mu); used[name] = true; }
     return &it->second;
   }
   template <class T> int put(const std::vector<T> &h, T **dst) {
     void *p = nullptr;
     TTS_HIP(ctx, hipMalloc(&p, h.size() * sizeof(T)));
-    st->owned.push_back(p);
+    { std::lock_guard<std::mutex> lk(mu); st->owned.push_back(p); }
     TTS_HIP(ctx, PinnedPool::copy_now(p, h.data(), h.size() * sizeof(T), ctx->load_stream)); // not the legacy stream: this load may run beside a capturing AR stage
     *dst = (T *)p;
     return TTS_OK;
@@ -420,10 +420,8 @@ int voc_load(tts_ctx *ctx, const char *path) {
   std::unique_ptr<VocState> st(new VocState());
   VLoader ld{ctx, st.get(), wf, {}};
 #define R(x) do { int _r = (x); if (_r) return _r; } while (0)
-  R(ld.conv_kcc("conv_pre.weight", 32, 64, 7, true, &st->pre_w));
-  R(ld.f32("conv_pre.bias", 32, &st->pre_b));
   const int strides[3] = {8, 8, 4};
-  for (int i = 0; i < 3; i++) {
+  auto load_stack = [&](int i) -> int { // one res stack (kernel predictor incl. its 4.7 M-weight kernel_conv, transposed conv, conv blocks)
     std::string rs = "res_stack." + std::to_string(i) + ".", kp = rs + "kernel_predictor.";
     KpDev &k = st->kp[i];
     R(ld.conv_kcc(kp + "input_conv.0.weight", 64, 100, 5, true, &k.in_w));
@@ -465,7 +463,11 @@ int voc_load(tts_ctx *ctx, const char *path) {
       R(ld.conv_kcc(p + ".weight", 32, 32, 3, true, &st->cb_w[i][c]));
       R(ld.f32(p + ".bias", 32, &st->cb_b[i][c]));
     }
-  }
+    return TTS_OK;
+  };
+  auto load_ends = [&]() -> int {
+  R(ld.conv_kcc("conv_pre.weight", 32, 64, 7, true, &st->pre_w));
+  R(ld.f32("conv_pre.bias", 32, &st->pre_b));
   { // conv_post.1.weight ne=[7,32]: w[ci*7 + k] -> [k][ci], fp16-rounded
     const HostTensor *t = ld.get("conv_post.1.weight", 7 * 32);
     if (!t) return TTS_ERR_FORMAT;
@@ -475,7 +477,10 @@ int voc_load(tts_ctx *ctx, const char *path) {
     R(ld.put(h, &st->post_w));
     R(ld.f32("conv_post.1.bias", 1, &st->post_b));
   }
+  return TTS_OK;
+  };
 #undef R
+  if (int r = run_parallel(ctx, 4, [&](int j) { return j < 3 ? load_stack(j) : load_ends(); })) return r;
   for (auto &kv : wf.t)
     if (!ld.used.count(kv.first)) return fail(ctx, TTS_ERR_FORMAT, "unknown tensor '%s' in model file", kv.first.c_str());
   if (ctx->voc) voc_free(ctx->voc);
